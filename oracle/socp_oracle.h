@@ -1,0 +1,87 @@
+/*
+ * socp_oracle.h -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * Plain-C restatement of the SOCP hot path (batched state+costate integration,
+ * shooting residual, finite-difference / variational Jacobian).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this; the
+ * product (socp_amd/) never links or calls it.
+ *
+ * Pinning: the reference ships no golden data and no asserting tests
+ * (SURVEY.md 8c), so this restatement is pinned against outputs of the
+ * reference itself, compiled here from /root/reference into oracle/_ref/
+ * (see oracle/Makefile, oracle/ref_driver.cpp) and frozen as fixtures under
+ * tests/golden/ (generator: tests/golden/make_golden.py).
+ *
+ * Every function cites the reference file:line whose arithmetic ORDER it
+ * follows; all arithmetic is IEEE double, compiled with -ffp-contract=off.
+ */
+#ifndef SOCP_ORACLE_H_
+#define SOCP_ORACLE_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { ORC_MODEL_GODDARD = 1, ORC_MODEL_DOUBLE_INTEGRATOR = 2 };
+enum { ORC_FIXED = 0, ORC_FREE = 1, ORC_CONTINUOUS = 2 };   /* model.hpp:34-38 */
+
+#define ORC_MAX_PARAMS 8
+#define ORC_MAX_SWITCH 64
+
+/* Goddard parameter slots (goddard.hpp:28-37, goddard.cpp:31-39) */
+enum { GP_C = 0, GP_B, GP_KD, GP_KR, GP_UMAX, GP_MU1, GP_MU2, GP_SING };
+/* doubleIntegrator parameter slots (doubleIntegrator.hpp:24-28) */
+enum { DP_UMAX = 0, DP_AMAX, DP_MUT };
+
+typedef struct {
+    int model_id;                 /* ORC_MODEL_* */
+    int dim;                      /* state dimension d (7 / 6) */
+    int step_nbr;                 /* model::stepNbr */
+    double p[ORC_MAX_PARAMS];     /* packed parameters */
+    int nsw;                      /* number of switching times pushed by ComputeTimeLine */
+    double sw[ORC_MAX_SWITCH];    /* goddard data->switchingTimes */
+} orc_model;
+
+typedef struct {
+    int dim;                      /* d */
+    int num_multi;                /* M */
+    const int *mode_t;            /* [M+1] */
+    const int *mode_x;            /* [(M+1)*d] */
+    const double *time;           /* [M+1]   data->time (current, after continuation blend) */
+    const double *xnode;          /* [(M+1)*2d] data->X (only first d of each row is read) */
+} orc_problem;
+
+/* ---- model layer ---- */
+void orc_model_init(orc_model *m, int model_id);      /* defaults of the reference ctors */
+int  orc_state_len(const orc_model *m, int is_jac);   /* 2d or (2d+1)*2d */
+void orc_control(const orc_model *m, double t, const double *X, double *u3);
+void orc_rhs(const orc_model *m, double t, const double *X, int is_jac, double *Xdot);
+/* is_jac==0: writes H[0]; is_jac==1: writes dH/dX (2d+1 values) */
+void orc_hamiltonian(const orc_model *m, double t, const double *X, int is_jac, double *H);
+double orc_goddard_singular_control(const orc_model *m, double t, const double *X);
+
+/* ---- ODE layer ---- */
+void orc_rk4_step(const orc_model *m, double t, double *X, double step, int is_jac);
+/* returns number of RK4 steps taken */
+long orc_integrate(const orc_model *m, double *X, double t0, double tf, double dt, int is_jac);
+long orc_model_int(const orc_model *m, double t0, const double *X0, double tf, int is_jac, double *Xf);
+/* batch of independent trajectories, one per row; aux_sw may be NULL, else [B][2] */
+void orc_integrate_batch(const orc_model *m, int B, const double *t0, const double *tf,
+                         const double *aux_sw, const double *X0, double *Xf, int is_jac);
+
+/* ---- shooting layer ---- */
+int  orc_num_param(const orc_problem *p);
+void orc_compute_timeline(orc_model *m, const orc_problem *p, const double *z, double *timeline);
+void orc_shooting_function(orc_model *m, const orc_problem *p, const double *z, double *fvec);
+/* row-major n x n, as the reference assembles it before the hand-over transpose */
+void orc_shooting_jacobian(orc_model *m, const orc_problem *p, const double *z, double *fjac_rm);
+/* MINPACK fdjac1 as hybrd drives it (dense): fjac column-major, ldfjac = n */
+void orc_fdjac1(orc_model *m, const orc_problem *p, const double *z, const double *fvec,
+                double epsfcn, double *fjac_cm);
+/* residual for a batch of unknown vectors Z[B][n] -> F[B][n] */
+void orc_residual_batch(orc_model *m, const orc_problem *p, int B, const double *Z, double *F);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
