@@ -1,0 +1,131 @@
+/*
+ * socp_hip.h -- C-ABI of the MI355X (gfx950) hot path of SOCP.
+ *
+ * Plain C types only (pointers, sizes, int status); no C++ or torch types cross this line.
+ * Each entry point names the reference interface it replaces (file:line into bherisse/socp).
+ * Host programs reach it either directly (ctypes / dlopen) or through the C++ mirror of the
+ * reference's own classes in socp_amd/host/ (model, goddard, doubleIntegrator, shooting).
+ *
+ * Conventions
+ *   - every function returns SOCP_OK (0) or a negative SOCP_ERR_*; socp_last_error() gives text.
+ *     No exceptions cross the boundary.  There is NO CPU fallback: without a HIP device
+ *     socp_ctx_create fails with SOCP_ERR_NO_DEVICE.
+ *   - "_dev" variants take DEVICE pointers and only enqueue work on the context's stream
+ *     (inputs already resident in HBM); the plain variants take HOST pointers, copy in,
+ *     run, copy out and synchronise.
+ *   - all reals are IEEE double (commonType.hpp:16, real = double).
+ *   - state vectors are [state(d) ; costate(d)], s = 2d doubles (Appendix B of SURVEY.md);
+ *     batches are row-major, one trajectory / unknown vector per row.
+ */
+#ifndef SOCP_HIP_H_
+#define SOCP_HIP_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SOCP_OK               0
+#define SOCP_ERR_ARG         -1   /* bad argument / inconsistent problem description */
+#define SOCP_ERR_HIP         -2   /* a HIP runtime call failed */
+#define SOCP_ERR_NO_DEVICE   -3   /* no gfx950 device visible: the product does not run on CPU */
+#define SOCP_ERR_UNSUPPORTED -4   /* model / mode combination without a device implementation */
+
+/* in-tree device dynamics (twins of src/models/goddard, src/models/doubleIntegrator) */
+#define SOCP_MODEL_GODDARD            1   /* dim 7, goddard.cpp:48-295 */
+#define SOCP_MODEL_DOUBLE_INTEGRATOR  2   /* dim 6, doubleIntegrator.cpp:49-300 */
+
+/* packed parameter block, refreshed before every Newton solve (parameters are mutated by the
+ * continuation loop through a raw real&, shooting.cpp:695-707) */
+#define SOCP_GODDARD_NPARAMS 8   /* C, b, KD, kr, u_max, mu1, mu2, singularControl (goddard.hpp:28-37) */
+#define SOCP_DINT_NPARAMS    3   /* u_max, a_max, muT (doubleIntegrator.hpp:24-28) */
+
+/* time / state modes, model.hpp:34-38 */
+#define SOCP_FIXED      0
+#define SOCP_FREE       1
+#define SOCP_CONTINUOUS 2
+
+/* kernel variants behind one call */
+#define SOCP_VARIANT_AUTO       0   /* chosen from batch size */
+#define SOCP_VARIANT_LANE_EXACT 1   /* one trajectory per lane, reference operation order, no FMA contraction */
+#define SOCP_VARIANT_LANE_FAST  2   /* one trajectory per lane, reciprocal/FMA-restructured arithmetic */
+#define SOCP_VARIANT_WAVE       3   /* one trajectory per wavefront, state staged in LDS (latency variant) */
+
+/* what socp_eval_batch computes */
+#define SOCP_EVAL_RHS         0   /* odeTools.hpp:82  Model(t, X, isJac)      -> len(X) values  */
+#define SOCP_EVAL_CONTROL     1   /* model.hpp:375    Control(t, X)           -> 3 values       */
+#define SOCP_EVAL_HAMILTONIAN 2   /* model.hpp:384    Hamiltonian(t, X, 0)    -> 1 value        */
+
+typedef struct socp_ctx socp_ctx;
+
+/* ---- context ---------------------------------------------------------------------------- */
+/* replaces: construction of a model object + its parameters (goddard.cpp:23-40,
+ * doubleIntegrator.cpp:26-34).  device < 0 selects the current HIP device. */
+int socp_ctx_create(socp_ctx **ctx, int model_id, int device);
+int socp_ctx_destroy(socp_ctx *ctx);
+const char *socp_last_error(const socp_ctx *ctx);   /* ctx may be NULL: last creation error */
+
+int socp_ctx_set_params(socp_ctx *ctx, const double *params, int nparams);
+int socp_ctx_get_params(const socp_ctx *ctx, double *params, int nparams);
+int socp_ctx_set_step_number(socp_ctx *ctx, int step_nbr);      /* model::stepNbr, model.hpp:367 */
+int socp_ctx_set_switching_times(socp_ctx *ctx, const double *sw, int nsw);  /* goddard.cpp:373-377 */
+int socp_ctx_set_variant(socp_ctx *ctx, int variant);
+int socp_ctx_set_stream(socp_ctx *ctx, void *hip_stream);       /* hipStream_t; NULL = context's own */
+int socp_ctx_synchronize(socp_ctx *ctx);
+int socp_ctx_dims(const socp_ctx *ctx, int *dim, int *state_len, int *state_len_jac);
+
+/* counters since creation: trajectories integrated, kernel launches */
+int socp_ctx_counters(const socp_ctx *ctx, long long *trajectories, long long *launches);
+
+/* ---- batched trajectory integration ------------------------------------------------------ */
+/* replaces: shooting::Move -> model::ComputeTraj -> ModelInt -> odeTools::integrate -> RK4
+ * (shooting.cpp:365-372, model.hpp:77-79,395-414, goddard.cpp:298-317, odeTools.cpp:89-98,128-146),
+ * once per row.  t0,tf: [B]; sw: NULL (use the context's switching times) or [B][2];
+ * X0,Xf: [B][len], len = s (is_jac = 0) or (s+1)*s (is_jac = 1, variational state, identity
+ * block supplied by the caller exactly as shooting.cpp:1003-1005 builds it).  Xf may alias X0. */
+int socp_integrate_batch(socp_ctx *ctx, int B, const double *t0, const double *tf,
+                         const double *sw, const double *X0, double *Xf, int is_jac);
+int socp_integrate_batch_dev(socp_ctx *ctx, int B, const double *d_t0, const double *d_tf,
+                             const double *d_sw, const double *d_X0, double *d_Xf, int is_jac);
+
+/* replaces: model::Model / Control / Hamiltonian called outside the integrator (trace,
+ * free-time rows).  t: [B]; X: [B][len]; out: [B][out_len]. */
+int socp_eval_batch(socp_ctx *ctx, int what, int B, const double *t, const double *sw,
+                    const double *X, int len, double *out, int is_jac);
+
+/* ---- shooting problem --------------------------------------------------------------------- */
+/* replaces: the part of shooting::data_struct the residual reads (shooting.cpp:21-35):
+ * numMulti M, mode_t[M+1], mode_X[M+1][d], current node times time[M+1] and node states
+ * X[M+1][2d] (only the first d of each row is read).  Must be re-sent when the continuation
+ * loop blends the boundary data (shooting.cpp:609-611). */
+int socp_problem_set(socp_ctx *ctx, int num_multi, const int *mode_t, const int *mode_x,
+                     const double *time, const double *xnode);
+int socp_problem_num_param(const socp_ctx *ctx);   /* n = 2 d M + #FREE times (shooting.cpp:179,196) */
+
+/* replaces: shooting::ComputeTimeLine (shooting.cpp:1579-1617) for one unknown vector */
+int socp_timeline(socp_ctx *ctx, const double *z, double *timeline);
+
+/* replaces: shooting::StaticShootingFunction -> ShootingFunction[Parallel]
+ * (shooting.cpp:859-874,918-993,1133-1158,1215-1307), for B unknown vectors at once:
+ * Z[B][n] -> F[B][n].  One trajectory per (row, segment); every trajectory writes its own
+ * residual slots, as the reference's threads do. */
+int socp_residual_batch(socp_ctx *ctx, int B, const double *Z, double *F);
+int socp_residual_batch_dev(socp_ctx *ctx, int B, const double *d_Z, double *d_F);
+
+/* replaces: MINPACK fdjac1 as hybrd drives it (call site shooting.cpp:803-826):
+ * J[:,j] = (F(z + h_j e_j) - fvec) / h_j, h_j = sqrt(max(epsfcn, eps_mach)) * |z_j| (or that
+ * factor itself when z_j == 0).  fjac is column-major with leading dimension n.  The n
+ * perturbed residuals are one batch.  dedup != 0 integrates only the segments a column can
+ * change (bit-identical result, fewer trajectories; SURVEY 7 "free win"). */
+int socp_fd_jacobian(socp_ctx *ctx, const double *z, const double *fvec, double epsfcn,
+                     double *fjac, int dedup);
+int socp_fd_jacobian_dev(socp_ctx *ctx, const double *d_z, const double *d_fvec, double epsfcn,
+                         double *d_fjac, int dedup);
+
+/* replaces: shooting::ShootingFunctionJacobian (shooting.cpp:996-1130), variational Jacobian
+ * for models with modelOrder == 1; fjac column-major as handed to hybrj (shooting.cpp:889-893). */
+int socp_var_jacobian(socp_ctx *ctx, const double *z, double *fjac);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOCP_HIP_H_ */

@@ -1,0 +1,64 @@
+/*
+ * socp_solver.h -- Powell-hybrid Newton solver of the shooting problem, in two extra forms
+ * besides the CMinPack-compatible hybrd/hybrj of cminpack.h:
+ *
+ *  (1) socp_hybrd_batched: hybrd whose finite-difference stage (MINPACK fdjac1: n sequential
+ *      callbacks in the reference, 85-93 % of all residual evaluations of a testGoddard solve,
+ *      SURVEY 8a row a2) is ONE call that returns the whole forward-difference Jacobian -- the
+ *      hook through which the n perturbed residuals become one GPU batch.
+ *
+ *  (2) a resumable ("reverse communication") solver object: the caller evaluates what the
+ *      solver asks for.  Many independent problems (multi-start / continuation sweeps) can
+ *      then advance in lock-step with every request of a round evaluated in one launch.
+ *
+ * Same algorithm, constants and `info` codes as hybrd/hybrj; nfev is accounted as MINPACK does
+ * (a forward-difference Jacobian adds min(ml+mu+1, n) = n) so shooting::GetCallNumber keeps
+ * its meaning (shooting.cpp:491-493).
+ */
+#ifndef SOCP_SOLVER_H_
+#define SOCP_SOLVER_H_
+
+#include "cminpack.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* whole forward-difference Jacobian at x (fvec = F(x) already known), column-major, ld = ldfjac.
+ * Return < 0 to abort. */
+typedef int (*socp_fdjac_fn)(void *p, int n, const double *x, const double *fvec, double epsfcn,
+                             double *fjac, int ldfjac);
+
+int socp_hybrd_batched(cminpack_func_nn fcn, socp_fdjac_fn fdjac, void *p, int n, double *x,
+                       double *fvec, double xtol, int maxfev, int ml, int mu, double epsfcn,
+                       double *diag, int mode, double factor, int nprint, int *nfev,
+                       double *fjac, int ldfjac, double *r, int lr, double *qtf,
+                       double *wa1, double *wa2, double *wa3, double *wa4);
+
+/* ---- resumable solver ---- */
+#define SOCP_REQ_DONE 0   /* finished: read info / x / fvec                        */
+#define SOCP_REQ_FVEC 1   /* evaluate F at *x_eval, write n values to *out         */
+#define SOCP_REQ_JAC  2   /* evaluate J at *x_eval, write n*n (column-major) to *out */
+
+typedef struct socp_hybr socp_hybr;
+
+/* analytic_jac = 0: Jacobians are forward differences (hybrd accounting: nfev += n each);
+ * analytic_jac = 1: Jacobians are exact (hybrj accounting: njev += 1 each). */
+socp_hybr *socp_hybr_create(int n, double xtol, int maxfev, double epsfcn, int mode, double factor,
+                            int analytic_jac);
+void socp_hybr_destroy(socp_hybr *s);
+/* (re)start from x0; diag may be NULL (mode 1) */
+int socp_hybr_start(socp_hybr *s, const double *x0, const double *diag);
+/* user_flag: value the caller's evaluation returned for the PREVIOUS request (< 0 aborts). */
+int socp_hybr_advance(socp_hybr *s, int user_flag, const double **x_eval, double **out);
+int socp_hybr_info(const socp_hybr *s);
+int socp_hybr_nfev(const socp_hybr *s);
+int socp_hybr_njev(const socp_hybr *s);
+const double *socp_hybr_x(const socp_hybr *s);
+const double *socp_hybr_fvec(const socp_hybr *s);
+double socp_hybr_epsfcn(const socp_hybr *s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOCP_SOLVER_H_ */

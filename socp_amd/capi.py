@@ -1,0 +1,371 @@
+"""ctypes bindings over the C-ABI of libsocp_hip.so (include/socp_hip.h, cminpack.h, socp_solver.h).
+
+Thin plumbing only: every call goes straight to the shared library, which has no CPU path.
+If the library is missing, importing the loader raises -- nothing here falls back to NumPy.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_build", "libsocp_hip.so")
+
+OK, ERR_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4
+MODEL_GODDARD, MODEL_DOUBLE_INTEGRATOR = 1, 2
+FIXED, FREE, CONTINUOUS = 0, 1, 2
+VARIANT_AUTO, VARIANT_LANE_EXACT, VARIANT_LANE_FAST, VARIANT_WAVE = 0, 1, 2, 3
+EVAL_RHS, EVAL_CONTROL, EVAL_HAMILTONIAN = 0, 1, 2
+REQ_DONE, REQ_FVEC, REQ_JAC = 0, 1, 2
+GODDARD_PARAM_NAMES = ["C", "b", "KD", "kr", "u_max", "mu1", "mu2", "singularControl"]
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+_vp = C.c_void_p
+
+FCN = C.CFUNCTYPE(C.c_int, _vp, C.c_int, _dp, _dp, C.c_int)
+FCNDER = C.CFUNCTYPE(C.c_int, _vp, C.c_int, _dp, _dp, _dp, C.c_int, C.c_int)
+FDJAC = C.CFUNCTYPE(C.c_int, _vp, C.c_int, _dp, _dp, C.c_double, _dp, C.c_int)
+
+_lib = None
+
+
+class SocpError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libsocp_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def lib():
+    """Load libsocp_hip.so (fails loudly if it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.socp_last_error.restype = C.c_char_p
+        L.socp_last_error.argtypes = [_vp]
+        L.socp_ctx_create.argtypes = [C.POINTER(_vp), C.c_int, C.c_int]
+        for name in ("socp_ctx_destroy", "socp_ctx_synchronize"):
+            getattr(L, name).argtypes = [_vp]
+        L.socp_ctx_set_params.argtypes = [_vp, _dp, C.c_int]
+        L.socp_ctx_get_params.argtypes = [_vp, _dp, C.c_int]
+        L.socp_ctx_set_step_number.argtypes = [_vp, C.c_int]
+        L.socp_ctx_set_switching_times.argtypes = [_vp, _dp, C.c_int]
+        L.socp_ctx_set_variant.argtypes = [_vp, C.c_int]
+        L.socp_ctx_set_stream.argtypes = [_vp, _vp]
+        L.socp_ctx_dims.argtypes = [_vp, _ip, _ip, _ip]
+        L.socp_ctx_counters.argtypes = [_vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+        L.socp_integrate_batch.argtypes = [_vp, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_int]
+        L.socp_integrate_batch_dev.argtypes = [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int]
+        L.socp_eval_batch.argtypes = [_vp, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, _dp, C.c_int]
+        L.socp_problem_set.argtypes = [_vp, C.c_int, _ip, _ip, _dp, _dp]
+        L.socp_problem_num_param.argtypes = [_vp]
+        L.socp_timeline.argtypes = [_vp, _dp, _dp]
+        L.socp_residual_batch.argtypes = [_vp, C.c_int, _dp, _dp]
+        L.socp_residual_batch_dev.argtypes = [_vp, C.c_int, _vp, _vp]
+        L.socp_fd_jacobian.argtypes = [_vp, _dp, _dp, C.c_double, _dp, C.c_int]
+        L.socp_fd_jacobian_dev.argtypes = [_vp, _vp, _vp, C.c_double, _vp, C.c_int]
+        L.socp_var_jacobian.argtypes = [_vp, _dp, _dp]
+        L.hybrd.argtypes = [FCN, _vp, C.c_int, _dp, _dp, C.c_double, C.c_int, C.c_int, C.c_int, C.c_double,
+                            _dp, C.c_int, C.c_double, C.c_int, _ip, _dp, C.c_int, _dp, C.c_int, _dp,
+                            _dp, _dp, _dp, _dp]
+        L.socp_hybrd_batched.argtypes = [FCN, FDJAC] + L.hybrd.argtypes[1:]
+        L.hybrj.argtypes = [FCNDER, _vp, C.c_int, _dp, _dp, _dp, C.c_int, C.c_double, C.c_int, _dp, C.c_int,
+                            C.c_double, C.c_int, _ip, _ip, _dp, C.c_int, _dp, _dp, _dp, _dp, _dp]
+        L.socp_hybr_create.restype = _vp
+        L.socp_hybr_create.argtypes = [C.c_int, C.c_double, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int]
+        L.socp_hybr_destroy.argtypes = [_vp]
+        L.socp_hybr_start.argtypes = [_vp, _dp, _dp]
+        L.socp_hybr_advance.argtypes = [_vp, C.c_int, C.POINTER(_dp), C.POINTER(_dp)]
+        for name in ("socp_hybr_info", "socp_hybr_nfev", "socp_hybr_njev"):
+            getattr(L, name).argtypes = [_vp]
+        for name in ("socp_hybr_x", "socp_hybr_fvec"):
+            getattr(L, name).argtypes = [_vp]
+            getattr(L, name).restype = _dp
+        _lib = L
+    return _lib
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Context:
+    """One device context = one model object with its packed parameters (socp_ctx)."""
+
+    def __init__(self, model_id, device=-1):
+        self.L = lib()
+        self.h = _vp()
+        rc = self.L.socp_ctx_create(C.byref(self.h), int(model_id), int(device))
+        if rc != OK:
+            raise SocpError(rc, self.L.socp_last_error(None).decode())
+        dim, s, sj = C.c_int(), C.c_int(), C.c_int()
+        self.L.socp_ctx_dims(self.h, C.byref(dim), C.byref(s), C.byref(sj))
+        self.model_id, self.dim, self.s, self.s_jac = model_id, dim.value, s.value, sj.value
+        self.n = None
+
+    def close(self):
+        if self.h:
+            self.L.socp_ctx_destroy(self.h)
+            self.h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != OK:
+            raise SocpError(rc, self.L.socp_last_error(self.h).decode())
+
+    # -- configuration
+    def set_params(self, params):
+        p = _f64(params)
+        self._chk(self.L.socp_ctx_set_params(self.h, _d(p), len(p)))
+
+    def get_params(self):
+        n = 8 if self.model_id == MODEL_GODDARD else 3
+        p = np.empty(n)
+        self._chk(self.L.socp_ctx_get_params(self.h, _d(p), n))
+        return p
+
+    def set_param(self, name, value):
+        p = self.get_params()
+        p[GODDARD_PARAM_NAMES.index(name)] = value
+        self.set_params(p)
+
+    def set_step_number(self, n):
+        self._chk(self.L.socp_ctx_set_step_number(self.h, int(n)))
+
+    def set_switching_times(self, sw):
+        sw = _f64(sw)
+        self._chk(self.L.socp_ctx_set_switching_times(self.h, _d(sw), len(sw)))
+
+    def set_variant(self, v):
+        self._chk(self.L.socp_ctx_set_variant(self.h, int(v)))
+
+    def set_stream(self, stream_ptr):
+        self._chk(self.L.socp_ctx_set_stream(self.h, _vp(stream_ptr)))
+
+    def synchronize(self):
+        self._chk(self.L.socp_ctx_synchronize(self.h))
+
+    def counters(self):
+        a, b = C.c_longlong(), C.c_longlong()
+        self._chk(self.L.socp_ctx_counters(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    # -- trajectories (host buffers)
+    def integrate_batch(self, t0, tf, X0, sw=None, is_jac=0):
+        X0 = _f64(X0)
+        B = X0.shape[0]
+        t0 = _f64(np.broadcast_to(t0, (B,)))
+        tf = _f64(np.broadcast_to(tf, (B,)))
+        Xf = np.empty_like(X0)
+        swp = None
+        if sw is not None:
+            sw = _f64(sw)
+            swp = _d(sw)
+        self._chk(self.L.socp_integrate_batch(self.h, B, _d(t0), _d(tf), swp, _d(X0), _d(Xf), int(is_jac)))
+        return Xf
+
+    def integrate_batch_dev(self, B, d_t0, d_tf, d_sw, d_X0, d_Xf, is_jac=0):
+        """Device pointers (ints); enqueue only."""
+        self._chk(self.L.socp_integrate_batch_dev(self.h, int(B), _vp(d_t0), _vp(d_tf), _vp(d_sw), _vp(d_X0),
+                                                  _vp(d_Xf), int(is_jac)))
+
+    def eval_batch(self, what, t, X, sw=None):
+        X = _f64(X)
+        B = X.shape[0]
+        t = _f64(np.broadcast_to(t, (B,)))
+        out_len = {EVAL_RHS: X.shape[1], EVAL_CONTROL: 3, EVAL_HAMILTONIAN: 1}[what]
+        out = np.empty((B, out_len))
+        swp = None
+        if sw is not None:
+            sw = _f64(sw)
+            swp = _d(sw)
+        self._chk(self.L.socp_eval_batch(self.h, what, B, _d(t), swp, _d(X), X.shape[1], _d(out), 0))
+        return out
+
+    # -- shooting problem
+    def problem_set(self, mode_t, mode_x, time, xnode):
+        mode_t = np.ascontiguousarray(mode_t, dtype=np.int32)
+        M = len(mode_t) - 1
+        mode_x = np.ascontiguousarray(mode_x, dtype=np.int32).reshape(M + 1, self.dim)
+        time = _f64(time)
+        xnode = _f64(xnode).reshape(M + 1, self.s)
+        self._chk(self.L.socp_problem_set(self.h, M, mode_t.ctypes.data_as(_ip), mode_x.ctypes.data_as(_ip),
+                                          _d(time), _d(xnode)))
+        self.M = M
+        self.n = self.L.socp_problem_num_param(self.h)
+        return self.n
+
+    def timeline(self, z):
+        z = _f64(z)
+        tl = np.empty(self.M + 1)
+        self._chk(self.L.socp_timeline(self.h, _d(z), _d(tl)))
+        return tl
+
+    def residual_batch(self, Z):
+        Z = _f64(Z)
+        assert Z.ndim == 2 and Z.shape[1] == self.n
+        F = np.empty_like(Z)
+        self._chk(self.L.socp_residual_batch(self.h, Z.shape[0], _d(Z), _d(F)))
+        return F
+
+    def residual(self, z):
+        return self.residual_batch(_f64(z)[None, :])[0]
+
+    def residual_batch_dev(self, B, d_Z, d_F):
+        self._chk(self.L.socp_residual_batch_dev(self.h, int(B), _vp(d_Z), _vp(d_F)))
+
+    def fd_jacobian(self, z, fvec, epsfcn=1e-15, dedup=False):
+        """Returns J[row, col] (the C side is column-major)."""
+        z, fvec = _f64(z), _f64(fvec)
+        Jcm = np.empty((self.n, self.n))
+        self._chk(self.L.socp_fd_jacobian(self.h, _d(z), _d(fvec), float(epsfcn), _d(Jcm), int(bool(dedup))))
+        return Jcm.T.copy()
+
+    def fd_jacobian_dev(self, d_z, d_fvec, epsfcn, d_fjac, dedup=False):
+        self._chk(self.L.socp_fd_jacobian_dev(self.h, _vp(d_z), _vp(d_fvec), float(epsfcn), _vp(d_fjac),
+                                              int(bool(dedup))))
+
+
+# ---------------------------------------------------------------------------------------------
+# MINPACK entry points (host code inside the same library)
+# ---------------------------------------------------------------------------------------------
+
+def _workspace(n):
+    return dict(fvec=np.zeros(n), diag=np.ones(n), fjac=np.zeros((n, n)), r=np.zeros(n * (n + 1) // 2),
+                qtf=np.zeros(n), wa1=np.zeros(n), wa2=np.zeros(n), wa3=np.zeros(n), wa4=np.zeros(n))
+
+
+def hybrd(func, x0, xtol=1e-8, maxfev=10000, ml=None, mu=None, epsfcn=1e-15, mode=1, factor=1.0,
+          diag=None, fdjac=None):
+    """Drive the library's hybrd (or socp_hybrd_batched when `fdjac` is given) with Python callables.
+
+    func(x) -> F(x) (or None to abort);  fdjac(x, fvec, epsfcn) -> J[row, col].
+    Returns dict(x, fvec, info, nfev, fjac (Q, column-major as MINPACK leaves it), r, qtf, diag).
+    """
+    L = lib()
+    x = _f64(np.array(x0, dtype=np.float64))
+    n = len(x)
+    ws = _workspace(n)
+    if diag is not None:
+        ws["diag"][:] = diag
+    ml = n - 1 if ml is None else ml
+    mu = n - 1 if mu is None else mu
+    nfev = C.c_int(0)
+
+    def _fcn(p, nn, xp, fp, iflag):
+        out = func(np.ctypeslib.as_array(xp, shape=(nn,)).copy())
+        if out is None:
+            return -1
+        np.ctypeslib.as_array(fp, shape=(nn,))[:] = out
+        return 0
+
+    def _jac(p, nn, xp, fp, eps, jp, ld):
+        J = fdjac(np.ctypeslib.as_array(xp, shape=(nn,)).copy(), np.ctypeslib.as_array(fp, shape=(nn,)).copy(), eps)
+        if J is None:
+            return -1
+        np.ctypeslib.as_array(jp, shape=(nn, ld))[:, :nn] = np.asarray(J).T   # column-major
+        return 0
+
+    cb = FCN(_fcn)
+    args = [None, n, _d(x), _d(ws["fvec"]), xtol, maxfev, ml, mu, epsfcn, _d(ws["diag"]), mode, factor, 0,
+            C.byref(nfev), _d(ws["fjac"]), n, _d(ws["r"]), len(ws["r"]), _d(ws["qtf"]),
+            _d(ws["wa1"]), _d(ws["wa2"]), _d(ws["wa3"]), _d(ws["wa4"])]
+    if fdjac is None:
+        info = L.hybrd(cb, *args)
+    else:
+        info = L.socp_hybrd_batched(cb, FDJAC(_jac), *args)
+    return dict(x=x, fvec=ws["fvec"], info=info, nfev=nfev.value, fjac=ws["fjac"], r=ws["r"], qtf=ws["qtf"],
+                diag=ws["diag"])
+
+
+def hybrj(func, jac, x0, xtol=1e-8, maxfev=10000, mode=1, factor=1.0, diag=None):
+    """Drive the library's hybrj.  func(x) -> F, jac(x) -> J[row, col]."""
+    L = lib()
+    x = _f64(np.array(x0, dtype=np.float64))
+    n = len(x)
+    ws = _workspace(n)
+    if diag is not None:
+        ws["diag"][:] = diag
+    nfev, njev = C.c_int(0), C.c_int(0)
+
+    def _fcn(p, nn, xp, fp, jp, ld, iflag):
+        xx = np.ctypeslib.as_array(xp, shape=(nn,)).copy()
+        if iflag == 1:
+            out = func(xx)
+            if out is None:
+                return -1
+            np.ctypeslib.as_array(fp, shape=(nn,))[:] = out
+        else:
+            J = jac(xx)
+            if J is None:
+                return -1
+            np.ctypeslib.as_array(jp, shape=(nn, ld))[:, :nn] = np.asarray(J).T
+        return 0
+
+    cb = FCNDER(_fcn)
+    info = L.hybrj(cb, None, n, _d(x), _d(ws["fvec"]), _d(ws["fjac"]), n, xtol, maxfev, _d(ws["diag"]), mode,
+                   factor, 0, C.byref(nfev), C.byref(njev), _d(ws["r"]), len(ws["r"]), _d(ws["qtf"]),
+                   _d(ws["wa1"]), _d(ws["wa2"]), _d(ws["wa3"]), _d(ws["wa4"]))
+    return dict(x=x, fvec=ws["fvec"], info=info, nfev=nfev.value, njev=njev.value, fjac=ws["fjac"], r=ws["r"],
+                qtf=ws["qtf"], diag=ws["diag"])
+
+
+class HybrSolver:
+    """Resumable solver object (socp_hybr_*)."""
+
+    def __init__(self, n, xtol=1e-8, maxfev=10000, epsfcn=1e-15, mode=1, factor=1.0, analytic_jac=False):
+        self.L = lib()
+        self.n = n
+        self.h = _vp(self.L.socp_hybr_create(n, xtol, maxfev, epsfcn, mode, factor, int(analytic_jac)))
+        self._xe = _dp()
+        self._out = _dp()
+
+    def __del__(self):
+        try:
+            self.L.socp_hybr_destroy(self.h)
+        except Exception:
+            pass
+
+    def start(self, x0, diag=None):
+        x0 = _f64(x0)
+        self.L.socp_hybr_start(self.h, _d(x0), _d(_f64(diag)) if diag is not None else None)
+
+    def advance(self, flag=0):
+        """Returns (request, x_eval view, out view)."""
+        req = self.L.socp_hybr_advance(self.h, int(flag), C.byref(self._xe), C.byref(self._out))
+        if req == REQ_DONE:
+            return req, None, None
+        xe = np.ctypeslib.as_array(self._xe, shape=(self.n,))
+        out = np.ctypeslib.as_array(self._out, shape=(self.n,) if req == REQ_FVEC else (self.n * self.n,))
+        return req, xe, out
+
+    @property
+    def info(self):
+        return self.L.socp_hybr_info(self.h)
+
+    @property
+    def nfev(self):
+        return self.L.socp_hybr_nfev(self.h)
+
+    @property
+    def njev(self):
+        return self.L.socp_hybr_njev(self.h)
+
+    @property
+    def x(self):
+        return np.ctypeslib.as_array(self.L.socp_hybr_x(self.h), shape=(self.n,)).copy()
+
+    @property
+    def fvec(self):
+        return np.ctypeslib.as_array(self.L.socp_hybr_fvec(self.h), shape=(self.n,)).copy()

@@ -1,0 +1,534 @@
+// capi.cpp -- implementation of include/socp_hip.h (context, device tables, launch dispatch).
+// Host logic only: every number the caller receives was computed by a gfx950 kernel.
+#include "../../include/socp_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "launch.hpp"
+
+using namespace socp;
+
+namespace {
+
+std::string g_create_error;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
+        size_t want = bytes < 4096 ? 4096 : bytes + bytes / 4;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+}  // namespace
+
+struct socp_ctx {
+    int model_id = 0;
+    int device = 0;
+    int dim = 0, S = 0;
+    int nparams = 0;
+    int variant = SOCP_VARIANT_AUTO;
+    ModelParams P{};
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+
+    // shooting problem (host copy + device tables)
+    bool has_problem = false;
+    int M = 0, n = 0;
+    std::vector<int> mode_t, mode_x, node_kind, lo, hi, ft_row;
+    std::vector<double> time, xnode;
+    int sw_node0 = -1, sw_node1 = -1;
+    DevBuf d_tables;                 // one allocation holding every table
+    ProblemDev pb{};
+    DevBuf d_pairs_full, d_pairs_dedup;
+    int T_full = 0, T_dedup = 0;
+
+    // grow-only staging for the host-pointer entry points
+    DevBuf s_t0, s_tf, s_sw, s_in, s_out, s_aux;
+
+    long long n_traj = 0, n_launch = 0;
+    std::string err;
+};
+
+namespace {
+
+int fail(socp_ctx *c, int code, const std::string &msg)
+{
+    if (c) c->err = msg; else g_create_error = msg;
+    return code;
+}
+
+int hip_fail(socp_ctx *c, hipError_t e, const char *what)
+{
+    return fail(c, SOCP_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIP_TRY(c, call)                                                 \
+    do {                                                                 \
+        hipError_t e__ = (call);                                         \
+        if (e__ != hipSuccess) return hip_fail((c), e__, #call);         \
+    } while (0)
+
+bool use_fast(const socp_ctx *c)
+{
+    // AUTO keeps the reference operation order: it is the variant every parity claim is made on.
+    return c->variant == SOCP_VARIANT_LANE_FAST;
+}
+
+int check_variant(socp_ctx *c)
+{
+    if (c->variant == SOCP_VARIANT_WAVE)
+        return fail(c, SOCP_ERR_UNSUPPORTED, "wave-per-trajectory variant is not available for this entry point");
+    return SOCP_OK;
+}
+
+hipError_t run_traj(socp_ctx *c, int B, const double *t0, const double *tf, const double *sw,
+                    const double *X0, double *Xf)
+{
+    c->n_traj += B; c->n_launch += 1;
+    return use_fast(c) ? traj_fast(c->model_id, c->stream, c->P, B, t0, tf, sw, X0, Xf)
+                       : traj_exact(c->model_id, c->stream, c->P, B, t0, tf, sw, X0, Xf);
+}
+
+hipError_t run_residual(socp_ctx *c, int B, const double *Z, double *F)
+{
+    c->n_traj += (long long)B * c->M; c->n_launch += 1;
+    return use_fast(c) ? residual_fast(c->model_id, c->stream, c->P, c->pb, B, Z, F)
+                       : residual_exact(c->model_id, c->stream, c->P, c->pb, B, Z, F);
+}
+
+hipError_t run_fdjac(socp_ctx *c, int T, const int2 *pairs, const double *z, const double *fvec,
+                     double eps, double *fjac)
+{
+    c->n_traj += T; c->n_launch += 1;
+    return use_fast(c) ? fdjac_fast(c->model_id, c->stream, c->P, c->pb, T, pairs, z, fvec, eps, fjac)
+                       : fdjac_exact(c->model_id, c->stream, c->P, c->pb, T, pairs, z, fvec, eps, fjac);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *socp_last_error(const socp_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int socp_ctx_create(socp_ctx **out, int model_id, int device)
+{
+    if (!out) return fail(nullptr, SOCP_ERR_ARG, "socp_ctx_create: null output pointer");
+    *out = nullptr;
+    if (model_id != SOCP_MODEL_GODDARD && model_id != SOCP_MODEL_DOUBLE_INTEGRATOR)
+        return fail(nullptr, SOCP_ERR_UNSUPPORTED, "socp_ctx_create: unknown model id (no device dynamics)");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, SOCP_ERR_NO_DEVICE,
+                    "socp_ctx_create: no HIP device visible -- this library has no CPU path");
+    if (device < 0) { e = hipGetDevice(&device); if (e != hipSuccess) return hip_fail(nullptr, e, "hipGetDevice"); }
+    if (device >= ndev) return fail(nullptr, SOCP_ERR_ARG, "socp_ctx_create: device index out of range");
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return hip_fail(nullptr, e, "hipSetDevice");
+
+    socp_ctx *c = new socp_ctx;
+    c->model_id = model_id;
+    c->device = device;
+    if (model_id == SOCP_MODEL_GODDARD) {
+        // goddard.cpp:23-40 defaults
+        c->dim = 7; c->nparams = SOCP_GODDARD_NPARAMS;
+        const double d[8] = {3.5, 7.0, 310.0, 500.0, 1.0, 1.0, 0.0, -1.0};
+        std::memcpy(c->P.p, d, sizeof(d));
+        c->P.sw0 = 0.0227; c->P.sw1 = 0.08; c->P.step_nbr = 10;
+    } else {
+        // doubleIntegrator.cpp:26-34 defaults
+        c->dim = 6; c->nparams = SOCP_DINT_NPARAMS;
+        c->P.p[0] = 1.0; c->P.p[1] = 1.0; c->P.p[2] = 0.01;
+        c->P.sw0 = c->P.sw1 = 0.0; c->P.step_nbr = 30;
+    }
+    c->S = 2 * c->dim;
+    e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return hip_fail(nullptr, e, "hipStreamCreate"); }
+    c->stream = c->own_stream;
+    *out = c;
+    return SOCP_OK;
+}
+
+int socp_ctx_destroy(socp_ctx *c)
+{
+    if (!c) return SOCP_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    c->d_tables.release(); c->d_pairs_full.release(); c->d_pairs_dedup.release();
+    c->s_t0.release(); c->s_tf.release(); c->s_sw.release(); c->s_in.release(); c->s_out.release(); c->s_aux.release();
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return SOCP_OK;
+}
+
+int socp_ctx_set_params(socp_ctx *c, const double *params, int nparams)
+{
+    if (!c || !params) return fail(c, SOCP_ERR_ARG, "set_params: null argument");
+    if (nparams != c->nparams) return fail(c, SOCP_ERR_ARG, "set_params: wrong parameter count for this model");
+    std::memcpy(c->P.p, params, sizeof(double) * nparams);
+    return SOCP_OK;
+}
+
+int socp_ctx_get_params(const socp_ctx *c, double *params, int nparams)
+{
+    if (!c || !params || nparams != c->nparams) return SOCP_ERR_ARG;
+    std::memcpy(params, c->P.p, sizeof(double) * nparams);
+    return SOCP_OK;
+}
+
+int socp_ctx_set_step_number(socp_ctx *c, int step_nbr)
+{
+    if (!c) return SOCP_ERR_ARG;
+    if (step_nbr < 1) return fail(c, SOCP_ERR_ARG, "set_step_number: step number must be >= 1");
+    c->P.step_nbr = step_nbr;
+    return SOCP_OK;
+}
+
+int socp_ctx_set_switching_times(socp_ctx *c, const double *sw, int nsw)
+{
+    if (!c || (nsw > 0 && !sw)) return fail(c, SOCP_ERR_ARG, "set_switching_times: null argument");
+    // the control law reads entries [0] and [1] only (goddard.cpp:148-151); a missing entry is an
+    // out-of-bounds read in the reference -- here it is NaN, so every comparison is false.
+    c->P.sw0 = nsw > 0 ? sw[0] : NAN;
+    c->P.sw1 = nsw > 1 ? sw[1] : NAN;
+    return SOCP_OK;
+}
+
+int socp_ctx_set_variant(socp_ctx *c, int variant)
+{
+    if (!c) return SOCP_ERR_ARG;
+    if (variant < SOCP_VARIANT_AUTO || variant > SOCP_VARIANT_WAVE) return fail(c, SOCP_ERR_ARG, "set_variant: unknown variant");
+    c->variant = variant;
+    return SOCP_OK;
+}
+
+int socp_ctx_set_stream(socp_ctx *c, void *hip_stream)
+{
+    if (!c) return SOCP_ERR_ARG;
+    c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    return SOCP_OK;
+}
+
+int socp_ctx_synchronize(socp_ctx *c)
+{
+    if (!c) return SOCP_ERR_ARG;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SOCP_OK;
+}
+
+int socp_ctx_dims(const socp_ctx *c, int *dim, int *state_len, int *state_len_jac)
+{
+    if (!c) return SOCP_ERR_ARG;
+    if (dim) *dim = c->dim;
+    if (state_len) *state_len = c->S;
+    if (state_len_jac) *state_len_jac = (c->S + 1) * c->S;
+    return SOCP_OK;
+}
+
+int socp_ctx_counters(const socp_ctx *c, long long *trajectories, long long *launches)
+{
+    if (!c) return SOCP_ERR_ARG;
+    if (trajectories) *trajectories = c->n_traj;
+    if (launches) *launches = c->n_launch;
+    return SOCP_OK;
+}
+
+/* ---- trajectories ------------------------------------------------------------------------ */
+
+int socp_integrate_batch_dev(socp_ctx *c, int B, const double *d_t0, const double *d_tf,
+                             const double *d_sw, const double *d_X0, double *d_Xf, int is_jac)
+{
+    if (!c) return SOCP_ERR_ARG;
+    if (B < 0 || (B > 0 && (!d_t0 || !d_tf || !d_X0 || !d_Xf))) return fail(c, SOCP_ERR_ARG, "integrate_batch: null argument");
+    if (is_jac) return fail(c, SOCP_ERR_UNSUPPORTED, "integrate_batch: variational state (is_jac=1) not available in this build");
+    if (int rc = check_variant(c)) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, run_traj(c, B, d_t0, d_tf, d_sw, d_X0, d_Xf));
+    return SOCP_OK;
+}
+
+int socp_integrate_batch(socp_ctx *c, int B, const double *t0, const double *tf, const double *sw,
+                         const double *X0, double *Xf, int is_jac)
+{
+    if (!c) return SOCP_ERR_ARG;
+    if (B < 0 || (B > 0 && (!t0 || !tf || !X0 || !Xf))) return fail(c, SOCP_ERR_ARG, "integrate_batch: null argument");
+    if (B == 0) return SOCP_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t len = is_jac ? (size_t)(c->S + 1) * c->S : (size_t)c->S;
+    const size_t nb = sizeof(double) * len * B;
+    HIP_TRY(c, c->s_t0.reserve(sizeof(double) * B));
+    HIP_TRY(c, c->s_tf.reserve(sizeof(double) * B));
+    HIP_TRY(c, c->s_in.reserve(nb));
+    HIP_TRY(c, c->s_out.reserve(nb));
+    HIP_TRY(c, hipMemcpyAsync(c->s_t0.p, t0, sizeof(double) * B, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->s_tf.p, tf, sizeof(double) * B, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->s_in.p, X0, nb, hipMemcpyHostToDevice, c->stream));
+    const double *dsw = nullptr;
+    if (sw) {
+        HIP_TRY(c, c->s_sw.reserve(sizeof(double) * 2 * B));
+        HIP_TRY(c, hipMemcpyAsync(c->s_sw.p, sw, sizeof(double) * 2 * B, hipMemcpyHostToDevice, c->stream));
+        dsw = c->s_sw.as<double>();
+    }
+    int rc = socp_integrate_batch_dev(c, B, c->s_t0.as<double>(), c->s_tf.as<double>(), dsw,
+                                      c->s_in.as<double>(), c->s_out.as<double>(), is_jac);
+    if (rc != SOCP_OK) return rc;
+    HIP_TRY(c, hipMemcpyAsync(Xf, c->s_out.p, nb, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SOCP_OK;
+}
+
+int socp_eval_batch(socp_ctx *c, int what, int B, const double *t, const double *sw,
+                    const double *X, int len, double *out, int is_jac)
+{
+    if (!c) return SOCP_ERR_ARG;
+    if (B < 0 || (B > 0 && (!t || !X || !out))) return fail(c, SOCP_ERR_ARG, "eval_batch: null argument");
+    if (what < SOCP_EVAL_RHS || what > SOCP_EVAL_HAMILTONIAN) return fail(c, SOCP_ERR_ARG, "eval_batch: unknown quantity");
+    if (is_jac) return fail(c, SOCP_ERR_UNSUPPORTED, "eval_batch: is_jac=1 not available in this build");
+    if (len != c->S) return fail(c, SOCP_ERR_ARG, "eval_batch: state length must be 2*dim");
+    if (B == 0) return SOCP_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int out_len = what == SOCP_EVAL_RHS ? c->S : (what == SOCP_EVAL_CONTROL ? 3 : 1);
+    HIP_TRY(c, c->s_t0.reserve(sizeof(double) * B));
+    HIP_TRY(c, c->s_in.reserve(sizeof(double) * (size_t)B * len));
+    HIP_TRY(c, c->s_out.reserve(sizeof(double) * (size_t)B * out_len));
+    HIP_TRY(c, hipMemcpyAsync(c->s_t0.p, t, sizeof(double) * B, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->s_in.p, X, sizeof(double) * (size_t)B * len, hipMemcpyHostToDevice, c->stream));
+    const double *dsw = nullptr;
+    if (sw) {
+        HIP_TRY(c, c->s_sw.reserve(sizeof(double) * 2 * B));
+        HIP_TRY(c, hipMemcpyAsync(c->s_sw.p, sw, sizeof(double) * 2 * B, hipMemcpyHostToDevice, c->stream));
+        dsw = c->s_sw.as<double>();
+    }
+    c->n_launch += 1;
+    hipError_t e = use_fast(c)
+        ? eval_fast(c->model_id, c->stream, c->P, what, B, c->s_t0.as<double>(), dsw, c->s_in.as<double>(), c->s_out.as<double>())
+        : eval_exact(c->model_id, c->stream, c->P, what, B, c->s_t0.as<double>(), dsw, c->s_in.as<double>(), c->s_out.as<double>());
+    HIP_TRY(c, e);
+    HIP_TRY(c, hipMemcpyAsync(out, c->s_out.p, sizeof(double) * (size_t)B * out_len, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SOCP_OK;
+}
+
+/* ---- shooting problem --------------------------------------------------------------------- */
+
+int socp_problem_set(socp_ctx *c, int M, const int *mode_t, const int *mode_x, const double *time, const double *xnode)
+{
+    if (!c) return SOCP_ERR_ARG;
+    if (M < 1 || !mode_t || !mode_x || !time || !xnode) return fail(c, SOCP_ERR_ARG, "problem_set: bad argument");
+    if (M + 1 > kMaxNodes) return fail(c, SOCP_ERR_ARG, "problem_set: too many shooting nodes");
+    const int d = c->dim, S = c->S;
+    for (int j = 0; j <= M; j++)
+        if (mode_t[j] < SOCP_FIXED || mode_t[j] > SOCP_CONTINUOUS) return fail(c, SOCP_ERR_ARG, "problem_set: bad time mode");
+    // a CONTINUOUS end node would leave the tail of the timeline unset in the reference
+    // (shooting.cpp:1586-1613 only closes an interval at a FIXED/FREE node)
+    if (mode_t[0] == SOCP_CONTINUOUS || mode_t[M] == SOCP_CONTINUOUS)
+        return fail(c, SOCP_ERR_ARG, "problem_set: first and last time must be FIXED or FREE");
+    for (int k = 0; k <= M; k++)
+        for (int j = 0; j < d; j++) {
+            const int m = mode_x[k * d + j];
+            if (m < SOCP_FIXED || m > SOCP_CONTINUOUS) return fail(c, SOCP_ERR_ARG, "problem_set: bad state mode");
+            // interior FREE states defer to model::SwitchingStateFunction, a no-op in every in-tree
+            // model (model.hpp:339-341, "TO TEST" at shooting.cpp:1536): no defined behaviour to mirror
+            if (k > 0 && k < M && m == SOCP_FREE)
+                return fail(c, SOCP_ERR_UNSUPPORTED, "problem_set: FREE state mode at an interior node");
+            if ((k == 0 || k == M) && m == SOCP_CONTINUOUS)
+                return fail(c, SOCP_ERR_ARG, "problem_set: CONTINUOUS state mode at a boundary node");
+        }
+
+    c->M = M;
+    c->mode_t.assign(mode_t, mode_t + M + 1);
+    c->mode_x.assign(mode_x, mode_x + (size_t)(M + 1) * d);
+    c->time.assign(time, time + M + 1);
+    c->xnode.assign(xnode, xnode + (size_t)(M + 1) * S);
+    c->node_kind.assign(M + 1, -2); c->lo.assign(M + 1, 0); c->hi.assign(M + 1, 0); c->ft_row.assign(M + 1, -1);
+
+    // unknown / residual layout (shooting.cpp:228-243, 945-990)
+    int nbr = S * M;
+    c->sw_node0 = c->sw_node1 = -1;
+    for (int j = 0; j <= M; j++) {
+        if (mode_t[j] == SOCP_FIXED) c->node_kind[j] = -1;
+        if (mode_t[j] == SOCP_FREE) {
+            c->node_kind[j] = nbr;           // index of the time unknown in z ...
+            c->ft_row[j] = nbr;              // ... and of its residual row in F
+            nbr++;
+            if (j < M) { if (c->sw_node0 < 0) c->sw_node0 = j; else if (c->sw_node1 < 0) c->sw_node1 = j; }
+        }
+    }
+    c->n = nbr;
+    int cur = 0;
+    for (int j = 0; j <= M; j++) {
+        if (c->node_kind[j] != -2) {
+            for (int k = cur + 1; k < j; k++) { c->lo[k] = cur; c->hi[k] = j; }
+            c->lo[j] = c->hi[j] = j;
+            cur = j;
+        }
+    }
+
+    // FD column -> segments to integrate
+    std::vector<int2> full, dedup;
+    for (int j = 0; j < c->n; j++)
+        for (int i = 0; i < M; i++) full.push_back(make_int2(j, i));
+    for (int j = 0; j < c->n; j++) {
+        if (j < S * M) {
+            const int k = j / S;
+            if (k >= 1) dedup.push_back(make_int2(j, k - 1));
+            dedup.push_back(make_int2(j, k));
+        } else {
+            int q = 0;
+            for (int k = 0; k <= M; k++) if (c->node_kind[k] == j) q = k;
+            if (q == c->sw_node0 || q == c->sw_node1) {
+                for (int i = 0; i < M; i++) dedup.push_back(make_int2(j, i));   // control law reads it everywhere
+            } else {
+                int a = q, b = q;
+                while (a > 0 && c->node_kind[a - 1] == -2) a--;
+                if (a > 0) a--;                                // previous junction
+                while (b < M && c->node_kind[b + 1] == -2) b++;
+                if (b < M) b++;                                // next junction
+                for (int i = a; i < b; i++) dedup.push_back(make_int2(j, i));
+            }
+        }
+    }
+    c->T_full = (int)full.size();
+    c->T_dedup = (int)dedup.size();
+
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));     // tables may still be in use by enqueued work
+    const size_t nI = (size_t)(M + 1), off_kind = 0, off_lo = nI, off_hi = 2 * nI, off_ft = 3 * nI, off_mx = 4 * nI;
+    const size_t n_int = 4 * nI + nI * d;
+    const size_t int_bytes = ((n_int * sizeof(int) + 15) / 16) * 16;
+    const size_t n_dbl = nI + nI * S;
+    HIP_TRY(c, c->d_tables.reserve(int_bytes + n_dbl * sizeof(double)));
+    std::vector<char> blob(int_bytes + n_dbl * sizeof(double));
+    int *bi = reinterpret_cast<int *>(blob.data());
+    double *bd = reinterpret_cast<double *>(blob.data() + int_bytes);
+    std::memcpy(bi + off_kind, c->node_kind.data(), nI * sizeof(int));
+    std::memcpy(bi + off_lo, c->lo.data(), nI * sizeof(int));
+    std::memcpy(bi + off_hi, c->hi.data(), nI * sizeof(int));
+    std::memcpy(bi + off_ft, c->ft_row.data(), nI * sizeof(int));
+    std::memcpy(bi + off_mx, c->mode_x.data(), nI * d * sizeof(int));
+    std::memcpy(bd, c->time.data(), nI * sizeof(double));
+    std::memcpy(bd + nI, c->xnode.data(), nI * S * sizeof(double));
+    HIP_TRY(c, hipMemcpy(c->d_tables.p, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    HIP_TRY(c, c->d_pairs_full.reserve(sizeof(int2) * full.size()));
+    HIP_TRY(c, c->d_pairs_dedup.reserve(sizeof(int2) * dedup.size()));
+    HIP_TRY(c, hipMemcpy(c->d_pairs_full.p, full.data(), sizeof(int2) * full.size(), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_pairs_dedup.p, dedup.data(), sizeof(int2) * dedup.size(), hipMemcpyHostToDevice));
+
+    const int *di = c->d_tables.as<int>();
+    const double *dd = reinterpret_cast<const double *>(c->d_tables.as<char>() + int_bytes);
+    c->pb.dim = d; c->pb.M = M; c->pb.n = c->n;
+    c->pb.sw_node0 = c->sw_node0; c->pb.sw_node1 = c->sw_node1;
+    c->pb.node_kind = di + off_kind; c->pb.lo = di + off_lo; c->pb.hi = di + off_hi;
+    c->pb.ft_row = di + off_ft; c->pb.mode_x = di + off_mx;
+    c->pb.time = dd; c->pb.xnode = dd + nI;
+    c->has_problem = true;
+    return SOCP_OK;
+}
+
+int socp_problem_num_param(const socp_ctx *c) { return (c && c->has_problem) ? c->n : SOCP_ERR_ARG; }
+
+int socp_timeline(socp_ctx *c, const double *z, double *tl)
+{
+    // Pure index/interpolation logic on host data (no RHS arithmetic): shooting.cpp:1579-1617.
+    if (!c || !z || !tl) return fail(c, SOCP_ERR_ARG, "timeline: null argument");
+    if (!c->has_problem) return fail(c, SOCP_ERR_ARG, "timeline: no problem set");
+    auto jt = [&](int j) { return c->node_kind[j] >= 0 ? z[c->node_kind[j]] : c->time[j]; };
+    for (int k = 0; k <= c->M; k++) {
+        if (c->node_kind[k] >= -1) tl[k] = jt(k);
+        else {
+            const int a = c->lo[k], b = c->hi[k];
+            const double ta = jt(a), tb = jt(b);
+            tl[k] = ta + (k - a) * (tb - ta) / (b - a);
+        }
+    }
+    return SOCP_OK;
+}
+
+int socp_residual_batch_dev(socp_ctx *c, int B, const double *d_Z, double *d_F)
+{
+    if (!c) return SOCP_ERR_ARG;
+    if (!c->has_problem) return fail(c, SOCP_ERR_ARG, "residual_batch: no problem set");
+    if (B < 0 || (B > 0 && (!d_Z || !d_F))) return fail(c, SOCP_ERR_ARG, "residual_batch: null argument");
+    if (int rc = check_variant(c)) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, run_residual(c, B, d_Z, d_F));
+    return SOCP_OK;
+}
+
+int socp_residual_batch(socp_ctx *c, int B, const double *Z, double *F)
+{
+    if (!c) return SOCP_ERR_ARG;
+    if (!c->has_problem) return fail(c, SOCP_ERR_ARG, "residual_batch: no problem set");
+    if (B < 0 || (B > 0 && (!Z || !F))) return fail(c, SOCP_ERR_ARG, "residual_batch: null argument");
+    if (B == 0) return SOCP_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t nb = sizeof(double) * (size_t)B * c->n;
+    HIP_TRY(c, c->s_in.reserve(nb));
+    HIP_TRY(c, c->s_out.reserve(nb));
+    HIP_TRY(c, hipMemcpyAsync(c->s_in.p, Z, nb, hipMemcpyHostToDevice, c->stream));
+    int rc = socp_residual_batch_dev(c, B, c->s_in.as<double>(), c->s_out.as<double>());
+    if (rc != SOCP_OK) return rc;
+    HIP_TRY(c, hipMemcpyAsync(F, c->s_out.p, nb, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SOCP_OK;
+}
+
+int socp_fd_jacobian_dev(socp_ctx *c, const double *d_z, const double *d_fvec, double epsfcn, double *d_fjac, int dedup)
+{
+    if (!c) return SOCP_ERR_ARG;
+    if (!c->has_problem) return fail(c, SOCP_ERR_ARG, "fd_jacobian: no problem set");
+    if (!d_z || !d_fvec || !d_fjac) return fail(c, SOCP_ERR_ARG, "fd_jacobian: null argument");
+    if (int rc = check_variant(c)) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const double eps = std::sqrt(epsfcn > DBL_EPSILON ? epsfcn : DBL_EPSILON);
+    if (dedup) {
+        // rows a column cannot change reproduce fvec bit for bit => exact zeros
+        HIP_TRY(c, hipMemsetAsync(d_fjac, 0, sizeof(double) * (size_t)c->n * c->n, c->stream));
+        HIP_TRY(c, run_fdjac(c, c->T_dedup, c->d_pairs_dedup.as<int2>(), d_z, d_fvec, eps, d_fjac));
+    } else {
+        HIP_TRY(c, run_fdjac(c, c->T_full, c->d_pairs_full.as<int2>(), d_z, d_fvec, eps, d_fjac));
+    }
+    return SOCP_OK;
+}
+
+int socp_fd_jacobian(socp_ctx *c, const double *z, const double *fvec, double epsfcn, double *fjac, int dedup)
+{
+    if (!c) return SOCP_ERR_ARG;
+    if (!c->has_problem) return fail(c, SOCP_ERR_ARG, "fd_jacobian: no problem set");
+    if (!z || !fvec || !fjac) return fail(c, SOCP_ERR_ARG, "fd_jacobian: null argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t n = c->n;
+    HIP_TRY(c, c->s_in.reserve(sizeof(double) * n));
+    HIP_TRY(c, c->s_aux.reserve(sizeof(double) * n));
+    HIP_TRY(c, c->s_out.reserve(sizeof(double) * n * n));
+    HIP_TRY(c, hipMemcpyAsync(c->s_in.p, z, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->s_aux.p, fvec, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    int rc = socp_fd_jacobian_dev(c, c->s_in.as<double>(), c->s_aux.as<double>(), epsfcn, c->s_out.as<double>(), dedup);
+    if (rc != SOCP_OK) return rc;
+    HIP_TRY(c, hipMemcpyAsync(fjac, c->s_out.p, sizeof(double) * n * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SOCP_OK;
+}
+
+int socp_var_jacobian(socp_ctx *c, const double *, double *)
+{
+    return fail(c, SOCP_ERR_UNSUPPORTED, "var_jacobian: variational Jacobian not available in this build");
+}
+
+}  // extern "C"

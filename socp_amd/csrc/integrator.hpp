@@ -1,0 +1,247 @@
+// integrator.hpp -- per-lane fixed-step RK4 driver and the three lane-per-trajectory kernels
+// (trajectory batch, fused shooting residual, fused FD-Jacobian column batch).
+//
+// Included by kernels_exact.hip (compiled -ffp-contract=off with the reference-order models)
+// and by kernels_fast.hip (contraction on, restructured models).  One lane owns one
+// trajectory: its s-vector, the RK4 stage vectors and all RHS temporaries live in VGPRs, so
+// the inner loop touches neither LDS nor HBM; a 64-lane wave is 64 independent trajectories.
+#pragma once
+#include "dev_common.hpp"
+
+namespace socp {
+
+template <class Mdl>
+struct Lane {
+    static constexpr int S = Mdl::S;
+    static constexpr int D = Mdl::D;
+
+    // odeTools.cpp:89-98.  Stage states X + (step/2.0) F, stage times t + step/2.0 (twice) and
+    // t + step, update X + (step/6.0)*(F1 + (F4 + 2.0*(F2 + F3))): this association order is
+    // the parity contract.
+    __device__ static __forceinline__ void rk4(const ModelParams &P, double sw0, double sw1,
+                                              double t, double (&X)[S], double step)
+    {
+        double F1[S], Fs[S], F[S], Y[S];
+        const double h2 = step / 2.0;
+        const double th = t + step / 2.0;
+        Mdl::rhs(P, sw0, sw1, t, X, F1);
+#pragma unroll
+        for (int i = 0; i < S; i++) Y[i] = X[i] + h2 * F1[i];
+        Mdl::rhs(P, sw0, sw1, th, Y, Fs);                 // F2
+#pragma unroll
+        for (int i = 0; i < S; i++) Y[i] = X[i] + h2 * Fs[i];
+        Mdl::rhs(P, sw0, sw1, th, Y, F);                  // F3
+#pragma unroll
+        for (int i = 0; i < S; i++) { Y[i] = X[i] + step * F[i]; Fs[i] = Fs[i] + F[i]; }   // F2 + F3
+        Mdl::rhs(P, sw0, sw1, t + step, Y, F);            // F4
+        const double h6 = step / 6.0;
+#pragma unroll
+        for (int i = 0; i < S; i++) X[i] = X[i] + h6 * (F1[i] + (F[i] + 2.0 * Fs[i]));
+    }
+
+    // model.hpp:395-414 / goddard.cpp:298-317 (dt) + odeTools.cpp:128-146 (loop): t is
+    // accumulated by t += dt, the last step is clamped to tf - t, and a segment with
+    // tf <= t0 + dt/2 (zero length or backward) takes no step at all.
+    __device__ static __forceinline__ void integrate(const ModelParams &P, double sw0, double sw1,
+                                                    double t0, double tf, double (&X)[S])
+    {
+        const double dt = (tf - t0) / P.step_nbr;
+        double t = t0;
+        while (t < (tf - dt / 2)) {
+            const double step = (t + dt > tf) ? (tf - t) : dt;
+            rk4(P, sw0, sw1, t, X, step);
+            t += dt;
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// K_traj: B independent trajectories, X0[B][S] -> Xf[B][S].
+// HBM side: the wave's 64 rows are one contiguous 64*S*8-byte span; it is read and written with
+// consecutive lanes on consecutive doubles (coalesced) and transposed through LDS so that each
+// lane ends up with its own row in registers.
+// ---------------------------------------------------------------------------------------------
+template <class Mdl>
+__global__ __launch_bounds__(64) void traj_lane_kernel(ModelParams P, int B,
+                                                       const double *__restrict__ t0,
+                                                       const double *__restrict__ tf,
+                                                       const double *__restrict__ sw,
+                                                       const double *__restrict__ X0,
+                                                       double *__restrict__ Xf)
+{
+    constexpr int S = Mdl::S;
+    constexpr int LD = S + 1;                       // padded row: conflict-free lane-strided access
+    __shared__ double tile[64 * LD];
+    const int lane = threadIdx.x;
+    const long row0 = (long)blockIdx.x * 64;
+    const int rows = (B - row0) < 64 ? (int)(B - row0) : 64;
+    const double *src = X0 + row0 * S;
+    for (int idx = lane; idx < rows * S; idx += 64) tile[(idx / S) * LD + (idx % S)] = src[idx];
+    __syncthreads();
+
+    double X[S];
+    const bool live = lane < rows;
+    if (live) {
+#pragma unroll
+        for (int k = 0; k < S; k++) X[k] = tile[lane * LD + k];
+        const long b = row0 + lane;
+        const double s0 = sw ? sw[2 * b] : P.sw0;
+        const double s1 = sw ? sw[2 * b + 1] : P.sw1;
+        Lane<Mdl>::integrate(P, s0, s1, t0[b], tf[b], X);
+#pragma unroll
+        for (int k = 0; k < S; k++) tile[lane * LD + k] = X[k];
+    }
+    __syncthreads();
+    double *dst = Xf + row0 * S;
+    for (int idx = lane; idx < rows * S; idx += 64) dst[idx] = tile[(idx / S) * LD + (idx % S)];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Shooting residual pieces shared by K_res and K_fdj.  One trajectory = (row, segment i).
+// It owns these residual rows (shooting.cpp:945-990):
+//   i == 0     : F[0..d)            initial rows (+ H row at s*M when t0 is FREE)
+//   i <  M-1   : F[s(i+1) .. +s)    continuity at node i+1 (+ free-time row of node i+1)
+//   i == M-1   : F[d..2d)           final rows (+ H row when tf is FREE)
+// `Emit` receives (row index, value).
+// ---------------------------------------------------------------------------------------------
+template <class Mdl, class ZRead, class Emit>
+__device__ __forceinline__ void segment_residual(const ModelParams &P, const ProblemDev &pb,
+                                                 const ZRead &z, int i, Emit &&emit)
+{
+    constexpr int S = Mdl::S;
+    constexpr int D = Mdl::D;
+    const int M = pb.M;
+
+    // timeline entries this segment needs (shooting.cpp:1579-1617)
+    auto jt = [&](int j) -> double { const int kind = pb.node_kind[j]; return kind >= 0 ? z(kind) : pb.time[j]; };
+    auto nt = [&](int k) -> double {
+        const int kind = pb.node_kind[k];
+        if (kind >= -1) return jt(k);
+        const int a = pb.lo[k], b = pb.hi[k];
+        const double ta = jt(a), tb = jt(b);
+        return ta + (k - a) * (tb - ta) / (b - a);
+    };
+    const double t1 = nt(i), t2 = nt(i + 1);
+    // model switching times = FREE node times with index < M, in node order (:1604,1615)
+    const double sw0 = pb.sw_node0 >= 0 ? nt(pb.sw_node0) : P.sw0;
+    const double sw1 = pb.sw_node1 >= 0 ? nt(pb.sw_node1) : P.sw1;
+
+    double X1[S], X[S];
+#pragma unroll
+    for (int k = 0; k < S; k++) { X1[k] = z(S * i + k); X[k] = X1[k]; }
+    Lane<Mdl>::integrate(P, sw0, sw1, t1, t2, X);          // shooting.cpp:943 Move(t1, X1, t2)
+
+    if (i == 0) {
+        // model.hpp:196-228 InitialFunction / :239-290 InitialHFunction, isJac == 0
+#pragma unroll
+        for (int j = 0; j < D; j++) {
+            const bool fr = pb.mode_x[j] == 1;
+            emit(j, fr ? X1[j + D] : X1[j] - pb.xnode[j]);
+        }
+        if (pb.ft_row[0] >= 0) emit(pb.ft_row[0], Mdl::hamiltonian(P, sw0, sw1, t1, X1));
+    }
+    if (i < M - 1) {
+        double Xp[S];
+#pragma unroll
+        for (int k = 0; k < S; k++) Xp[k] = z(S * (i + 1) + k);
+        // free interior time: model::SwitchingTimesFunction (shooting.cpp:964-968)
+        if (pb.ft_row[i + 1] >= 0) emit(pb.ft_row[i + 1], Mdl::switching_fn(P, sw0, sw1, t2, X, Xp));
+        // shooting::MultipleShootingFunction, isJac == 0 (shooting.cpp:1511-1576)
+        const int *mx = pb.mode_x + (i + 1) * D;
+        const double *xd = pb.xnode + (i + 1) * S;
+#pragma unroll
+        for (int j = 0; j < D; j++) {
+            const int row = S * (i + 1) + j;
+            if (mx[j] == 0) {                               // FIXED: pin both sides
+                emit(row, X[j] - xd[j]);
+                emit(row + D, Xp[j] - xd[j]);
+            } else {                                        // CONTINUOUS
+                emit(row, X[j] - Xp[j]);
+                emit(row + D, X[j + D] - Xp[j + D]);
+            }
+        }
+    }
+    if (i == M - 1) {
+        // model.hpp:90-122 FinalFunction / :133-185 FinalHFunction, isJac == 0
+        const int *mx = pb.mode_x + M * D;
+        const double *xd = pb.xnode + M * S;
+#pragma unroll
+        for (int j = 0; j < D; j++) {
+            const bool fr = mx[j] == 1;
+            emit(D + j, fr ? X[j + D] : X[j] - xd[j]);
+        }
+        if (pb.ft_row[M] >= 0) emit(pb.ft_row[M], Mdl::hamiltonian(P, sw0, sw1, t2, X));
+    }
+}
+
+// K_res: Z[B][n] -> F[B][n]; trajectory index T = row*M + segment.
+template <class Mdl>
+__global__ __launch_bounds__(64) void residual_lane_kernel(ModelParams P, ProblemDev pb, int B,
+                                                           const double *__restrict__ Z,
+                                                           double *__restrict__ F)
+{
+    const long T = (long)blockIdx.x * 64 + threadIdx.x;
+    if (T >= (long)B * pb.M) return;
+    const long b = T / pb.M;
+    const int i = (int)(T - b * pb.M);
+    const double *zr = Z + b * pb.n;
+    double *fr = F + b * pb.n;
+    auto z = [=](int k) -> double { return zr[k]; };
+    segment_residual<Mdl>(P, pb, z, i, [=](int row, double v) { fr[row] = v; });
+}
+
+// K_fdj: MINPACK fdjac1 columns as one batch.  `pairs[T]` = (column j,
+// segment i) to integrate; the unknown vector of column j is z with z_j + h_j generated on the
+// fly, so the perturbation matrix never exists in HBM: reads are z[n], fvec[n] (cache
+// resident), writes are the Jacobian entries fjac[row + n*j] = (F_j[row] - fvec[row]) / h_j.
+template <class Mdl>
+__global__ __launch_bounds__(64) void fdjac_lane_kernel(ModelParams P, ProblemDev pb, int T,
+                                                        const int2 *__restrict__ pairs,
+                                                        const double *__restrict__ zb,
+                                                        const double *__restrict__ fvec,
+                                                        double eps, double *__restrict__ fjac)
+{
+    const int tid = blockIdx.x * 64 + threadIdx.x;
+    if (tid >= T) return;
+    const int j = pairs[tid].x, i = pairs[tid].y;
+    const double temp = zb[j];
+    double h = eps * fabs(temp);
+    if (h == 0) h = eps;
+    const double zj = temp + h;
+    auto z = [=](int k) -> double { return k == j ? zj : zb[k]; };
+    double *col = fjac + (long)pb.n * j;
+    segment_residual<Mdl>(P, pb, z, i, [=](int row, double v) { col[row] = (v - fvec[row]) / h; });
+}
+
+// K_eval: model::Model / Control / Hamiltonian for a batch of (t, X) points (set-up and trace
+// paths of the host mirror; not on the hot path).
+template <class Mdl>
+__global__ __launch_bounds__(64) void eval_lane_kernel(ModelParams P, int what, int B,
+                                                       const double *__restrict__ t,
+                                                       const double *__restrict__ sw,
+                                                       const double *__restrict__ Xin,
+                                                       double *__restrict__ out)
+{
+    constexpr int S = Mdl::S;
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    double X[S];
+#pragma unroll
+    for (int k = 0; k < S; k++) X[k] = Xin[(long)b * S + k];
+    const double s0 = sw ? sw[2 * b] : P.sw0;
+    const double s1 = sw ? sw[2 * b + 1] : P.sw1;
+    if (what == 0) {
+        double dX[S];
+        Mdl::rhs(P, s0, s1, t[b], X, dX);
+#pragma unroll
+        for (int k = 0; k < S; k++) out[(long)b * S + k] = dX[k];
+    } else if (what == 1) {
+        double u[3];
+        Mdl::control_only(P, s0, s1, t[b], X, u);
+        out[3L * b] = u[0]; out[3L * b + 1] = u[1]; out[3L * b + 2] = u[2];
+    } else {
+        out[b] = Mdl::hamiltonian(P, s0, s1, t[b], X);
+    }
+}
+
+}  // namespace socp

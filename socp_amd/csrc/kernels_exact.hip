@@ -1,0 +1,8 @@
+// kernels_exact.hip -- reference-operation-order kernels.  MUST be compiled with
+// -ffp-contract=off (see socp_amd/csrc/Makefile): the parity tests compare these against the
+// CPU oracle at the few-ulp level.
+#include "models_exact.hpp"
+#define SOCP_FLAVOUR exact
+#define SOCP_GODDARD GoddardExact
+#define SOCP_DINT DIntExact
+#include "launch_impl.hpp"

@@ -1,0 +1,8 @@
+// kernels_fast.hip -- throughput flavour: compiled with FMA contraction, restructured models
+// (models_fast.hpp).  Results agree with the reference order to rounding level, not bitwise;
+// the tolerance is stated and tested in tests/test_gpu_parity.py.
+#include "models_fast.hpp"
+#define SOCP_FLAVOUR fast
+#define SOCP_GODDARD GoddardFast
+#define SOCP_DINT DIntFast
+#include "launch_impl.hpp"

@@ -1,0 +1,60 @@
+// launch_impl.hpp -- body of the launchers; included once per flavour with
+// SOCP_FLAVOUR, SOCP_GODDARD and SOCP_DINT defined by the including .hip file.
+#include "integrator.hpp"
+#include "launch.hpp"
+
+namespace socp {
+
+#define SOCP_CAT_(a, b) a##b
+#define SOCP_CAT(a, b) SOCP_CAT_(a, b)
+
+static inline unsigned blocks_for(long n) { return (unsigned)((n + 63) / 64); }
+
+hipError_t SOCP_CAT(traj_, SOCP_FLAVOUR)(int model_id, hipStream_t st, const ModelParams &P, int B,
+                                         const double *t0, const double *tf, const double *sw,
+                                         const double *X0, double *Xf)
+{
+    if (B <= 0) return hipSuccess;
+    if (model_id == 1)
+        hipLaunchKernelGGL(traj_lane_kernel<SOCP_GODDARD>, dim3(blocks_for(B)), dim3(64), 0, st, P, B, t0, tf, sw, X0, Xf);
+    else
+        hipLaunchKernelGGL(traj_lane_kernel<SOCP_DINT>, dim3(blocks_for(B)), dim3(64), 0, st, P, B, t0, tf, sw, X0, Xf);
+    return hipGetLastError();
+}
+
+hipError_t SOCP_CAT(residual_, SOCP_FLAVOUR)(int model_id, hipStream_t st, const ModelParams &P,
+                                             const ProblemDev &pb, int B, const double *Z, double *F)
+{
+    if (B <= 0) return hipSuccess;
+    const long T = (long)B * pb.M;
+    if (model_id == 1)
+        hipLaunchKernelGGL(residual_lane_kernel<SOCP_GODDARD>, dim3(blocks_for(T)), dim3(64), 0, st, P, pb, B, Z, F);
+    else
+        hipLaunchKernelGGL(residual_lane_kernel<SOCP_DINT>, dim3(blocks_for(T)), dim3(64), 0, st, P, pb, B, Z, F);
+    return hipGetLastError();
+}
+
+hipError_t SOCP_CAT(fdjac_, SOCP_FLAVOUR)(int model_id, hipStream_t st, const ModelParams &P,
+                                          const ProblemDev &pb, int T, const int2 *pairs, const double *z,
+                                          const double *fvec, double eps, double *fjac)
+{
+    if (T <= 0) return hipSuccess;
+    if (model_id == 1)
+        hipLaunchKernelGGL(fdjac_lane_kernel<SOCP_GODDARD>, dim3(blocks_for(T)), dim3(64), 0, st, P, pb, T, pairs, z, fvec, eps, fjac);
+    else
+        hipLaunchKernelGGL(fdjac_lane_kernel<SOCP_DINT>, dim3(blocks_for(T)), dim3(64), 0, st, P, pb, T, pairs, z, fvec, eps, fjac);
+    return hipGetLastError();
+}
+
+hipError_t SOCP_CAT(eval_, SOCP_FLAVOUR)(int model_id, hipStream_t st, const ModelParams &P, int what, int B,
+                                         const double *t, const double *sw, const double *X, double *out)
+{
+    if (B <= 0) return hipSuccess;
+    if (model_id == 1)
+        hipLaunchKernelGGL(eval_lane_kernel<SOCP_GODDARD>, dim3(blocks_for(B)), dim3(64), 0, st, P, what, B, t, sw, X, out);
+    else
+        hipLaunchKernelGGL(eval_lane_kernel<SOCP_DINT>, dim3(blocks_for(B)), dim3(64), 0, st, P, what, B, t, sw, X, out);
+    return hipGetLastError();
+}
+
+}  // namespace socp

@@ -1,0 +1,616 @@
+// minpack.cpp -- Powell hybrid method (MINPACK hybrd / hybrj) as a resumable state machine,
+// plus the CMinPack-compatible callback entry points built on it.
+//
+// Written from the published MINPACK algorithm (More, Garbow, Hillstrom, ANL-80-74; SURVEY.md
+// Appendix A): forward-difference or user Jacobian, Householder QR without pivoting, dogleg
+// trust-region step, Broyden rank-1 updates of the QR factors through Givens rotations.
+// CMinPack is an un-vendored dependency of the reference (src/socp/CMakeLists.txt:11-24); the
+// call sites this replaces are shooting.cpp:803-826 (hybrd) and :830-851 (hybrj).
+// Iterates are validated against SciPy's MINPACK (scipy.optimize._minpack) in
+// tests/test_minpack.py.
+//
+// Host code by design: the O(n^3) factor work stays on the CPU; what it
+// asks for -- residuals and Jacobian columns -- is what the GPU computes.
+#include "../../include/socp_solver.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+constexpr double kEpsMch = DBL_EPSILON;      // dpmpar(1)
+constexpr double kGiant = DBL_MAX;           // dpmpar(3)
+
+// Euclidean norm with the three-accumulator scaling of MINPACK's enorm (robust against
+// overflow / destructive underflow; keeps iterates comparable with other MINPACK builds).
+double enorm(int n, const double *x)
+{
+    const double rdwarf = 3.834e-20, rgiant = 1.304e19;
+    double s1 = 0, s2 = 0, s3 = 0, x1max = 0, x3max = 0;
+    const double agiant = rgiant / (double)n;
+    for (int i = 0; i < n; i++) {
+        const double xabs = std::fabs(x[i]);
+        if (xabs > rdwarf && xabs < agiant) {
+            s2 += xabs * xabs;
+        } else if (xabs <= rdwarf) {
+            if (xabs > x3max) {
+                const double q = x3max / xabs;
+                s3 = 1 + s3 * (q * q);
+                x3max = xabs;
+            } else if (xabs != 0) {
+                const double q = xabs / x3max;
+                s3 += q * q;
+            }
+        } else {
+            if (xabs > x1max) {
+                const double q = x1max / xabs;
+                s1 = 1 + s1 * (q * q);
+                x1max = xabs;
+            } else {
+                const double q = xabs / x1max;
+                s1 += q * q;
+            }
+        }
+    }
+    if (s1 != 0) return x1max * std::sqrt(s1 + (s2 / x1max) / x1max);
+    if (s2 != 0) {
+        if (s2 >= x3max) return std::sqrt(s2 * (1 + (x3max / s2) * (x3max * s3)));
+        return std::sqrt(x3max * ((s2 / x3max) + (x3max * s3)));
+    }
+    return x3max * std::sqrt(s3);
+}
+
+// Householder QR of the n x n matrix a (column-major, ld lda), no column pivoting: on return the
+// strict upper triangle holds R's off-diagonal, rdiag its diagonal, the lower trapezoid the
+// Householder vectors; acnorm = input column norms.
+void qrfac_nopivot(int n, double *a, int lda, double *rdiag, double *acnorm)
+{
+    for (int j = 0; j < n; j++) {
+        acnorm[j] = enorm(n, a + (size_t)j * lda);
+        rdiag[j] = acnorm[j];
+    }
+    for (int j = 0; j < n; j++) {
+        double *aj = a + (size_t)j * lda;
+        double ajnorm = enorm(n - j, aj + j);
+        if (ajnorm != 0) {
+            if (aj[j] < 0) ajnorm = -ajnorm;
+            for (int i = j; i < n; i++) aj[i] /= ajnorm;
+            aj[j] += 1;
+            for (int k = j + 1; k < n; k++) {
+                double *ak = a + (size_t)k * lda;
+                double sum = 0;
+                for (int i = j; i < n; i++) sum += aj[i] * ak[i];
+                const double temp = sum / aj[j];
+                for (int i = j; i < n; i++) ak[i] -= temp * aj[i];
+            }
+        }
+        rdiag[j] = -ajnorm;
+    }
+}
+
+// accumulate the orthogonal factor Q (n x n) from the Householder vectors left by qrfac
+void qform(int n, double *q, int ldq, double *wa)
+{
+    for (int j = 1; j < n; j++)
+        for (int i = 0; i < j; i++) q[i + (size_t)j * ldq] = 0;
+    for (int l = 0; l < n; l++) {
+        const int k = n - 1 - l;
+        double *qk = q + (size_t)k * ldq;
+        for (int i = k; i < n; i++) { wa[i] = qk[i]; qk[i] = 0; }
+        qk[k] = 1;
+        if (wa[k] != 0) {
+            for (int j = k; j < n; j++) {
+                double *qj = q + (size_t)j * ldq;
+                double sum = 0;
+                for (int i = k; i < n; i++) sum += qj[i] * wa[i];
+                const double temp = sum / wa[k];
+                for (int i = k; i < n; i++) qj[i] -= temp * wa[i];
+            }
+        }
+    }
+}
+
+// dogleg step: minimiser of |R x - qtb| within the ellipsoid |diag x| <= delta, restricted to
+// the span of the Gauss-Newton and scaled-gradient directions.  r: upper triangle by rows.
+void dogleg(int n, const double *r, const double *diag, const double *qtb, double delta,
+            double *x, double *wa1, double *wa2)
+{
+    // Gauss-Newton direction by back substitution
+    int jj = n * (n + 1) / 2;
+    for (int k = 1; k <= n; k++) {
+        const int j = n - k;                 // 0-based row
+        jj -= k;
+        int l = jj + 1;
+        double sum = 0;
+        for (int i = j + 1; i < n; i++) { sum += r[l] * x[i]; l++; }
+        double temp = r[jj];
+        if (temp == 0) {
+            l = j;
+            for (int i = 0; i <= j; i++) { temp = std::max(temp, std::fabs(r[l])); l += n - i - 1; }
+            temp = kEpsMch * temp;
+            if (temp == 0) temp = kEpsMch;
+        }
+        x[j] = (qtb[j] - sum) / temp;
+    }
+    for (int j = 0; j < n; j++) { wa1[j] = 0; wa2[j] = diag[j] * x[j]; }
+    const double qnorm = enorm(n, wa2);
+    if (qnorm <= delta) return;
+
+    // scaled gradient direction
+    int l = 0;
+    for (int j = 0; j < n; j++) {
+        const double temp = qtb[j];
+        for (int i = j; i < n; i++) { wa1[i] += r[l] * temp; l++; }
+        wa1[j] /= diag[j];
+    }
+    const double gnorm = enorm(n, wa1);
+    double sgnorm = 0;
+    double alpha = delta / qnorm;
+    if (gnorm != 0) {
+        for (int j = 0; j < n; j++) wa1[j] = (wa1[j] / gnorm) / diag[j];
+        l = 0;
+        for (int j = 0; j < n; j++) {
+            double sum = 0;
+            for (int i = j; i < n; i++) { sum += r[l] * wa1[i]; l++; }
+            wa2[j] = sum;
+        }
+        double temp = enorm(n, wa2);
+        sgnorm = (gnorm / temp) / temp;
+        alpha = 0;
+        if (sgnorm < delta) {
+            const double bnorm = enorm(n, qtb);
+            const double dq = delta / qnorm, sd = sgnorm / delta;
+            temp = (bnorm / gnorm) * (bnorm / qnorm) * sd;
+            const double d1 = temp - dq;
+            temp = temp - dq * (sd * sd) + std::sqrt(d1 * d1 + (1 - dq * dq) * (1 - sd * sd));
+            alpha = (dq * (1 - sd * sd)) / temp;
+        }
+    }
+    const double temp = (1 - alpha) * std::min(sgnorm, delta);
+    for (int j = 0; j < n; j++) x[j] = temp * wa1[j] + alpha * x[j];
+}
+
+// Givens pair eliminating b against a, with the one-number encoding MINPACK stores so that
+// r1mpyq can replay the rotation: tau = sin if |cos| >= |sin|... (see r1updt in the user guide).
+inline void givens(double a, double b, double &cs, double &sn, double &tau)
+{
+    // eliminate b using pivot a
+    if (std::fabs(a) < std::fabs(b)) {
+        const double cotan = a / b;
+        sn = 0.5 / std::sqrt(0.25 + 0.25 * (cotan * cotan));
+        cs = sn * cotan;
+        tau = 1;
+        if (std::fabs(cs) * kGiant > 1) tau = 1 / cs;
+    } else {
+        const double tn = b / a;
+        cs = 0.5 / std::sqrt(0.25 + 0.25 * (tn * tn));
+        sn = cs * tn;
+        tau = sn;
+    }
+}
+
+// rank-1 update of the packed lower-trapezoidal s (here n x n): find orthogonal Q1 with
+// (s + u v^T) Q1 lower trapezoidal again; rotations are encoded into v (first sweep) and w.
+void r1updt(int n, double *s, const double *u, double *v, double *w, bool &sing)
+{
+    const int m = n;
+    int jj = (n * (2 * m - n + 1)) / 2 - (m - n) - 1;      // 0-based index of the last diagonal
+    int l = jj;
+    for (int i = n - 1; i < m; i++) { w[i] = s[l]; l++; }
+    for (int nmj = 1; nmj <= n - 1; nmj++) {
+        const int j = n - 1 - nmj;
+        jj -= (m - j);
+        w[j] = 0;
+        if (v[j] != 0) {
+            double cs, sn, tau;
+            givens(v[n - 1], v[j], cs, sn, tau);
+            v[n - 1] = sn * v[j] + cs * v[n - 1];
+            v[j] = tau;
+            l = jj;
+            for (int i = j; i < m; i++) {
+                const double temp = cs * s[l] - sn * w[i];
+                w[i] = sn * s[l] + cs * w[i];
+                s[l] = temp;
+                l++;
+            }
+        }
+    }
+    for (int i = 0; i < m; i++) w[i] += v[n - 1] * u[i];
+    sing = false;
+    for (int j = 0; j < n - 1; j++) {
+        if (w[j] != 0) {
+            double cs, sn, tau;
+            givens(s[jj], w[j], cs, sn, tau);
+            l = jj;
+            for (int i = j; i < m; i++) {
+                const double temp = cs * s[l] + sn * w[i];
+                w[i] = -sn * s[l] + cs * w[i];
+                s[l] = temp;
+                l++;
+            }
+            w[j] = tau;
+        }
+        if (s[jj] == 0) sing = true;
+        jj += (m - j);
+    }
+    l = jj;
+    for (int i = n - 1; i < m; i++) { s[l] = w[i]; l++; }
+    if (s[jj] == 0) sing = true;
+}
+
+inline void decode_rotation(double t, double &cs, double &sn)
+{
+    if (std::fabs(t) > 1) { cs = 1 / t; sn = std::sqrt(1 - cs * cs); }
+    else { sn = t; cs = std::sqrt(1 - sn * sn); }
+}
+
+// a (m x n, column-major) <- a * Q1 with Q1 replayed from the encodings left in v and w by r1updt
+void r1mpyq(int m, int n, double *a, int lda, const double *v, const double *w)
+{
+    double *an = a + (size_t)(n - 1) * lda;
+    for (int nmj = 1; nmj <= n - 1; nmj++) {
+        const int j = n - 1 - nmj;
+        double cs, sn;
+        decode_rotation(v[j], cs, sn);
+        double *aj = a + (size_t)j * lda;
+        for (int i = 0; i < m; i++) {
+            const double temp = cs * aj[i] - sn * an[i];
+            an[i] = sn * aj[i] + cs * an[i];
+            aj[i] = temp;
+        }
+    }
+    for (int j = 0; j < n - 1; j++) {
+        double cs, sn;
+        decode_rotation(w[j], cs, sn);
+        double *aj = a + (size_t)j * lda;
+        for (int i = 0; i < m; i++) {
+            const double temp = cs * aj[i] + sn * an[i];
+            an[i] = -sn * aj[i] + cs * an[i];
+            aj[i] = temp;
+        }
+    }
+}
+
+enum Phase { PH_INIT, PH_F0, PH_JAC, PH_TRIAL, PH_DONE };
+
+struct Core {
+    // configuration
+    int n = 0, maxfev = 0, mode = 1, msum = 0, ldfjac = 0, lr = 0;
+    double xtol = 0, epsfcn = 0, factor = 0;
+    bool analytic = false, bad_input = false;
+    // caller-visible arrays
+    double *x = nullptr, *fvec = nullptr, *diag = nullptr, *fjac = nullptr, *r = nullptr, *qtf = nullptr;
+    double *wa1 = nullptr, *wa2 = nullptr, *wa3 = nullptr, *wa4 = nullptr;
+    // iteration state
+    Phase phase = PH_INIT;
+    int iter = 0, ncsuc = 0, ncfail = 0, nslow1 = 0, nslow2 = 0, nfev = 0, njev = 0, info = 0;
+    bool jeval = false, sing = false;
+    double delta = 0, xnorm = 0, fnorm = 0, pnorm = 0;
+
+    int request_jac(const double **xe, double **out)
+    {
+        jeval = true;
+        phase = PH_JAC;
+        *xe = x; *out = fjac;
+        return SOCP_REQ_JAC;
+    }
+
+    int request_trial(const double **xe, double **out)
+    {
+        // direction p, trial point x + p, scaled step length
+        dogleg(n, r, diag, qtf, delta, wa1, wa2, wa3);
+        for (int j = 0; j < n; j++) {
+            wa1[j] = -wa1[j];
+            wa2[j] = x[j] + wa1[j];
+            wa3[j] = diag[j] * wa1[j];
+        }
+        pnorm = enorm(n, wa3);
+        if (iter == 1) delta = std::min(delta, pnorm);
+        phase = PH_TRIAL;
+        *xe = wa2; *out = wa4;
+        return SOCP_REQ_FVEC;
+    }
+
+    int finish(int code)
+    {
+        info = code;
+        phase = PH_DONE;
+        return SOCP_REQ_DONE;
+    }
+
+    void after_jacobian()
+    {
+        if (analytic) njev += 1; else nfev += msum;
+        qrfac_nopivot(n, fjac, ldfjac, wa1, wa2);      // wa1 = diag(R), wa2 = column norms
+        if (iter == 1) {
+            if (mode != 2)
+                for (int j = 0; j < n; j++) diag[j] = wa2[j] == 0 ? 1.0 : wa2[j];
+            for (int j = 0; j < n; j++) wa3[j] = diag[j] * x[j];
+            xnorm = enorm(n, wa3);
+            delta = factor * xnorm;
+            if (delta == 0) delta = factor;
+        }
+        // qtf = Q^T fvec from the Householder vectors
+        for (int i = 0; i < n; i++) qtf[i] = fvec[i];
+        for (int j = 0; j < n; j++) {
+            const double *aj = fjac + (size_t)j * ldfjac;
+            if (aj[j] != 0) {
+                double sum = 0;
+                for (int i = j; i < n; i++) sum += aj[i] * qtf[i];
+                const double temp = -sum / aj[j];
+                for (int i = j; i < n; i++) qtf[i] += aj[i] * temp;
+            }
+        }
+        // R into packed row storage
+        sing = false;
+        for (int j = 0; j < n; j++) {
+            int l = j;
+            for (int i = 0; i < j; i++) { r[l] = fjac[i + (size_t)j * ldfjac]; l += n - i - 1; }
+            r[l] = wa1[j];
+            if (wa1[j] == 0) sing = true;
+        }
+        qform(n, fjac, ldfjac, wa1);
+        if (mode != 2)
+            for (int j = 0; j < n; j++) diag[j] = std::max(diag[j], wa2[j]);
+    }
+
+    // returns true when the solve continues with another trial on the current factorisation
+    int after_trial(const double **xe, double **out)
+    {
+        const double p1 = .1, p5 = .5, p001 = .001, p0001 = 1e-4;
+        nfev += 1;
+        const double fnorm1 = enorm(n, wa4);
+        double actred = -1;
+        if (fnorm1 < fnorm) { const double q = fnorm1 / fnorm; actred = 1 - q * q; }
+        // predicted reduction from |qtf + R p|
+        int l = 0;
+        for (int i = 0; i < n; i++) {
+            double sum = 0;
+            for (int j = i; j < n; j++) { sum += r[l] * wa1[j]; l++; }
+            wa3[i] = qtf[i] + sum;
+        }
+        const double temp = enorm(n, wa3);
+        double prered = 0;
+        if (temp < fnorm) { const double q = temp / fnorm; prered = 1 - q * q; }
+        const double ratio = prered > 0 ? actred / prered : 0;
+
+        if (ratio < p1) {
+            ncsuc = 0; ncfail += 1; delta = p5 * delta;
+        } else {
+            ncfail = 0; ncsuc += 1;
+            if (ratio >= p5 || ncsuc > 1) delta = std::max(delta, pnorm / p5);
+            if (std::fabs(ratio - 1) <= p1) delta = pnorm / p5;
+        }
+        if (ratio >= p0001) {
+            for (int j = 0; j < n; j++) { x[j] = wa2[j]; wa2[j] = diag[j] * x[j]; fvec[j] = wa4[j]; }
+            xnorm = enorm(n, wa2);
+            fnorm = fnorm1;
+            iter += 1;
+        }
+        nslow1 += 1; if (actred >= p001) nslow1 = 0;
+        if (jeval) nslow2 += 1;
+        if (actred >= p1) nslow2 = 0;
+
+        if (delta <= xtol * xnorm || fnorm == 0) return finish(1);
+        int code = 0;
+        if (nfev >= maxfev) code = 2;
+        if (p1 * std::max(p1 * delta, pnorm) <= kEpsMch * xnorm) code = 3;
+        if (nslow2 == 5) code = 4;
+        if (nslow1 == 10) code = 5;
+        if (code != 0) return finish(code);
+        if (ncfail == 2) return request_jac(xe, out);
+
+        // Broyden rank-1 update of (Q, R, Q^T f)
+        for (int j = 0; j < n; j++) {
+            const double *qj = fjac + (size_t)j * ldfjac;
+            double sum = 0;
+            for (int i = 0; i < n; i++) sum += qj[i] * wa4[i];
+            wa2[j] = (sum - wa3[j]) / pnorm;
+            wa1[j] = diag[j] * ((diag[j] * wa1[j]) / pnorm);
+            if (ratio >= p0001) qtf[j] = sum;
+        }
+        r1updt(n, r, wa1, wa2, wa3, sing);
+        r1mpyq(n, n, fjac, ldfjac, wa2, wa3);
+        r1mpyq(1, n, qtf, 1, wa2, wa3);
+        jeval = false;
+        return request_trial(xe, out);
+    }
+
+    int advance(int flag, const double **xe, double **out)
+    {
+        if (phase == PH_DONE) return SOCP_REQ_DONE;
+        if (phase != PH_INIT && flag < 0) return finish(flag);
+        switch (phase) {
+        case PH_INIT:
+            info = 0; nfev = 0; njev = 0;
+            if (bad_input) return finish(0);
+            if (mode == 2)
+                for (int j = 0; j < n; j++) if (diag[j] <= 0) return finish(0);
+            phase = PH_F0;
+            *xe = x; *out = fvec;
+            return SOCP_REQ_FVEC;
+        case PH_F0:
+            nfev = 1;
+            fnorm = enorm(n, fvec);
+            iter = 1; ncsuc = ncfail = nslow1 = nslow2 = 0;
+            return request_jac(xe, out);
+        case PH_JAC:
+            after_jacobian();
+            return request_trial(xe, out);
+        case PH_TRIAL:
+            return after_trial(xe, out);
+        default:
+            return SOCP_REQ_DONE;
+        }
+    }
+};
+
+// MINPACK fdjac1 through a one-point callback: dense when ml+mu+1 >= n, banded otherwise.
+int fdjac1(cminpack_func_nn fcn, void *p, int n, double *x, const double *fvec, double *fjac, int ldfjac,
+           int ml, int mu, double epsfcn, double *wa1, double *wa2)
+{
+    const double eps = std::sqrt(std::max(epsfcn, kEpsMch));
+    const int msum = ml + mu + 1;
+    int iflag = 0;
+    if (msum >= n) {
+        for (int j = 0; j < n; j++) {
+            const double temp = x[j];
+            double h = eps * std::fabs(temp);
+            if (h == 0) h = eps;
+            x[j] = temp + h;
+            iflag = fcn(p, n, x, wa1, 2);
+            if (iflag < 0) return iflag;
+            x[j] = temp;
+            for (int i = 0; i < n; i++) fjac[i + (size_t)j * ldfjac] = (wa1[i] - fvec[i]) / h;
+        }
+        return 0;
+    }
+    for (int k = 0; k < msum; k++) {
+        for (int j = k; j < n; j += msum) {
+            wa2[j] = x[j];
+            double h = eps * std::fabs(wa2[j]);
+            if (h == 0) h = eps;
+            x[j] = wa2[j] + h;
+        }
+        iflag = fcn(p, n, x, wa1, 2);
+        if (iflag < 0) return iflag;
+        for (int j = k; j < n; j += msum) {
+            x[j] = wa2[j];
+            double h = eps * std::fabs(wa2[j]);
+            if (h == 0) h = eps;
+            for (int i = 0; i < n; i++) {
+                fjac[i + (size_t)j * ldfjac] = 0;
+                if (i >= j - mu && i <= j + ml) fjac[i + (size_t)j * ldfjac] = (wa1[i] - fvec[i]) / h;
+            }
+        }
+    }
+    return 0;
+}
+
+void bind(Core &s, int n, double *x, double *fvec, double xtol, int maxfev, double epsfcn, double *diag, int mode,
+          double factor, double *fjac, int ldfjac, double *r, int lr, double *qtf,
+          double *wa1, double *wa2, double *wa3, double *wa4)
+{
+    s.n = n; s.x = x; s.fvec = fvec; s.xtol = xtol; s.maxfev = maxfev; s.epsfcn = epsfcn; s.diag = diag;
+    s.mode = mode; s.factor = factor; s.fjac = fjac; s.ldfjac = ldfjac; s.r = r; s.lr = lr; s.qtf = qtf;
+    s.wa1 = wa1; s.wa2 = wa2; s.wa3 = wa3; s.wa4 = wa4;
+    s.bad_input = n <= 0 || xtol < 0 || maxfev <= 0 || factor <= 0 || ldfjac < n || lr < n * (n + 1) / 2;
+    s.phase = PH_INIT;
+}
+
+}  // namespace
+
+extern "C" {
+
+int socp_hybrd_batched(cminpack_func_nn fcn, socp_fdjac_fn fdjac, void *p, int n, double *x, double *fvec,
+                       double xtol, int maxfev, int ml, int mu, double epsfcn, double *diag, int mode,
+                       double factor, int nprint, int *nfev, double *fjac, int ldfjac, double *r, int lr,
+                       double *qtf, double *wa1, double *wa2, double *wa3, double *wa4)
+{
+    (void)nprint;
+    Core s;
+    bind(s, n, x, fvec, xtol, maxfev, epsfcn, diag, mode, factor, fjac, ldfjac, r, lr, qtf, wa1, wa2, wa3, wa4);
+    s.analytic = false;
+    if (ml < 0 || mu < 0) s.bad_input = true;
+    s.msum = std::min(ml + mu + 1, n);
+    const double *xe = nullptr;
+    double *out = nullptr;
+    int flag = 0;
+    for (;;) {
+        const int req = s.advance(flag, &xe, &out);
+        if (req == SOCP_REQ_DONE) break;
+        if (req == SOCP_REQ_FVEC) {
+            flag = fcn(p, n, xe, out, 1);
+        } else if (fdjac) {
+            flag = fdjac(p, n, xe, fvec, epsfcn, out, ldfjac);
+        } else {
+            flag = fdjac1(fcn, p, n, x, fvec, out, ldfjac, ml, mu, epsfcn, wa1, wa2);
+        }
+    }
+    if (nfev) *nfev = s.nfev;
+    return s.info;
+}
+
+int hybrd(cminpack_func_nn fcn, void *p, int n, double *x, double *fvec, double xtol, int maxfev,
+          int ml, int mu, double epsfcn, double *diag, int mode, double factor, int nprint,
+          int *nfev, double *fjac, int ldfjac, double *r, int lr, double *qtf,
+          double *wa1, double *wa2, double *wa3, double *wa4)
+{
+    return socp_hybrd_batched(fcn, nullptr, p, n, x, fvec, xtol, maxfev, ml, mu, epsfcn, diag, mode, factor,
+                              nprint, nfev, fjac, ldfjac, r, lr, qtf, wa1, wa2, wa3, wa4);
+}
+
+int hybrj(cminpack_funcder_nn fcn, void *p, int n, double *x, double *fvec, double *fjac, int ldfjac,
+          double xtol, int maxfev, double *diag, int mode, double factor, int nprint,
+          int *nfev, int *njev, double *r, int lr, double *qtf,
+          double *wa1, double *wa2, double *wa3, double *wa4)
+{
+    (void)nprint;
+    Core s;
+    bind(s, n, x, fvec, xtol, maxfev, 0.0, diag, mode, factor, fjac, ldfjac, r, lr, qtf, wa1, wa2, wa3, wa4);
+    s.analytic = true;
+    const double *xe = nullptr;
+    double *out = nullptr;
+    int flag = 0;
+    for (;;) {
+        const int req = s.advance(flag, &xe, &out);
+        if (req == SOCP_REQ_DONE) break;
+        if (req == SOCP_REQ_FVEC) flag = fcn(p, n, xe, out, fjac, ldfjac, 1);
+        else flag = fcn(p, n, xe, fvec, out, ldfjac, 2);
+    }
+    if (nfev) *nfev = s.nfev;
+    if (njev) *njev = s.njev;
+    return s.info;
+}
+
+/* ---- resumable object ---- */
+struct socp_hybr {
+    Core core;
+    std::vector<double> x, fvec, diag, fjac, r, qtf, wa1, wa2, wa3, wa4;
+    double epsfcn = 0;
+};
+
+socp_hybr *socp_hybr_create(int n, double xtol, int maxfev, double epsfcn, int mode, double factor, int analytic_jac)
+{
+    if (n <= 0) return nullptr;
+    socp_hybr *s = new socp_hybr;
+    s->x.assign(n, 0); s->fvec.assign(n, 0); s->diag.assign(n, 1); s->fjac.assign((size_t)n * n, 0);
+    s->r.assign((size_t)n * (n + 1) / 2, 0); s->qtf.assign(n, 0);
+    s->wa1.assign(n, 0); s->wa2.assign(n, 0); s->wa3.assign(n, 0); s->wa4.assign(n, 0);
+    s->epsfcn = epsfcn;
+    bind(s->core, n, s->x.data(), s->fvec.data(), xtol, maxfev, epsfcn, s->diag.data(), mode, factor,
+         s->fjac.data(), n, s->r.data(), n * (n + 1) / 2, s->qtf.data(),
+         s->wa1.data(), s->wa2.data(), s->wa3.data(), s->wa4.data());
+    s->core.analytic = analytic_jac != 0;
+    s->core.msum = n;
+    return s;
+}
+
+void socp_hybr_destroy(socp_hybr *s) { delete s; }
+
+int socp_hybr_start(socp_hybr *s, const double *x0, const double *diag)
+{
+    if (!s || !x0) return -1;
+    std::memcpy(s->x.data(), x0, sizeof(double) * s->core.n);
+    if (diag) std::memcpy(s->diag.data(), diag, sizeof(double) * s->core.n);
+    else std::fill(s->diag.begin(), s->diag.end(), 1.0);
+    s->core.phase = PH_INIT;
+    return 0;
+}
+
+int socp_hybr_advance(socp_hybr *s, int user_flag, const double **x_eval, double **out)
+{
+    return s->core.advance(user_flag, x_eval, out);
+}
+
+int socp_hybr_info(const socp_hybr *s) { return s->core.info; }
+int socp_hybr_nfev(const socp_hybr *s) { return s->core.nfev; }
+int socp_hybr_njev(const socp_hybr *s) { return s->core.njev; }
+const double *socp_hybr_x(const socp_hybr *s) { return s->x.data(); }
+const double *socp_hybr_fvec(const socp_hybr *s) { return s->fvec.data(); }
+double socp_hybr_epsfcn(const socp_hybr *s) { return s->epsfcn; }
+
+}  // extern "C"

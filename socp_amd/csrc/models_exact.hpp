@@ -1,0 +1,236 @@
+// models_exact.hpp -- device dynamics in the REFERENCE OPERATION ORDER.
+//
+// These are the parity anchors on the GPU: every product, quotient and sum is formed in the
+// association order of the reference expressions, the translation unit is compiled with
+// -ffp-contract=off, and divisions / square roots are the IEEE-correct expansions.  Repeated
+// sub-expressions (the reference evaluates exp(-kr(r-1)) ten times per call, and Control()
+// recomputes what Model() already has) are bitwise-equal values, so naming them once does not
+// change any result.  The only rounding that can differ from the x86 reference is inside
+// ocml's exp.  Citations: file:line into bherisse/socp.
+#pragma once
+#include "dev_common.hpp"
+
+namespace socp {
+
+enum { GP_C = 0, GP_B, GP_KD, GP_KR, GP_UMAX, GP_MU1, GP_MU2, GP_SING };
+enum { DP_UMAX = 0, DP_AMAX, DP_MUT };
+
+struct GoddardExact {
+    static constexpr int D = 7;
+    static constexpr int S = 14;
+
+    // quantities both Model() and Control() derive from the state (goddard.cpp:66-76,121-130)
+    struct Common {
+        double r, v, pvdotv, g, norm_pv, E;
+    };
+
+    __device__ static __forceinline__ Common common(const ModelParams &P, const double (&X)[S])
+    {
+        Common c;
+        c.r = sqrt(X[0]*X[0] + X[1]*X[1] + X[2]*X[2]);
+        c.v = sqrt(X[3]*X[3] + X[4]*X[4] + X[5]*X[5]);
+        c.pvdotv = X[10]*X[3] + X[11]*X[4] + X[12]*X[5];
+        c.g = 1 / c.r / c.r;
+        c.norm_pv = sqrt(X[10]*X[10] + X[11]*X[11] + X[12]*X[12]);
+        c.E = exp(-P.p[GP_KR]*(c.r - 1));
+        return c;
+    }
+
+    // costate derivatives of position and velocity (goddard.cpp:91-96, reused at :214-219)
+    __device__ static __forceinline__ void costate_dots(const ModelParams &P, const Common &c,
+                                                       const double (&X)[S], double (&pd)[6])
+    {
+        const double x = X[0], y = X[1], z = X[2], vx = X[3], vy = X[4], vz = X[5], mass = X[6];
+        const double p_x = X[7], p_y = X[8], p_z = X[9], p_vx = X[10], p_vy = X[11], p_vz = X[12];
+        const double KD = P.p[GP_KD], kr = P.p[GP_KR];
+        const double r = c.r, v = c.v, g = c.g, pvdotv = c.pvdotv, E = c.E;
+        const double A = -kr*KD / mass*v*E;          // common left prefix of :91-93
+        const double Q = KD / mass*E;                // common left prefix of :94-96
+        pd[0] = A*x / r*pvdotv + g*(p_vx*(1 - 3 * x*x / r / r) / r - p_vy * 3 * x*y / r / r / r - p_vz * 3 * x*z / r / r / r);
+        pd[1] = A*y / r*pvdotv + g*(-p_vx * 3 * y*x / r / r / r + p_vy*(1 - 3 * y*y / r / r) / r - p_vz * 3 * y*z / r / r / r);
+        pd[2] = A*z / r*pvdotv + g*(-p_vx * 3 * z*x / r / r / r - p_vy * 3 * z*y / r / r / r + p_vz*(1 - 3 * z*z / r / r) / r);
+        pd[3] = -p_x + Q*(pvdotv*vx / v + p_vx*v);
+        pd[4] = -p_y + Q*(pvdotv*vy / v + p_vy*v);
+        pd[5] = -p_z + Q*(pvdotv*vz / v + p_vz*v);
+    }
+
+    // goddard.cpp:188-253
+    __device__ static double singular_control(const ModelParams &P, const Common &c, const double (&X)[S])
+    {
+        const double x = X[0], y = X[1], z = X[2], vx = X[3], vy = X[4], vz = X[5], mass = X[6];
+        const double p_x = X[7], p_y = X[8], p_z = X[9], p_vx = X[10], p_vy = X[11], p_vz = X[12];
+        const double b = P.p[GP_B], C = P.p[GP_C], KD = P.p[GP_KD], kr = P.p[GP_KR];
+        const double r = c.r, v = c.v, g = c.g, pvdotv = c.pvdotv, norm_pv = c.norm_pv;
+        const double rdotv = x*vx + y*vy + z*vz;
+        const double D = KD*c.E;
+        double pd[6];
+        costate_dots(P, c, X, pd);
+        const double prdotdotpv = pd[0]*p_vx + pd[1]*p_vy + pd[2]*p_vz;
+        const double prdotpvdot = p_x*pd[3] + p_y*pd[4] + p_z*pd[5];
+        const double prdotpv = p_x*p_vx + p_y*p_vy + p_z*p_vz;
+        const double pvdotdotv = pd[3]*vx + pd[4]*vy + pd[5]*vz;
+        const double pvdotdotpv = pd[3]*p_vx + pd[4]*p_vy + pd[5]*p_vz;
+        const double vdotg = vx*g*x / r + vy*g*y / r + vz*g*z / r;
+        const double pvdotg = p_vx*g*x / r + p_vy*g*y / r + p_vz*g*z / r;
+
+        const double au = 2 * norm_pv*C / mass*pvdotv
+            + 2 * pvdotv*C / mass*norm_pv
+            - b / mass*(2 * pvdotv*pvdotv + norm_pv*norm_pv*v*v)
+            - b / D*v*prdotpv - C / D*prdotpv / v*pvdotv / norm_pv;
+
+        const double bu = -2 * norm_pv*norm_pv*(vdotg + D / mass*v*v*v) + 2 * v*v*pvdotdotpv
+            - 2 * pvdotv*(pvdotg + D / mass*v*pvdotv - pvdotdotv)
+            + b / C*(2 * norm_pv*pvdotv*(vdotg + D / mass*v*v*v) + norm_pv*v*v*(pvdotg + D / mass*v*pvdotv - pvdotdotv) - v*v*pvdotv / norm_pv*pvdotdotpv)
+            - mass / D*kr*rdotv / r*v*prdotpv + mass / D*prdotpv / v*(vdotg + D / mass*v*v*v) - mass / D*v*(prdotdotpv + prdotpvdot);
+
+        return bu / au;
+    }
+
+    // goddard.cpp:104-185
+    __device__ static __forceinline__ void control(const ModelParams &P, const Common &c, double sw0, double sw1,
+                                                  double t, const double (&X)[S], double (&u)[3])
+    {
+        const double mass = X[6], p_vx = X[10], p_vy = X[11], p_vz = X[12], p_mass = X[13];
+        const double Switch = P.p[GP_MU1] - P.p[GP_B]*p_mass - P.p[GP_C] / mass*c.norm_pv;
+        double alpha_u = 0;
+        if (P.p[GP_MU2] > 0) {
+            if (Switch < 0) alpha_u = -Switch / 2 / P.p[GP_MU2];
+        } else {
+            if (t <= sw0) {
+                alpha_u = 1.0;
+            } else if (t > sw0 && t <= sw1) {
+                alpha_u = (P.p[GP_SING] < 0) ? singular_control(P, c, X) : P.p[GP_SING];
+            }
+        }
+        u[0] = -p_vx*alpha_u / c.norm_pv;
+        u[1] = -p_vy*alpha_u / c.norm_pv;
+        u[2] = -p_vz*alpha_u / c.norm_pv;
+        const double norm_u = fabs(alpha_u);
+        const double u_max = P.p[GP_UMAX];
+        if (norm_u > u_max) {
+            u[0] = u[0] / norm_u*u_max;
+            u[1] = u[1] / norm_u*u_max;
+            u[2] = u[2] / norm_u*u_max;
+        }
+    }
+
+    // goddard.cpp:48-101
+    __device__ static __forceinline__ void rhs(const ModelParams &P, double sw0, double sw1, double t,
+                                              const double (&X)[S], double (&dX)[S])
+    {
+        const Common c = common(P, X);
+        double u[3];
+        control(P, c, sw0, sw1, t, X, u);
+        const double x = X[0], y = X[1], z = X[2], vx = X[3], vy = X[4], vz = X[5], mass = X[6];
+        const double p_vx = X[10], p_vy = X[11], p_vz = X[12];
+        const double b = P.p[GP_B], C = P.p[GP_C], KD = P.p[GP_KD];
+        const double norm_u = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+        const double pvdotu = p_vx*u[0] + p_vy*u[1] + p_vz*u[2];
+        const double W = -KD*c.v;                    // common left prefix of :84-86
+        double pd[6];
+        costate_dots(P, c, X, pd);
+        dX[0] = vx;
+        dX[1] = vy;
+        dX[2] = vz;
+        dX[3] = W*vx*c.E / mass - c.g*x / c.r + C*u[0] / mass;
+        dX[4] = W*vy*c.E / mass - c.g*y / c.r + C*u[1] / mass;
+        dX[5] = W*vz*c.E / mass - c.g*z / c.r + C*u[2] / mass;
+        dX[6] = -b*norm_u;
+        dX[7] = pd[0];
+        dX[8] = pd[1];
+        dX[9] = pd[2];
+        dX[10] = pd[3];
+        dX[11] = pd[4];
+        dX[12] = pd[5];
+        dX[13] = -KD*c.E / mass / mass*c.v*c.pvdotv + C / mass / mass*pvdotu;
+    }
+
+    // goddard.cpp:104 as a standalone entry (trace / model::Control)
+    __device__ static void control_only(const ModelParams &P, double sw0, double sw1, double t,
+                                        const double (&X)[S], double (&u)[3])
+    {
+        const Common c = common(P, X);
+        control(P, c, sw0, sw1, t, X, u);
+    }
+
+    // goddard.cpp:256-295
+    __device__ static double hamiltonian(const ModelParams &P, double sw0, double sw1, double t, const double (&X)[S])
+    {
+        const Common c = common(P, X);
+        double u[3];
+        control(P, c, sw0, sw1, t, X, u);
+        const double x = X[0], y = X[1], z = X[2], vx = X[3], vy = X[4], vz = X[5], mass = X[6];
+        const double p_x = X[7], p_y = X[8], p_z = X[9], p_vx = X[10], p_vy = X[11], p_vz = X[12], p_mass = X[13];
+        const double b = P.p[GP_B], C = P.p[GP_C], KD = P.p[GP_KD];
+        const double norm_u = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+        const double W = -KD*c.v;
+        const double H = P.p[GP_MU1]*norm_u + P.p[GP_MU2]*norm_u*norm_u
+            + p_x*vx + p_y*vy + p_z*vz
+            + p_vx*(W*vx*c.E / mass - c.g*x / c.r + C*u[0] / mass)
+            + p_vy*(W*vy*c.E / mass - c.g*y / c.r + C*u[1] / mass)
+            + p_vz*(W*vz*c.E / mass - c.g*z / c.r + C*u[2] / mass)
+            - p_mass*b*norm_u;
+        return H;
+    }
+
+    // goddard.cpp:343-370: the free interior-time row is H(t, X-) (Xp unused)
+    __device__ static double switching_fn(const ModelParams &P, double sw0, double sw1, double t,
+                                          const double (&X)[S], const double (&)[S])
+    {
+        return hamiltonian(P, sw0, sw1, t, X);
+    }
+};
+
+struct DIntExact {
+    static constexpr int D = 6;
+    static constexpr int S = 12;
+
+    // doubleIntegrator.cpp:218-259
+    __device__ static __forceinline__ void control_only(const ModelParams &P, double, double, double,
+                                                       const double (&X)[S], double (&u)[3])
+    {
+        const double a_max = P.p[DP_AMAX], u_max = P.p[DP_UMAX];
+        u[0] = -X[9] / a_max;
+        u[1] = -X[10] / a_max;
+        u[2] = -X[11] / a_max;
+        const double norm_u = sqrt(u[0]*u[0] + u[1]*u[1] + u[2]*u[2]);
+        if (norm_u > u_max) {
+            u[0] = u[0] / norm_u*u_max;
+            u[1] = u[1] / norm_u*u_max;
+            u[2] = u[2] / norm_u*u_max;
+        }
+    }
+
+    // doubleIntegrator.cpp:67-108
+    __device__ static __forceinline__ void rhs(const ModelParams &P, double sw0, double sw1, double t,
+                                              const double (&X)[S], double (&dX)[S])
+    {
+        double u[3];
+        control_only(P, sw0, sw1, t, X, u);
+        const double a_max = P.p[DP_AMAX];
+        dX[0] = X[3];  dX[1] = X[4];  dX[2] = X[5];
+        dX[3] = a_max * u[0];  dX[4] = a_max * u[1];  dX[5] = a_max * u[2];
+        dX[6] = 0;  dX[7] = 0;  dX[8] = 0;
+        dX[9] = -X[6];  dX[10] = -X[7];  dX[11] = -X[8];
+    }
+
+    // doubleIntegrator.cpp:264-300, isJac == 0
+    __device__ static double hamiltonian(const ModelParams &P, double sw0, double sw1, double t, const double (&X)[S])
+    {
+        double u[3];
+        control_only(P, sw0, sw1, t, X, u);
+        const double a_max = P.p[DP_AMAX];
+        const double norm_u = sqrt(u[0]*u[0] + u[1]*u[1] + u[2]*u[2]);
+        return P.p[DP_MUT] + a_max * a_max*norm_u*norm_u / 2 + X[6] * X[3] + X[7] * X[4] + X[8] * X[5]
+             + a_max * (X[9]*u[0] + X[10] * u[1] + X[11] * u[2]);
+    }
+
+    // model.hpp:299-304 default: H(t, X-) - H(t, X+)
+    __device__ static double switching_fn(const ModelParams &P, double sw0, double sw1, double t,
+                                          const double (&X)[S], const double (&Xp)[S])
+    {
+        return hamiltonian(P, sw0, sw1, t, X) - hamiltonian(P, sw0, sw1, t, Xp);
+    }
+};
+
+}  // namespace socp

@@ -1,0 +1,76 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def built():
+    """Make sure the checker library exists (the product library is built by __graft_entry__.build())."""
+    from oracle import oracle as orc
+    if not os.path.exists(orc.ORACLE_SO):
+        orc.build(ref=False)
+    return True
+
+
+# ---- shared problem definitions (workloads of the reference's tests) -------------------------
+
+GODDARD_X0_STATE = np.array([0.999949994, 1e-4, 0.01, 1e-10, 1e-10, 1e-10, 1.0])      # testGoddard.cpp:53-59
+# converged initial costates of the KD=310, mu2=1 problem (stage 2 of testGoddard)
+GODDARD_PSTAR = np.array([-8.121947733, 7.775439382e-3, 0.7775438809, -0.4779369965,
+                          5.715013318e-4, 5.715009222e-2, 9.958404873e-2])
+GODDARD_TF = 0.2640825
+
+
+def goddard_c1_problem(oracle_model):
+    """testGoddard.cpp:24-82: M=6, free tf, final velocity and mass free; returns (Problem, z0)."""
+    from oracle.oracle import Problem, FIXED, FREE, CONTINUOUS
+    M, d, s = 6, 7, 14
+    Xi = np.concatenate([GODDARD_X0_STATE, np.full(7, 0.1)])
+    Xf = np.zeros(14)
+    Xf[0] = 1.01
+    ti, tf = 0.0, 0.1
+    mode_t = [FIXED] + [CONTINUOUS] * (M - 1) + [FREE]
+    mode_x = np.zeros((M + 1, d), dtype=np.int32)
+    mode_x[1:M] = CONTINUOUS
+    mode_x[M, 3:7] = FREE
+    time = np.array([ti + i * (tf - ti) / M for i in range(M + 1)])
+    X = np.zeros((M + 1, s))
+    X[0], X[M] = Xi, Xf
+    for i in range(1, M):
+        X[i] = oracle_model.traj(ti, Xi, time[i])      # shooting.cpp:218-222
+    z = np.concatenate([X[:M].ravel(), [time[M]]])
+    return Problem(d, mode_t, mode_x, time, X), z
+
+
+def goddard_single_problem(tf=GODDARD_TF):
+    """BASELINE config 2: single shooting, fixed tf, n = 14 (SURVEY 8 'C2')."""
+    from oracle.oracle import Problem, FIXED, FREE
+    d, s = 7, 14
+    mode_t = [FIXED, FIXED]
+    mode_x = np.zeros((2, d), dtype=np.int32)
+    mode_x[1, 3:7] = FREE
+    X = np.zeros((2, s))
+    X[0, :7] = GODDARD_X0_STATE
+    X[1, 0] = 1.01
+    z = np.concatenate([GODDARD_X0_STATE, GODDARD_PSTAR])
+    return Problem(d, mode_t, mode_x, np.array([0.0, tf]), X), z
+
+
+def goddard_costate_batch(B, eps, seed=20250905):
+    """Synthetic starts p = p*(1 + eps*xi), xi uniform(-1,1) (SURVEY 8d 'Synthetic inputs')."""
+    rng = np.random.Generator(np.random.MT19937(seed))
+    xi = rng.uniform(-1.0, 1.0, size=(B, 7))
+    X0 = np.empty((B, 14))
+    X0[:, :7] = GODDARD_X0_STATE
+    X0[:, 7:] = GODDARD_PSTAR * (1.0 + eps * xi)
+    return X0

@@ -1,0 +1,189 @@
+"""GPU parity: HIP path (through the C-ABI) vs the CPU oracle on the same seeded inputs.
+
+Tolerances (SURVEY 8d "Parity tolerance"):
+  * reference-order variant, N = 10 / 30 steps: |Xf_gpu - Xf_cpu|_inf <= 1e-10 * max(1, |Xf|_inf)
+    (observed: a few ulp -- the only rounding that differs from x86 is inside exp);
+  * N = 1e4 steps: <= 1e-8 on the benchmark distribution;
+  * residual rows: same bound scaled by the row magnitude.
+"""
+import numpy as np
+import pytest
+
+from conftest import (GODDARD_TF, goddard_c1_problem, goddard_costate_batch, goddard_single_problem)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gctx():
+    from socp_amd import capi
+    c = capi.Context(capi.MODEL_GODDARD)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def goracle(built):
+    from oracle.oracle import Oracle, MODEL_GODDARD
+    return Oracle(MODEL_GODDARD)
+
+
+def relerr(a, b):
+    return np.max(np.abs(a - b)) / max(1.0, np.max(np.abs(b)))
+
+
+@pytest.mark.parametrize("mu2", [1.0, 0.2, 0.0])
+def test_eval_rhs_control_hamiltonian(gctx, goracle, mu2):
+    from socp_amd import capi
+    rng = np.random.default_rng(3)
+    B = 200
+    X = goddard_costate_batch(B, 0.3) * (1 + 0.05 * rng.uniform(-1, 1, (B, 14)))
+    X[:, 3:6] = rng.uniform(-0.1, 0.1, (B, 3))
+    t = rng.uniform(0, 0.12, B)        # straddles both default switching times (mu2 = 0 branches)
+    gctx.set_param("mu2", mu2)
+    goracle.set_param("mu2", mu2)
+    rhs = gctx.eval_batch(capi.EVAL_RHS, t, X)
+    ctl = gctx.eval_batch(capi.EVAL_CONTROL, t, X)
+    ham = gctx.eval_batch(capi.EVAL_HAMILTONIAN, t, X)
+    for b in range(B):
+        ref = goracle.rhs(t[b], X[b])
+        assert np.allclose(rhs[b], ref, rtol=1e-13, atol=1e-13 * np.max(np.abs(ref))), (b, rhs[b] - ref)
+        assert np.allclose(ctl[b], goracle.control(t[b], X[b]), rtol=1e-13, atol=1e-15)
+        h = goracle.hamiltonian(t[b], X[b])[0]
+        assert abs(ham[b, 0] - h) <= 1e-12 * max(1.0, abs(h))
+
+
+@pytest.mark.parametrize("N,tol", [(10, 1e-10), (1000, 1e-10)])
+def test_integrate_batch_short(gctx, goracle, N, tol):
+    gctx.set_param("mu2", 1.0)
+    goracle.set_param("mu2", 1.0)
+    gctx.set_step_number(N)
+    goracle.m.step_nbr = N
+    B = 130                               # ragged: 2 full waves + 2 lanes
+    X0 = goddard_costate_batch(B, 1e-3)
+    tf = np.full(B, GODDARD_TF)
+    Xg = gctx.integrate_batch(0.0, tf, X0)
+    Xc = goracle.integrate_batch(0.0, tf, X0)
+    assert relerr(Xg, Xc) <= tol
+
+
+def test_integrate_batch_full_size(gctx, goracle):
+    """BASELINE metric unit: 1e4 RK4 steps per trajectory."""
+    gctx.set_param("mu2", 1.0)
+    goracle.set_param("mu2", 1.0)
+    gctx.set_step_number(10000)
+    goracle.m.step_nbr = 10000
+    B = 64
+    X0 = goddard_costate_batch(B, 1e-3)
+    Xg = gctx.integrate_batch(0.0, GODDARD_TF, X0)
+    Xc = goracle.integrate_batch(0.0, GODDARD_TF, X0)
+    assert np.all(np.isfinite(Xg))
+    assert relerr(Xg, Xc) <= 1e-8
+
+
+def test_integrate_edge_cases(gctx, goracle):
+    """Empty batch, zero-length and backward segments (odeTools.cpp:136: zero steps, input returned)."""
+    gctx.set_step_number(10)
+    goracle.m.step_nbr = 10
+    assert gctx.integrate_batch(0.0, 0.1, np.empty((0, 14))).shape == (0, 14)
+    X0 = goddard_costate_batch(5, 1e-3)
+    t0 = np.array([0.0, 0.1, 0.2, 0.0, 0.05])
+    tf = np.array([0.0, 0.1, 0.1, 0.1, 0.05])      # zero, zero, backward, normal, zero
+    Xg = gctx.integrate_batch(t0, tf, X0)
+    Xc = goracle.integrate_batch(t0, tf, X0)
+    for b in (0, 1, 2, 4):
+        assert np.array_equal(Xg[b], X0[b])
+    assert relerr(Xg, Xc) <= 1e-12
+
+
+def test_switching_times_per_row(gctx, goracle):
+    """mu2 = 0: bang / singular / off selected by t vs per-row switching times (goddard.cpp:146-162)."""
+    gctx.set_param("mu2", 0.0)
+    goracle.set_param("mu2", 0.0)
+    gctx.set_step_number(10)
+    goracle.m.step_nbr = 10
+    B = 70
+    rng = np.random.default_rng(5)
+    X0 = goddard_costate_batch(B, 1e-2)
+    sw = np.stack([rng.uniform(0.005, 0.04, B), rng.uniform(0.05, 0.1, B)], axis=1)
+    tf = rng.uniform(0.02, 0.12, B)
+    Xg = gctx.integrate_batch(0.0, tf, X0, sw=sw)
+    Xc = goracle.integrate_batch(0.0, tf, X0, aux_sw=sw)
+    assert relerr(Xg, Xc) <= 1e-10
+    gctx.set_param("mu2", 1.0)
+    goracle.set_param("mu2", 1.0)
+
+
+def _setup_problem(gctx, prob):
+    n = gctx.problem_set(prob.mode_t, prob.mode_x, prob.time, prob.xnode)
+    assert n == prob.n
+
+
+def test_residual_c1_stage1(gctx, goracle):
+    """testGoddard.cpp as shipped: M = 6, free tf, n = 85; KD = 0 first solve (testGoddard.cpp:94-99)."""
+    goracle.set_param("mu2", 1.0)
+    goracle.set_param("KD", 310.0)
+    goracle.m.step_nbr = 10
+    prob, z = goddard_c1_problem(goracle)
+    for KD in (0.0, 310.0):
+        goracle.set_param("KD", KD)
+        gctx.set_param("KD", KD)
+        gctx.set_param("mu2", 1.0)
+        gctx.set_step_number(10)
+        _setup_problem(gctx, prob)
+        Fc = goracle.residual(prob, z)
+        Fg = gctx.residual(z)
+        assert np.allclose(Fg, Fc, rtol=1e-12, atol=1e-12 * np.max(np.abs(Fc)))
+        if KD == 0.0:
+            # the reference's own value of this residual (probe of the reference build)
+            assert abs(Fg[84] - (-1240.5248135826923)) <= 1e-9
+    gctx.set_param("KD", 310.0)
+    goracle.set_param("KD", 310.0)
+
+
+def test_residual_batch_and_fd_jacobian_c2(gctx, goracle):
+    """BASELINE config 2: n = 14 single shooting; the FD batch is base + 14 perturbed rows."""
+    for c in (gctx, goracle):
+        c.set_param("mu2", 1.0)
+        c.set_param("KD", 310.0)
+    gctx.set_step_number(100)
+    goracle.m.step_nbr = 100
+    prob, z = goddard_single_problem()
+    _setup_problem(gctx, prob)
+    eps = np.sqrt(1e-15)
+    Z = np.tile(z, (15, 1))
+    for j in range(14):
+        h = eps * abs(z[j]) or eps
+        Z[j + 1, j] += h
+    Fg = gctx.residual_batch(Z)
+    Fc = goracle.residual_batch(prob, Z)
+    assert np.allclose(Fg, Fc, rtol=1e-11, atol=1e-11 * np.max(np.abs(Fc)))
+    # the fused FD kernel must reproduce (F_j - F_0)/h from the SAME implementation bit for bit
+    Jg = gctx.fd_jacobian(z, Fg[0], epsfcn=1e-15, dedup=False)
+    Jman = np.stack([(Fg[j + 1] - Fg[0]) / (eps * abs(z[j]) or eps) for j in range(14)], axis=1)
+    assert np.array_equal(Jg, Jman)
+    Jd = gctx.fd_jacobian(z, Fg[0], epsfcn=1e-15, dedup=True)
+    assert np.array_equal(Jg, Jd)
+
+
+def test_fd_jacobian_dedup_c1(gctx, goracle):
+    """n = 85: integrating only the segments a column can change gives the identical Jacobian."""
+    for c in (gctx, goracle):
+        c.set_param("mu2", 1.0)
+        c.set_param("KD", 310.0)
+    gctx.set_step_number(10)
+    goracle.m.step_nbr = 10
+    prob, z = goddard_c1_problem(goracle)
+    _setup_problem(gctx, prob)
+    F0 = gctx.residual(z)
+    t0, _ = gctx.counters()
+    Jfull = gctx.fd_jacobian(z, F0, dedup=False)
+    t1, _ = gctx.counters()
+    Jded = gctx.fd_jacobian(z, F0, dedup=True)
+    t2, _ = gctx.counters()
+    assert np.array_equal(Jfull, Jded)
+    assert (t1 - t0) == 85 * 6 and (t2 - t1) < (t1 - t0) / 2
+    # against MINPACK fdjac1 on the oracle: FD noise is amplified by 1/h, compare loosely
+    Jc = goracle.fdjac(prob, z, goracle.residual(prob, z))
+    scale = np.max(np.abs(Jc))
+    assert np.max(np.abs(Jfull - Jc)) <= 1e-5 * scale
