@@ -121,6 +121,20 @@ int socp_fd_jacobian(socp_ctx *ctx, const double *z, const double *fvec, double 
 int socp_fd_jacobian_dev(socp_ctx *ctx, const double *d_z, const double *d_fvec, double epsfcn,
                          double *d_fjac, int dedup);
 
+/* The same for `np` independent unknown vectors of ONE problem structure (multi-start /
+ * continuation sweeps): Z[np][n], Fvec[np][n] -> Fjac[np][n*n]; one launch. */
+int socp_fd_jacobian_multi_dev(socp_ctx *ctx, int np, const double *d_Z, const double *d_Fvec,
+                               double epsfcn, double *d_Fjac, int dedup);
+
+/* The (n+1) residual rows of a forward-difference Jacobian in ONE launch: Rows[np][n+1][n], row 0
+ * = F(z), row j+1 = F(z + h_j e_j); base and perturbed trajectories are independent, so nothing
+ * waits on the base evaluation.  This is "one Newton step's batch": (n+1)*M trajectories per
+ * problem (15 rows).  socp_fd_diff_dev turns rows into the Jacobian. */
+int socp_fd_rows_dev(socp_ctx *ctx, int np, const double *d_Z, double epsfcn, double *d_Rows);
+int socp_fd_rows(socp_ctx *ctx, int np, const double *Z, double epsfcn, double *Rows);
+int socp_fd_diff_dev(socp_ctx *ctx, int np, const double *d_Z, double epsfcn, const double *d_Rows,
+                     double *d_Fjac);
+
 /* replaces: shooting::ShootingFunctionJacobian (shooting.cpp:996-1130), variational Jacobian
  * for models with modelOrder == 1; fjac column-major as handed to hybrj (shooting.cpp:889-893). */
 int socp_var_jacobian(socp_ctx *ctx, const double *z, double *fjac);

@@ -67,6 +67,10 @@ def lib():
         L.socp_fd_jacobian.argtypes = [_vp, _dp, _dp, C.c_double, _dp, C.c_int]
         L.socp_fd_jacobian_dev.argtypes = [_vp, _vp, _vp, C.c_double, _vp, C.c_int]
         L.socp_var_jacobian.argtypes = [_vp, _dp, _dp]
+        L.socp_fd_jacobian_multi_dev.argtypes = [_vp, C.c_int, _vp, _vp, C.c_double, _vp, C.c_int]
+        L.socp_fd_rows_dev.argtypes = [_vp, C.c_int, _vp, C.c_double, _vp]
+        L.socp_fd_rows.argtypes = [_vp, C.c_int, _dp, C.c_double, _dp]
+        L.socp_fd_diff_dev.argtypes = [_vp, C.c_int, _vp, C.c_double, _vp, _vp]
         L.hybrd.argtypes = [FCN, _vp, C.c_int, _dp, _dp, C.c_double, C.c_int, C.c_int, C.c_int, C.c_double,
                             _dp, C.c_int, C.c_double, C.c_int, _ip, _dp, C.c_int, _dp, C.c_int, _dp,
                             _dp, _dp, _dp, _dp]
@@ -231,6 +235,23 @@ class Context:
         Jcm = np.empty((self.n, self.n))
         self._chk(self.L.socp_fd_jacobian(self.h, _d(z), _d(fvec), float(epsfcn), _d(Jcm), int(bool(dedup))))
         return Jcm.T.copy()
+
+    def fd_rows(self, Z, epsfcn=1e-15):
+        """Rows[np][n+1][n]: F(z) and the n forward-difference residuals, one launch."""
+        Z = _f64(Z).reshape(-1, self.n)
+        rows = np.empty((Z.shape[0], self.n + 1, self.n))
+        self._chk(self.L.socp_fd_rows(self.h, Z.shape[0], _d(Z), float(epsfcn), _d(rows)))
+        return rows
+
+    def fd_rows_dev(self, np_, d_Z, epsfcn, d_rows):
+        self._chk(self.L.socp_fd_rows_dev(self.h, int(np_), _vp(d_Z), float(epsfcn), _vp(d_rows)))
+
+    def fd_diff_dev(self, np_, d_Z, epsfcn, d_rows, d_fjac):
+        self._chk(self.L.socp_fd_diff_dev(self.h, int(np_), _vp(d_Z), float(epsfcn), _vp(d_rows), _vp(d_fjac)))
+
+    def fd_jacobian_multi_dev(self, np_, d_Z, d_Fvec, epsfcn, d_Fjac, dedup=False):
+        self._chk(self.L.socp_fd_jacobian_multi_dev(self.h, int(np_), _vp(d_Z), _vp(d_Fvec), float(epsfcn),
+                                                    _vp(d_Fjac), int(bool(dedup))))
 
     def fd_jacobian_dev(self, d_z, d_fvec, epsfcn, d_fjac, dedup=False):
         self._chk(self.L.socp_fd_jacobian_dev(self.h, _vp(d_z), _vp(d_fvec), float(epsfcn), _vp(d_fjac),

@@ -112,13 +112,22 @@ hipError_t run_residual(socp_ctx *c, int B, const double *Z, double *F)
                        : residual_exact(c->model_id, c->stream, c->P, c->pb, B, Z, F);
 }
 
-hipError_t run_fdjac(socp_ctx *c, int T, const int2 *pairs, const double *z, const double *fvec,
+hipError_t run_fdjac(socp_ctx *c, int np, int T, const int2 *pairs, const double *z, const double *fvec,
                      double eps, double *fjac)
 {
-    c->n_traj += T; c->n_launch += 1;
-    return use_fast(c) ? fdjac_fast(c->model_id, c->stream, c->P, c->pb, T, pairs, z, fvec, eps, fjac)
-                       : fdjac_exact(c->model_id, c->stream, c->P, c->pb, T, pairs, z, fvec, eps, fjac);
+    c->n_traj += (long long)np * T; c->n_launch += 1;
+    return use_fast(c) ? fdjac_fast(c->model_id, c->stream, c->P, c->pb, np, T, pairs, z, fvec, eps, fjac)
+                       : fdjac_exact(c->model_id, c->stream, c->P, c->pb, np, T, pairs, z, fvec, eps, fjac);
 }
+
+hipError_t run_fdrows(socp_ctx *c, int np, const double *z, double eps, double *rows)
+{
+    c->n_traj += (long long)np * (c->n + 1) * c->M; c->n_launch += 1;
+    return use_fast(c) ? fdrows_fast(c->model_id, c->stream, c->P, c->pb, np, z, eps, rows)
+                       : fdrows_exact(c->model_id, c->stream, c->P, c->pb, np, z, eps, rows);
+}
+
+double fd_eps(double epsfcn) { return std::sqrt(epsfcn > DBL_EPSILON ? epsfcn : DBL_EPSILON); }
 
 }  // namespace
 
@@ -489,21 +498,69 @@ int socp_residual_batch(socp_ctx *c, int B, const double *Z, double *F)
     return SOCP_OK;
 }
 
-int socp_fd_jacobian_dev(socp_ctx *c, const double *d_z, const double *d_fvec, double epsfcn, double *d_fjac, int dedup)
+int socp_fd_jacobian_multi_dev(socp_ctx *c, int np, const double *d_Z, const double *d_Fvec, double epsfcn,
+                               double *d_Fjac, int dedup)
 {
     if (!c) return SOCP_ERR_ARG;
     if (!c->has_problem) return fail(c, SOCP_ERR_ARG, "fd_jacobian: no problem set");
-    if (!d_z || !d_fvec || !d_fjac) return fail(c, SOCP_ERR_ARG, "fd_jacobian: null argument");
+    if (np < 0 || (np > 0 && (!d_Z || !d_Fvec || !d_Fjac))) return fail(c, SOCP_ERR_ARG, "fd_jacobian: null argument");
+    if (np == 0) return SOCP_OK;
     if (int rc = check_variant(c)) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
-    const double eps = std::sqrt(epsfcn > DBL_EPSILON ? epsfcn : DBL_EPSILON);
+    const double eps = fd_eps(epsfcn);
     if (dedup) {
         // rows a column cannot change reproduce fvec bit for bit => exact zeros
-        HIP_TRY(c, hipMemsetAsync(d_fjac, 0, sizeof(double) * (size_t)c->n * c->n, c->stream));
-        HIP_TRY(c, run_fdjac(c, c->T_dedup, c->d_pairs_dedup.as<int2>(), d_z, d_fvec, eps, d_fjac));
+        HIP_TRY(c, hipMemsetAsync(d_Fjac, 0, sizeof(double) * (size_t)np * c->n * c->n, c->stream));
+        HIP_TRY(c, run_fdjac(c, np, c->T_dedup, c->d_pairs_dedup.as<int2>(), d_Z, d_Fvec, eps, d_Fjac));
     } else {
-        HIP_TRY(c, run_fdjac(c, c->T_full, c->d_pairs_full.as<int2>(), d_z, d_fvec, eps, d_fjac));
+        HIP_TRY(c, run_fdjac(c, np, c->T_full, c->d_pairs_full.as<int2>(), d_Z, d_Fvec, eps, d_Fjac));
     }
+    return SOCP_OK;
+}
+
+int socp_fd_jacobian_dev(socp_ctx *c, const double *d_z, const double *d_fvec, double epsfcn, double *d_fjac, int dedup)
+{
+    return socp_fd_jacobian_multi_dev(c, 1, d_z, d_fvec, epsfcn, d_fjac, dedup);
+}
+
+int socp_fd_rows_dev(socp_ctx *c, int np, const double *d_Z, double epsfcn, double *d_Rows)
+{
+    if (!c) return SOCP_ERR_ARG;
+    if (!c->has_problem) return fail(c, SOCP_ERR_ARG, "fd_rows: no problem set");
+    if (np < 0 || (np > 0 && (!d_Z || !d_Rows))) return fail(c, SOCP_ERR_ARG, "fd_rows: null argument");
+    if (np == 0) return SOCP_OK;
+    if (int rc = check_variant(c)) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, run_fdrows(c, np, d_Z, fd_eps(epsfcn), d_Rows));
+    return SOCP_OK;
+}
+
+int socp_fd_diff_dev(socp_ctx *c, int np, const double *d_Z, double epsfcn, const double *d_Rows, double *d_Fjac)
+{
+    if (!c) return SOCP_ERR_ARG;
+    if (!c->has_problem) return fail(c, SOCP_ERR_ARG, "fd_diff: no problem set");
+    if (np < 0 || (np > 0 && (!d_Z || !d_Rows || !d_Fjac))) return fail(c, SOCP_ERR_ARG, "fd_diff: null argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->n_launch += 1;
+    HIP_TRY(c, fd_diff(c->stream, c->n, np, d_Z, fd_eps(epsfcn), d_Rows, d_Fjac));
+    return SOCP_OK;
+}
+
+int socp_fd_rows(socp_ctx *c, int np, const double *Z, double epsfcn, double *Rows)
+{
+    if (!c) return SOCP_ERR_ARG;
+    if (!c->has_problem) return fail(c, SOCP_ERR_ARG, "fd_rows: no problem set");
+    if (np < 0 || (np > 0 && (!Z || !Rows))) return fail(c, SOCP_ERR_ARG, "fd_rows: null argument");
+    if (np == 0) return SOCP_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t n = c->n;
+    HIP_TRY(c, c->s_in.reserve(sizeof(double) * n * np));
+    HIP_TRY(c, c->s_out.reserve(sizeof(double) * n * (n + 1) * np));
+    HIP_TRY(c, hipMemcpyAsync(c->s_in.p, Z, sizeof(double) * n * np, hipMemcpyHostToDevice, c->stream));
+    int rc = socp_fd_rows_dev(c, np, c->s_in.as<double>(), epsfcn, c->s_out.as<double>());
+    if (rc != SOCP_OK) return rc;
+    HIP_TRY(c, hipMemcpyAsync(Rows, c->s_out.p, sizeof(double) * n * (n + 1) * np, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return SOCP_OK;
 }
 

@@ -126,20 +126,24 @@ __device__ __forceinline__ void segment_residual(const ModelParams &P, const Pro
     const double sw0 = pb.sw_node0 >= 0 ? nt(pb.sw_node0) : P.sw0;
     const double sw1 = pb.sw_node1 >= 0 ? nt(pb.sw_node1) : P.sw1;
 
-    double X1[S], X[S];
-#pragma unroll
-    for (int k = 0; k < S; k++) { X1[k] = z(S * i + k); X[k] = X1[k]; }
-    Lane<Mdl>::integrate(P, sw0, sw1, t1, t2, X);          // shooting.cpp:943 Move(t1, X1, t2)
-
+    double X[S];
     if (i == 0) {
-        // model.hpp:196-228 InitialFunction / :239-290 InitialHFunction, isJac == 0
+        // model.hpp:196-228 InitialFunction / :239-290 InitialHFunction, isJac == 0.
+        // Done BEFORE the integration so the node state is not live across it (register budget).
+#pragma unroll
+        for (int k = 0; k < S; k++) X[k] = z(k);
 #pragma unroll
         for (int j = 0; j < D; j++) {
             const bool fr = pb.mode_x[j] == 1;
-            emit(j, fr ? X1[j + D] : X1[j] - pb.xnode[j]);
+            emit(j, fr ? X[j + D] : X[j] - pb.xnode[j]);
         }
-        if (pb.ft_row[0] >= 0) emit(pb.ft_row[0], Mdl::hamiltonian(P, sw0, sw1, t1, X1));
+        if (pb.ft_row[0] >= 0) emit(pb.ft_row[0], Mdl::hamiltonian(P, sw0, sw1, t1, X));
+    } else {
+#pragma unroll
+        for (int k = 0; k < S; k++) X[k] = z(S * i + k);
     }
+    Lane<Mdl>::integrate(P, sw0, sw1, t1, t2, X);          // shooting.cpp:943 Move(t1, X1, t2)
+
     if (i < M - 1) {
         double Xp[S];
 #pragma unroll
@@ -176,9 +180,9 @@ __device__ __forceinline__ void segment_residual(const ModelParams &P, const Pro
 
 // K_res: Z[B][n] -> F[B][n]; trajectory index T = row*M + segment.
 template <class Mdl>
-__global__ __launch_bounds__(64) void residual_lane_kernel(ModelParams P, ProblemDev pb, int B,
-                                                           const double *__restrict__ Z,
-                                                           double *__restrict__ F)
+__global__ __launch_bounds__(64, 2) void residual_lane_kernel(ModelParams P, ProblemDev pb, int B,
+                                                              const double *__restrict__ Z,
+                                                              double *__restrict__ F)
 {
     const long T = (long)blockIdx.x * 64 + threadIdx.x;
     if (T >= (long)B * pb.M) return;
@@ -190,28 +194,77 @@ __global__ __launch_bounds__(64) void residual_lane_kernel(ModelParams P, Proble
     segment_residual<Mdl>(P, pb, z, i, [=](int row, double v) { fr[row] = v; });
 }
 
-// K_fdj: MINPACK fdjac1 columns as one batch.  `pairs[T]` = (column j,
-// segment i) to integrate; the unknown vector of column j is z with z_j + h_j generated on the
-// fly, so the perturbation matrix never exists in HBM: reads are z[n], fvec[n] (cache
+// MINPACK fdjac1 step: h = eps*|z_j|, or eps when that is zero
+__device__ __forceinline__ double fd_step(double zj, double eps)
+{
+    const double h = eps * fabs(zj);
+    return h == 0 ? eps : h;
+}
+
+// K_fdj: fdjac1 columns of `np` problems as one batch.  pairs[t] = (column j, segment i) to
+// integrate; the unknown vector of column j is z with z_j + h_j generated on the fly, so the
+// perturbation matrix never exists in HBM: reads are z[n] and fvec[n] per problem (cache
 // resident), writes are the Jacobian entries fjac[row + n*j] = (F_j[row] - fvec[row]) / h_j.
 template <class Mdl>
-__global__ __launch_bounds__(64) void fdjac_lane_kernel(ModelParams P, ProblemDev pb, int T,
-                                                        const int2 *__restrict__ pairs,
-                                                        const double *__restrict__ zb,
-                                                        const double *__restrict__ fvec,
-                                                        double eps, double *__restrict__ fjac)
+__global__ __launch_bounds__(64, 2) void fdjac_lane_kernel(ModelParams P, ProblemDev pb, int np, int T,
+                                                           const int2 *__restrict__ pairs,
+                                                           const double *__restrict__ Zb,
+                                                           const double *__restrict__ Fvec,
+                                                           double eps, double *__restrict__ Fjac)
 {
-    const int tid = blockIdx.x * 64 + threadIdx.x;
-    if (tid >= T) return;
-    const int j = pairs[tid].x, i = pairs[tid].y;
-    const double temp = zb[j];
-    double h = eps * fabs(temp);
-    if (h == 0) h = eps;
-    const double zj = temp + h;
-    auto z = [=](int k) -> double { return k == j ? zj : zb[k]; };
-    double *col = fjac + (long)pb.n * j;
+    const long tid = (long)blockIdx.x * 64 + threadIdx.x;
+    if (tid >= (long)np * T) return;
+    const long prob = tid / T;
+    const int2 pr = pairs[tid - prob * T];
+    const int j = pr.x, i = pr.y;
+    const double *zb = Zb + prob * pb.n;
+    const double *fvec = Fvec + prob * pb.n;
+    const double h = fd_step(zb[j], eps);
+    const double zj = zb[j] + h;
+    auto z = [=](int k) -> double { const double v = zb[k]; return k == j ? zj : v; };
+    double *col = Fjac + prob * (long)pb.n * pb.n + (long)pb.n * j;
     segment_residual<Mdl>(P, pb, z, i, [=](int row, double v) { col[row] = (v - fvec[row]) / h; });
 }
+
+// K_fdr: the (n+1) residual rows of a forward-difference Jacobian -- row 0 at z, row j+1 at
+// z + h_j e_j -- for `np` problems in ONE launch (no dependency between base and perturbed
+// trajectories).  Rows[np][n+1][n]; the perturbation matrix is generated on the fly.
+template <class Mdl>
+__global__ __launch_bounds__(64, 2) void fdrows_lane_kernel(ModelParams P, ProblemDev pb, int np,
+                                                            const double *__restrict__ Zb, double eps,
+                                                            double *__restrict__ Rows)
+{
+    const long tid = (long)blockIdx.x * 64 + threadIdx.x;
+    const int per = (pb.n + 1) * pb.M;
+    if (tid >= (long)np * per) return;
+    const long prob = tid / per;
+    const int rem = (int)(tid - prob * per);
+    const int row = rem / pb.M;                 // 0 = base, j+1 = column j
+    const int i = rem - row * pb.M;
+    const int j = row - 1;
+    const double *zb = Zb + prob * pb.n;
+    const double zj = j >= 0 ? zb[j] + fd_step(zb[j], eps) : 0.0;
+    auto z = [=](int k) -> double { const double v = zb[k]; return k == j ? zj : v; };
+    double *out = Rows + (prob * (pb.n + 1) + row) * (long)pb.n;
+    segment_residual<Mdl>(P, pb, z, i, [=](int r, double v) { out[r] = v; });
+}
+
+#ifdef SOCP_DEFINE_COMMON
+// K_fdd: Jacobian from the rows of K_fdr: fjac[p][r + n*j] = (Rows[p][j+1][r] - Rows[p][0][r]) / h_j
+__global__ void fd_diff_kernel(int n, int np, const double *__restrict__ Zb, double eps,
+                               const double *__restrict__ Rows, double *__restrict__ Fjac)
+{
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long per = (long)n * n;
+    if (tid >= np * per) return;
+    const long prob = tid / per;
+    const int e = (int)(tid - prob * per);
+    const int j = e / n, r = e - j * n;
+    const double h = fd_step(Zb[prob * n + j], eps);
+    const double *rows = Rows + prob * (long)(n + 1) * n;
+    Fjac[tid] = (rows[(long)(j + 1) * n + r] - rows[r]) / h;
+}
+#endif
 
 // K_eval: model::Model / Control / Hamiltonian for a batch of (t, X) points (set-up and trace
 // paths of the host mirror; not on the hot path).

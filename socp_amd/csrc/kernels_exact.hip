@@ -3,6 +3,7 @@
 // CPU oracle at the few-ulp level.
 #include "models_exact.hpp"
 #define SOCP_FLAVOUR exact
+#define SOCP_DEFINE_COMMON 1   // fd_diff lives in the no-contraction TU
 #define SOCP_GODDARD GoddardExact
 #define SOCP_DINT DIntExact
 #include "launch_impl.hpp"

@@ -11,12 +11,18 @@ namespace socp {
     hipError_t residual_##FLAVOUR(int model_id, hipStream_t st, const ModelParams &P,                \
                                   const ProblemDev &pb, int B, const double *Z, double *F);          \
     hipError_t fdjac_##FLAVOUR(int model_id, hipStream_t st, const ModelParams &P,                   \
-                               const ProblemDev &pb, int T, const int2 *pairs, const double *z,      \
-                               const double *fvec, double eps, double *fjac);                        \
+                               const ProblemDev &pb, int np, int T, const int2 *pairs,               \
+                               const double *z, const double *fvec, double eps, double *fjac);       \
+    hipError_t fdrows_##FLAVOUR(int model_id, hipStream_t st, const ModelParams &P,                  \
+                                const ProblemDev &pb, int np, const double *z, double eps,           \
+                                double *rows);                                                       \
     hipError_t eval_##FLAVOUR(int model_id, hipStream_t st, const ModelParams &P, int what, int B,   \
                               const double *t, const double *sw, const double *X, double *out);
 
 SOCP_DECLARE_LAUNCHERS(exact)
+// flavour-independent: Jacobian from the rows of fdrows (differences and one division per entry)
+hipError_t fd_diff(hipStream_t st, int n, int np, const double *z, double eps, const double *rows, double *fjac);
+
 SOCP_DECLARE_LAUNCHERS(fast)
 
 }  // namespace socp

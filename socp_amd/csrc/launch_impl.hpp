@@ -35,16 +35,39 @@ hipError_t SOCP_CAT(residual_, SOCP_FLAVOUR)(int model_id, hipStream_t st, const
 }
 
 hipError_t SOCP_CAT(fdjac_, SOCP_FLAVOUR)(int model_id, hipStream_t st, const ModelParams &P,
-                                          const ProblemDev &pb, int T, const int2 *pairs, const double *z,
+                                          const ProblemDev &pb, int np, int T, const int2 *pairs, const double *z,
                                           const double *fvec, double eps, double *fjac)
 {
-    if (T <= 0) return hipSuccess;
+    if (T <= 0 || np <= 0) return hipSuccess;
+    const long total = (long)np * T;
     if (model_id == 1)
-        hipLaunchKernelGGL(fdjac_lane_kernel<SOCP_GODDARD>, dim3(blocks_for(T)), dim3(64), 0, st, P, pb, T, pairs, z, fvec, eps, fjac);
+        hipLaunchKernelGGL(fdjac_lane_kernel<SOCP_GODDARD>, dim3(blocks_for(total)), dim3(64), 0, st, P, pb, np, T, pairs, z, fvec, eps, fjac);
     else
-        hipLaunchKernelGGL(fdjac_lane_kernel<SOCP_DINT>, dim3(blocks_for(T)), dim3(64), 0, st, P, pb, T, pairs, z, fvec, eps, fjac);
+        hipLaunchKernelGGL(fdjac_lane_kernel<SOCP_DINT>, dim3(blocks_for(total)), dim3(64), 0, st, P, pb, np, T, pairs, z, fvec, eps, fjac);
     return hipGetLastError();
 }
+
+hipError_t SOCP_CAT(fdrows_, SOCP_FLAVOUR)(int model_id, hipStream_t st, const ModelParams &P,
+                                           const ProblemDev &pb, int np, const double *z, double eps, double *rows)
+{
+    if (np <= 0) return hipSuccess;
+    const long total = (long)np * (pb.n + 1) * pb.M;
+    if (model_id == 1)
+        hipLaunchKernelGGL(fdrows_lane_kernel<SOCP_GODDARD>, dim3(blocks_for(total)), dim3(64), 0, st, P, pb, np, z, eps, rows);
+    else
+        hipLaunchKernelGGL(fdrows_lane_kernel<SOCP_DINT>, dim3(blocks_for(total)), dim3(64), 0, st, P, pb, np, z, eps, rows);
+    return hipGetLastError();
+}
+
+#ifdef SOCP_DEFINE_COMMON
+hipError_t fd_diff(hipStream_t st, int n, int np, const double *z, double eps, const double *rows, double *fjac)
+{
+    if (np <= 0) return hipSuccess;
+    const long total = (long)np * n * n;
+    hipLaunchKernelGGL(fd_diff_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, n, np, z, eps, rows, fjac);
+    return hipGetLastError();
+}
+#endif
 
 hipError_t SOCP_CAT(eval_, SOCP_FLAVOUR)(int model_id, hipStream_t st, const ModelParams &P, int what, int B,
                                          const double *t, const double *sw, const double *X, double *out)

@@ -187,3 +187,36 @@ def test_fd_jacobian_dedup_c1(gctx, goracle):
     Jc = goracle.fdjac(prob, z, goracle.residual(prob, z))
     scale = np.max(np.abs(Jc))
     assert np.max(np.abs(Jfull - Jc)) <= 1e-5 * scale
+
+
+def test_fd_rows_many_problems(gctx, goracle):
+    """One launch for the (n+1) residual rows of many starts; rows must equal the residual of the
+    explicitly perturbed vectors, and the difference kernel the fused-FD Jacobian, bit for bit."""
+    import torch
+    for c in (gctx, goracle):
+        c.set_param("mu2", 1.0)
+        c.set_param("KD", 310.0)
+    gctx.set_step_number(50)
+    goracle.m.step_nbr = 50
+    prob, z = goddard_single_problem()
+    _setup_problem(gctx, prob)
+    P = 9
+    Z = np.tile(z, (P, 1))
+    Z[:, 7:] = goddard_costate_batch(P, 1e-3)[:, 7:]
+    rows = gctx.fd_rows(Z, epsfcn=1e-15)
+    eps = np.sqrt(1e-15)
+    for p in range(P):
+        Zp = np.tile(Z[p], (15, 1))
+        for j in range(14):
+            Zp[j + 1, j] += eps * abs(Z[p, j]) or eps
+        assert np.array_equal(rows[p], gctx.residual_batch(Zp))
+        J = gctx.fd_jacobian(Z[p], rows[p, 0], epsfcn=1e-15)
+        dZ = torch.from_numpy(Z[p:p + 1].copy()).cuda()
+        dR = torch.from_numpy(rows[p:p + 1].copy()).cuda()
+        dJ = torch.empty((1, 14, 14), dtype=torch.float64, device="cuda")
+        gctx.fd_diff_dev(1, dZ.data_ptr(), 1e-15, dR.data_ptr(), dJ.data_ptr())
+        gctx.synchronize()
+        torch.cuda.synchronize()
+        assert np.array_equal(dJ.cpu().numpy()[0].T, J)      # device J is column-major
+    Fc = goracle.residual(prob, Z[3])
+    assert np.allclose(rows[3, 0], Fc, rtol=1e-11, atol=1e-11 * np.max(np.abs(Fc)))
