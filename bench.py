@@ -91,7 +91,7 @@ def cpu_baseline(steps_rk4, Z, target_seconds):
         ref = orc.Ref(orc.MODEL_GODDARD, step_nbr=steps_rk4)
         probe = sample_rows(threads)
         _, sec = ref.goddard_traj_batch(threads, steps_rk4, GODDARD_PARAMS, 0.0, TF, probe)
-        count = int(max(threads, min(4096, threads * round(target_seconds / max(sec, 1e-3)))))
+        count = int(max(threads, min(65536, threads * round(target_seconds / max(sec, 1e-3)))))
         X0 = sample_rows(count)
         _, sec = ref.goddard_traj_batch(threads, steps_rk4, GODDARD_PARAMS, 0.0, TF, X0)
         return {"value": count / sec, "unit": "trajectories/s", "cores": threads, "kind": "reference",
@@ -139,8 +139,9 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     ctx = setup_context(local_rank, args.rk4_steps, args.variant)
-    stream = torch.cuda.current_stream(dev)
-    ctx.set_stream(stream.cuda_stream)       # kernels run on torch's current stream: torch events see them
+    stream = torch.cuda.Stream(device=dev)   # a real (non-default) HIP stream owned by torch
+    torch.cuda.set_stream(stream)
+    ctx.set_stream(stream.cuda_stream)       # kernels are enqueued on it: torch events on it bracket them
 
     P = args.starts
     Z_host = make_starts(P, seed=20250905 + rank)

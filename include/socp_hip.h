@@ -69,7 +69,9 @@ int socp_ctx_get_params(const socp_ctx *ctx, double *params, int nparams);
 int socp_ctx_set_step_number(socp_ctx *ctx, int step_nbr);      /* model::stepNbr, model.hpp:367 */
 int socp_ctx_set_switching_times(socp_ctx *ctx, const double *sw, int nsw);  /* goddard.cpp:373-377 */
 int socp_ctx_set_variant(socp_ctx *ctx, int variant);
-int socp_ctx_set_stream(socp_ctx *ctx, void *hip_stream);       /* hipStream_t; NULL = context's own */
+/* enqueue on the caller's hipStream_t (NULL is the device's default stream); use_own != 0 switches
+ * back to the context's private non-blocking stream */
+int socp_ctx_set_stream(socp_ctx *ctx, void *hip_stream, int use_own);
 int socp_ctx_synchronize(socp_ctx *ctx);
 int socp_ctx_dims(const socp_ctx *ctx, int *dim, int *state_len, int *state_len_jac);
 

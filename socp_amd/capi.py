@@ -42,6 +42,14 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise ImportError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
+        # One HIP runtime per process: the PyTorch wheel bundles its own libamdhip64 (same soname as
+        # /opt/rocm's).  Importing torch FIRST makes the loader bind this library to that copy, so
+        # torch tensors/streams and our kernels share one runtime; the other order gives two runtimes
+        # and torch then reports "No HIP GPUs are available".  Without torch, /opt/rocm's is used.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.socp_last_error.restype = C.c_char_p
         L.socp_last_error.argtypes = [_vp]
@@ -53,7 +61,7 @@ def lib():
         L.socp_ctx_set_step_number.argtypes = [_vp, C.c_int]
         L.socp_ctx_set_switching_times.argtypes = [_vp, _dp, C.c_int]
         L.socp_ctx_set_variant.argtypes = [_vp, C.c_int]
-        L.socp_ctx_set_stream.argtypes = [_vp, _vp]
+        L.socp_ctx_set_stream.argtypes = [_vp, _vp, C.c_int]
         L.socp_ctx_dims.argtypes = [_vp, _ip, _ip, _ip]
         L.socp_ctx_counters.argtypes = [_vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
         L.socp_integrate_batch.argtypes = [_vp, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_int]
@@ -154,8 +162,9 @@ class Context:
     def set_variant(self, v):
         self._chk(self.L.socp_ctx_set_variant(self.h, int(v)))
 
-    def set_stream(self, stream_ptr):
-        self._chk(self.L.socp_ctx_set_stream(self.h, _vp(stream_ptr)))
+    def set_stream(self, stream_ptr, use_own=False):
+        """stream_ptr: hipStream_t as int (0 = the default stream); use_own=True: context's own stream."""
+        self._chk(self.L.socp_ctx_set_stream(self.h, _vp(stream_ptr), int(bool(use_own))))
 
     def synchronize(self):
         self._chk(self.L.socp_ctx_synchronize(self.h))

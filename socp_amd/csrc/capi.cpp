@@ -227,10 +227,11 @@ int socp_ctx_set_variant(socp_ctx *c, int variant)
     return SOCP_OK;
 }
 
-int socp_ctx_set_stream(socp_ctx *c, void *hip_stream)
+int socp_ctx_set_stream(socp_ctx *c, void *hip_stream, int use_own)
 {
     if (!c) return SOCP_ERR_ARG;
-    c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    // a null hipStream_t is a real stream (the device's default stream), so "own" is explicit
+    c->stream = use_own ? c->own_stream : static_cast<hipStream_t>(hip_stream);
     return SOCP_OK;
 }
 
