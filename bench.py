@@ -17,7 +17,7 @@ Extra objects in the JSON line:
                 MI355X_MICROARCH.md); the HBM view the contract asks for is in roofline.hbm.
   cpu_baseline  the reference's own model::ComputeTraj (oracle/_ref, kind "reference") or the C
                 oracle (kind "port") timed on this box's host cores on a bounded sample.
-  single_problem  the latency-bound case: ONE problem (15 trajectories) per launch.
+  single_problem  (--single-problem) the latency-bound case: ONE problem (15 trajectories) per launch.
 """
 import argparse
 import json
@@ -121,6 +121,8 @@ def main():
     ap.add_argument("--rk4-steps", type=int, default=10000)
     ap.add_argument("--variant", choices=["exact", "fast"], default="exact")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="0 disables the CPU baseline leg")
+    ap.add_argument("--single-problem", action="store_true",
+                    help="also time ONE problem (15 trajectories) per launch: the latency-bound case")
     args = ap.parse_args()
 
     import torch
@@ -225,7 +227,7 @@ def main():
                                  "frac": gbs / PEAK_HBM_GBS, "bytes_per_trajectory": BYTES_PER_TRAJ}},
             "finite_jacobians": [int(r[1]) for r in recs],
         }
-        if world == 1:
+        if world == 1 and args.single_problem:
             # latency-bound case: one problem (15 trajectories) per launch
             one = torch.from_numpy(Z_host[:1].copy()).to(dev)
             ctx.fd_rows_dev(1, one.data_ptr(), epsfcn, d_rows.data_ptr())
@@ -237,8 +239,8 @@ def main():
             torch.cuda.synchronize(dev)
             ms = 1e3 * (time.perf_counter() - t1) / reps
             out["single_problem"] = {"trajectories": ROWS, "ms": ms, "value": ROWS / (ms * 1e-3), "unit": "trajectories/s"}
-            if args.cpu_seconds > 0:
-                out["cpu_baseline"] = cpu_baseline(args.rk4_steps, Z_host, args.cpu_seconds)
+        if world == 1 and args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(args.rk4_steps, Z_host, args.cpu_seconds)
         print(json.dumps(out), flush=True)
 
     ctx.close()

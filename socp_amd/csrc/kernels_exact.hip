@@ -5,5 +5,6 @@
 #define SOCP_FLAVOUR exact
 #define SOCP_DEFINE_COMMON 1   // fd_diff lives in the no-contraction TU
 #define SOCP_GODDARD GoddardExact
+#define SOCP_GODDARD_SMOOTH GoddardExactSmooth
 #define SOCP_DINT DIntExact
 #include "launch_impl.hpp"

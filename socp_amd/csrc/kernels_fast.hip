@@ -4,5 +4,6 @@
 #include "models_fast.hpp"
 #define SOCP_FLAVOUR fast
 #define SOCP_GODDARD GoddardFast
+#define SOCP_GODDARD_SMOOTH GoddardFastSmooth
 #define SOCP_DINT DIntFast
 #include "launch_impl.hpp"

@@ -10,15 +10,23 @@ namespace socp {
 
 static inline unsigned blocks_for(long n) { return (unsigned)((n + 63) / 64); }
 
+// model_id 1 = Goddard (smooth-law specialisation when mu2 > 0, parameter slot 6), 2 = double integrator
+#define SOCP_DISPATCH(KERNEL, GRID, ST, ...)                                                        \
+    do {                                                                                            \
+        if (model_id == 1 && P.p[6] > 0)                                                            \
+            hipLaunchKernelGGL(KERNEL<SOCP_GODDARD_SMOOTH>, dim3(GRID), dim3(64), 0, ST, __VA_ARGS__); \
+        else if (model_id == 1)                                                                     \
+            hipLaunchKernelGGL(KERNEL<SOCP_GODDARD>, dim3(GRID), dim3(64), 0, ST, __VA_ARGS__);        \
+        else                                                                                        \
+            hipLaunchKernelGGL(KERNEL<SOCP_DINT>, dim3(GRID), dim3(64), 0, ST, __VA_ARGS__);           \
+    } while (0)
+
 hipError_t SOCP_CAT(traj_, SOCP_FLAVOUR)(int model_id, hipStream_t st, const ModelParams &P, int B,
                                          const double *t0, const double *tf, const double *sw,
                                          const double *X0, double *Xf)
 {
     if (B <= 0) return hipSuccess;
-    if (model_id == 1)
-        hipLaunchKernelGGL(traj_lane_kernel<SOCP_GODDARD>, dim3(blocks_for(B)), dim3(64), 0, st, P, B, t0, tf, sw, X0, Xf);
-    else
-        hipLaunchKernelGGL(traj_lane_kernel<SOCP_DINT>, dim3(blocks_for(B)), dim3(64), 0, st, P, B, t0, tf, sw, X0, Xf);
+    SOCP_DISPATCH(traj_lane_kernel, blocks_for(B), st, P, B, t0, tf, sw, X0, Xf);
     return hipGetLastError();
 }
 
@@ -27,10 +35,7 @@ hipError_t SOCP_CAT(residual_, SOCP_FLAVOUR)(int model_id, hipStream_t st, const
 {
     if (B <= 0) return hipSuccess;
     const long T = (long)B * pb.M;
-    if (model_id == 1)
-        hipLaunchKernelGGL(residual_lane_kernel<SOCP_GODDARD>, dim3(blocks_for(T)), dim3(64), 0, st, P, pb, B, Z, F);
-    else
-        hipLaunchKernelGGL(residual_lane_kernel<SOCP_DINT>, dim3(blocks_for(T)), dim3(64), 0, st, P, pb, B, Z, F);
+    SOCP_DISPATCH(residual_lane_kernel, blocks_for(T), st, P, pb, B, Z, F);
     return hipGetLastError();
 }
 
@@ -40,10 +45,7 @@ hipError_t SOCP_CAT(fdjac_, SOCP_FLAVOUR)(int model_id, hipStream_t st, const Mo
 {
     if (T <= 0 || np <= 0) return hipSuccess;
     const long total = (long)np * T;
-    if (model_id == 1)
-        hipLaunchKernelGGL(fdjac_lane_kernel<SOCP_GODDARD>, dim3(blocks_for(total)), dim3(64), 0, st, P, pb, np, T, pairs, z, fvec, eps, fjac);
-    else
-        hipLaunchKernelGGL(fdjac_lane_kernel<SOCP_DINT>, dim3(blocks_for(total)), dim3(64), 0, st, P, pb, np, T, pairs, z, fvec, eps, fjac);
+    SOCP_DISPATCH(fdjac_lane_kernel, blocks_for(total), st, P, pb, np, T, pairs, z, fvec, eps, fjac);
     return hipGetLastError();
 }
 
@@ -52,10 +54,7 @@ hipError_t SOCP_CAT(fdrows_, SOCP_FLAVOUR)(int model_id, hipStream_t st, const M
 {
     if (np <= 0) return hipSuccess;
     const long total = (long)np * (pb.n + 1) * pb.M;
-    if (model_id == 1)
-        hipLaunchKernelGGL(fdrows_lane_kernel<SOCP_GODDARD>, dim3(blocks_for(total)), dim3(64), 0, st, P, pb, np, z, eps, rows);
-    else
-        hipLaunchKernelGGL(fdrows_lane_kernel<SOCP_DINT>, dim3(blocks_for(total)), dim3(64), 0, st, P, pb, np, z, eps, rows);
+    SOCP_DISPATCH(fdrows_lane_kernel, blocks_for(total), st, P, pb, np, z, eps, rows);
     return hipGetLastError();
 }
 
@@ -73,10 +72,7 @@ hipError_t SOCP_CAT(eval_, SOCP_FLAVOUR)(int model_id, hipStream_t st, const Mod
                                          const double *t, const double *sw, const double *X, double *out)
 {
     if (B <= 0) return hipSuccess;
-    if (model_id == 1)
-        hipLaunchKernelGGL(eval_lane_kernel<SOCP_GODDARD>, dim3(blocks_for(B)), dim3(64), 0, st, P, what, B, t, sw, X, out);
-    else
-        hipLaunchKernelGGL(eval_lane_kernel<SOCP_DINT>, dim3(blocks_for(B)), dim3(64), 0, st, P, what, B, t, sw, X, out);
+    SOCP_DISPATCH(eval_lane_kernel, blocks_for(B), st, P, what, B, t, sw, X, out);
     return hipGetLastError();
 }
 

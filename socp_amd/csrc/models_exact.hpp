@@ -15,9 +15,14 @@ namespace socp {
 enum { GP_C = 0, GP_B, GP_KD, GP_KR, GP_UMAX, GP_MU1, GP_MU2, GP_SING };
 enum { DP_UMAX = 0, DP_AMAX, DP_MUT };
 
-struct GoddardExact {
+// SMOOTH = true: specialised for the quadratic-cost law mu2 > 0 (goddard.cpp:137-145); the host
+// selects it from the parameter block, so the kernel carries no bang/singular/off code.  Both
+// instantiations evaluate identical expressions on the path they share.
+template <bool SMOOTH>
+struct GoddardExactT {
     static constexpr int D = 7;
     static constexpr int S = 14;
+    static constexpr bool kRefOrder = true;
 
     // quantities both Model() and Control() derive from the state (goddard.cpp:66-76,121-130)
     struct Common {
@@ -93,9 +98,9 @@ struct GoddardExact {
         const double mass = X[6], p_vx = X[10], p_vy = X[11], p_vz = X[12], p_mass = X[13];
         const double Switch = P.p[GP_MU1] - P.p[GP_B]*p_mass - P.p[GP_C] / mass*c.norm_pv;
         double alpha_u = 0;
-        if (P.p[GP_MU2] > 0) {
+        if (SMOOTH || P.p[GP_MU2] > 0) {
             if (Switch < 0) alpha_u = -Switch / 2 / P.p[GP_MU2];
-        } else {
+        } else if constexpr (!SMOOTH) {
             if (t <= sw0) {
                 alpha_u = 1.0;
             } else if (t > sw0 && t <= sw1) {
@@ -181,9 +186,13 @@ struct GoddardExact {
     }
 };
 
+using GoddardExact = GoddardExactT<false>;        // general law (any mu2)
+using GoddardExactSmooth = GoddardExactT<true>;   // mu2 > 0 only
+
 struct DIntExact {
     static constexpr int D = 6;
     static constexpr int S = 12;
+    static constexpr bool kRefOrder = true;
 
     // doubleIntegrator.cpp:218-259
     __device__ static __forceinline__ void control_only(const ModelParams &P, double, double, double,

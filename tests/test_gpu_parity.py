@@ -220,3 +220,79 @@ def test_fd_rows_many_problems(gctx, goracle):
         assert np.array_equal(dJ.cpu().numpy()[0].T, J)      # device J is column-major
     Fc = goracle.residual(prob, Z[3])
     assert np.allclose(rows[3, 0], Fc, rtol=1e-11, atol=1e-11 * np.max(np.abs(Fc)))
+
+
+# ---- throughput flavour (restructured arithmetic, FMA contraction): tolerance, not bit equality ----
+
+@pytest.fixture()
+def gfast(gctx):
+    from socp_amd import capi
+    gctx.set_variant(capi.VARIANT_LANE_FAST)
+    yield gctx
+    gctx.set_variant(capi.VARIANT_AUTO)
+
+
+@pytest.mark.parametrize("mu2", [1.0, 0.2, 0.0])
+def test_fast_rhs_matches_oracle(gfast, goracle, mu2):
+    from socp_amd import capi
+    rng = np.random.default_rng(11)
+    B = 256
+    X = goddard_costate_batch(B, 0.3) * (1 + 0.05 * rng.uniform(-1, 1, (B, 14)))
+    X[:, 3:6] = rng.uniform(-0.1, 0.1, (B, 3))
+    t = rng.uniform(0, 0.12, B)
+    gfast.set_param("mu2", mu2)
+    goracle.set_param("mu2", mu2)
+    rhs = gfast.eval_batch(capi.EVAL_RHS, t, X)
+    ref = np.stack([goracle.rhs(t[b], X[b]) for b in range(B)])
+    # relative to the size of each derivative vector: the factored gravity-gradient terms cancel
+    # differently from the reference's term-by-term sum
+    scale = np.max(np.abs(ref), axis=1, keepdims=True)
+    assert np.max(np.abs(rhs - ref) / scale) <= 5e-13
+    gfast.set_param("mu2", 1.0)
+    goracle.set_param("mu2", 1.0)
+
+
+@pytest.mark.parametrize("N,tol", [(10, 1e-12), (1000, 1e-10), (10000, 1e-8)])
+def test_fast_trajectory_tolerance(gfast, goracle, N, tol):
+    """SURVEY 8d parity tolerance (2): <= 1e-10 for short segments, <= 1e-8 at 1e4 RK4 steps."""
+    for c in (gfast, goracle):
+        c.set_param("mu2", 1.0)
+        c.set_param("KD", 310.0)
+    gfast.set_step_number(N)
+    goracle.m.step_nbr = N
+    B = 96
+    X0 = goddard_costate_batch(B, 1e-3)
+    Xg = gfast.integrate_batch(0.0, GODDARD_TF, X0)
+    Xc = goracle.integrate_batch(0.0, GODDARD_TF, X0)
+    assert np.all(np.isfinite(Xg))
+    assert relerr(Xg, Xc) <= tol
+
+
+def test_fast_bang_singular_off(gfast, goracle):
+    for c in (gfast, goracle):
+        c.set_param("mu2", 0.0)
+    gfast.set_step_number(20)
+    goracle.m.step_nbr = 20
+    B = 70
+    rng = np.random.default_rng(5)
+    X0 = goddard_costate_batch(B, 1e-2)
+    sw = np.stack([rng.uniform(0.005, 0.04, B), rng.uniform(0.05, 0.1, B)], axis=1)
+    tf = rng.uniform(0.02, 0.12, B)
+    Xg = gfast.integrate_batch(0.0, tf, X0, sw=sw)
+    Xc = goracle.integrate_batch(0.0, tf, X0, aux_sw=sw)
+    assert relerr(Xg, Xc) <= 1e-10
+    for c in (gfast, goracle):
+        c.set_param("mu2", 1.0)
+
+
+def test_fast_residual_c1(gfast, goracle):
+    for c in (gfast, goracle):
+        c.set_param("mu2", 1.0)
+        c.set_param("KD", 310.0)
+    gfast.set_step_number(10)
+    goracle.m.step_nbr = 10
+    prob, z = goddard_c1_problem(goracle)
+    _setup_problem(gfast, prob)
+    Fc = goracle.residual(prob, z)
+    Fg = gfast.residual(z)
+    assert np.max(np.abs(Fg - Fc)) <= 1e-11 * np.max(np.abs(Fc))
