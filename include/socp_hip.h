@@ -89,6 +89,13 @@ int socp_integrate_batch(socp_ctx *ctx, int B, const double *t0, const double *t
 int socp_integrate_batch_dev(socp_ctx *ctx, int B, const double *d_t0, const double *d_tf,
                              const double *d_sw, const double *d_X0, double *d_Xf, int is_jac);
 
+/* replaces: the observer form of odeTools::integrate (odeTools.cpp:103-123) used by the trace replay
+ * (shooting.cpp:496-544, model.hpp:401-407): one trajectory, the state after every step kept.
+ * dense: [cap][len], times: [cap]; row 0 = (t0, X0), row k = accumulated time and state after k
+ * steps; *rows = steps + 1 (rows beyond cap are counted, not stored).  sw: NULL or 2 values. */
+int socp_integrate_dense(socp_ctx *ctx, double t0, double tf, const double *sw, const double *X0,
+                         double *dense, double *times, int cap, int *rows);
+
 /* replaces: model::Model / Control / Hamiltonian called outside the integrator (trace,
  * free-time rows).  t: [B]; X: [B][len]; out: [B][out_len]. */
 int socp_eval_batch(socp_ctx *ctx, int what, int B, const double *t, const double *sw,

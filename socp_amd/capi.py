@@ -66,6 +66,7 @@ def lib():
         L.socp_ctx_counters.argtypes = [_vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
         L.socp_integrate_batch.argtypes = [_vp, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_int]
         L.socp_integrate_batch_dev.argtypes = [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int]
+        L.socp_integrate_dense.argtypes = [_vp, C.c_double, C.c_double, _dp, _dp, _dp, _dp, C.c_int, _ip]
         L.socp_eval_batch.argtypes = [_vp, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, _dp, C.c_int]
         L.socp_problem_set.argtypes = [_vp, C.c_int, _ip, _ip, _dp, _dp]
         L.socp_problem_num_param.argtypes = [_vp]
@@ -192,6 +193,19 @@ class Context:
         """Device pointers (ints); enqueue only."""
         self._chk(self.L.socp_integrate_batch_dev(self.h, int(B), _vp(d_t0), _vp(d_tf), _vp(d_sw), _vp(d_X0),
                                                   _vp(d_Xf), int(is_jac)))
+
+    def integrate_dense(self, t0, tf, X0, sw=None, cap=None):
+        """One trajectory, state after every step: returns (times[rows], X[rows][s])."""
+        X0 = _f64(X0)
+        cap = cap or 20000
+        dense = np.empty((cap, len(X0)))
+        times = np.empty(cap)
+        rows = C.c_int(0)
+        swp = _d(_f64(sw)) if sw is not None else None
+        self._chk(self.L.socp_integrate_dense(self.h, float(t0), float(tf), swp, _d(X0), _d(dense), _d(times), cap,
+                                              C.byref(rows)))
+        k = min(rows.value, cap)
+        return times[:k].copy(), dense[:k].copy()
 
     def eval_batch(self, what, t, X, sw=None):
         X = _f64(X)

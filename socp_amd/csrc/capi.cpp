@@ -303,6 +303,32 @@ int socp_integrate_batch(socp_ctx *c, int B, const double *t0, const double *tf,
     return SOCP_OK;
 }
 
+int socp_integrate_dense(socp_ctx *c, double t0, double tf, const double *sw, const double *X0,
+                         double *dense, double *times, int cap, int *rows)
+{
+    if (!c) return SOCP_ERR_ARG;
+    if (!X0 || !dense || !times || !rows || cap < 1) return fail(c, SOCP_ERR_ARG, "integrate_dense: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t S = c->S;
+    HIP_TRY(c, c->s_in.reserve(sizeof(double) * S));
+    HIP_TRY(c, c->s_out.reserve(sizeof(double) * S * cap));
+    HIP_TRY(c, c->s_t0.reserve(sizeof(double) * cap));
+    HIP_TRY(c, c->s_aux.reserve(sizeof(int) * 4));
+    HIP_TRY(c, hipMemcpyAsync(c->s_in.p, X0, sizeof(double) * S, hipMemcpyHostToDevice, c->stream));
+    const double s0 = sw ? sw[0] : c->P.sw0, s1 = sw ? sw[1] : c->P.sw1;
+    c->n_traj += 1; c->n_launch += 1;
+    hipError_t e = use_fast(c)
+        ? dense_fast(c->model_id, c->stream, c->P, t0, tf, s0, s1, c->s_in.as<double>(), c->s_out.as<double>(), c->s_t0.as<double>(), cap, c->s_aux.as<int>())
+        : dense_exact(c->model_id, c->stream, c->P, t0, tf, s0, s1, c->s_in.as<double>(), c->s_out.as<double>(), c->s_t0.as<double>(), cap, c->s_aux.as<int>());
+    HIP_TRY(c, e);
+    HIP_TRY(c, hipMemcpyAsync(rows, c->s_aux.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const int kept = *rows < cap ? *rows : cap;
+    HIP_TRY(c, hipMemcpy(dense, c->s_out.p, sizeof(double) * S * kept, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(times, c->s_t0.p, sizeof(double) * kept, hipMemcpyDeviceToHost));
+    return SOCP_OK;
+}
+
 int socp_eval_batch(socp_ctx *c, int what, int B, const double *t, const double *sw,
                     const double *X, int len, double *out, int is_jac)
 {

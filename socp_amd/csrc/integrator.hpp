@@ -97,6 +97,37 @@ __global__ __launch_bounds__(64) void traj_lane_kernel(ModelParams P, int B,
     for (int idx = lane; idx < rows * S; idx += 64) dst[idx] = tile[(idx / S) * LD + (idx % S)];
 }
 
+// K_dense: ONE trajectory with the state after every step kept (trace replay, shooting.cpp:496-544 ->
+// the observer form of integrate, odeTools.cpp:103-123).  Row 0 is (t0, X0); row k the accumulated
+// time t and state after k steps -- exactly what the reference's observer is shown.  Not hot.
+template <class Mdl>
+__global__ void traj_dense_kernel(ModelParams P, double t0, double tf, double sw0, double sw1,
+                                  const double *__restrict__ X0, double *__restrict__ dense,
+                                  double *__restrict__ times, int cap, int *__restrict__ rows)
+{
+    constexpr int S = Mdl::S;
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    double X[S];
+#pragma unroll
+    for (int k = 0; k < S; k++) { X[k] = X0[k]; dense[k] = X[k]; }
+    times[0] = t0;
+    int r = 1;
+    const double dt = (tf - t0) / P.step_nbr;
+    double t = t0;
+    while (t < (tf - dt / 2)) {
+        const double step = (t + dt > tf) ? (tf - t) : dt;
+        Lane<Mdl>::rk4(P, sw0, sw1, t, X, step);
+        t += dt;
+        if (r < cap) {
+#pragma unroll
+            for (int k = 0; k < S; k++) dense[(long)r * S + k] = X[k];
+            times[r] = t;
+        }
+        r++;
+    }
+    *rows = r;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Shooting residual pieces shared by K_res and K_fdj.  One trajectory = (row, segment i).
 // It owns these residual rows (shooting.cpp:945-990):

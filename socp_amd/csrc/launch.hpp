@@ -16,6 +16,9 @@ namespace socp {
     hipError_t fdrows_##FLAVOUR(int model_id, hipStream_t st, const ModelParams &P,                  \
                                 const ProblemDev &pb, int np, const double *z, double eps,           \
                                 double *rows);                                                       \
+    hipError_t dense_##FLAVOUR(int model_id, hipStream_t st, const ModelParams &P, double t0,         \
+                               double tf, double sw0, double sw1, const double *X0, double *dense,   \
+                               double *times, int cap, int *rows);                                   \
     hipError_t eval_##FLAVOUR(int model_id, hipStream_t st, const ModelParams &P, int what, int B,   \
                               const double *t, const double *sw, const double *X, double *out);
 
