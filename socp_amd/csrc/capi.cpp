@@ -7,6 +7,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -167,6 +168,12 @@ int socp_ctx_create(socp_ctx **out, int model_id, int device)
         c->P.sw0 = c->P.sw1 = 0.0; c->P.step_nbr = 30;
     }
     c->S = 2 * c->dim;
+    // default arithmetic flavour can be chosen from the environment (host programs that do not call
+    // socp_ctx_set_variant): SOCP_VARIANT=exact|fast
+    if (const char *v = std::getenv("SOCP_VARIANT")) {
+        if (std::strcmp(v, "fast") == 0) c->variant = SOCP_VARIANT_LANE_FAST;
+        else if (std::strcmp(v, "exact") == 0) c->variant = SOCP_VARIANT_LANE_EXACT;
+    }
     e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return hip_fail(nullptr, e, "hipStreamCreate"); }
     c->stream = c->own_stream;

@@ -1,11 +1,16 @@
 // goddard_flow.cpp -- the workload of the reference's tests/testGoddard.cpp (same problem set-up,
-// same four solves, same API calls), written as a checkable program: every stage prints one JSON
-// line {stage, info, nfev, n, z[...]} instead of "OK = info".  Run by tests/test_host_flow.py on
-// the GPU box; the expected solutions are in tests/golden/.
+// same API calls, same four solves) as a checkable program: every solve prints one JSON line
+// {stage, info, nfev, n, trajectories, z[...]} instead of "OK = info".
 //
-// usage: goddard_flow [stepNbr] [nMulti] [dedup 0|1] [tracefile]
+//   goddard_flow full  <stepNbr> <dedup> <xtol> [tracefile]      whole flow from the trivial guess
+//   goddard_flow stage <k> <stepNbr> <dedup> <xtol> <zfile>      ONE solve (k = 1..4) started from the
+//                       85 unknowns in <zfile> (node states + tf), the state testGoddard.cpp is in
+//                       just before its k-th SolveOCP call
+// Run by tests/test_host_flow.py on the GPU box; expected solutions are in tests/golden/.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <fstream>
 #include <iostream>
 #include <string>
 #include <vector>
@@ -13,83 +18,111 @@
 #include "socp/shooting.hpp"
 #include "models/goddard/goddard.hpp"
 
-static void report(const char *stage, int info, const shooting &s, int n)
+namespace {
+const int kMulti = 6;
+
+void report(const char *stage, int info, const shooting &s)
 {
     std::vector<real> z;
     s.GetParameters(z);
     std::vector<int> calls = s.GetCallNumber();
-    std::printf("{\"stage\": \"%s\", \"info\": %d, \"nfev\": %d, \"n\": %d, \"trajectories\": %lld, \"z\": [", stage, info, calls[0], n,
-                s.GetTrajectoryCount());
+    std::printf("{\"stage\": \"%s\", \"info\": %d, \"nfev\": %d, \"n\": %d, \"trajectories\": %lld, \"z\": [", stage, info,
+                calls[0], (int)z.size(), s.GetTrajectoryCount());
     for (size_t k = 0; k < z.size(); k++) std::printf("%s%.17g", k ? ", " : "", z[k]);
     std::printf("]}\n");
     std::fflush(stdout);
 }
 
+std::vector<int> final_modes(int dim)
+{
+    std::vector<int> m(dim, model::FIXED);
+    m[3] = m[4] = m[5] = m[6] = model::FREE;     // final velocity and mass free (testGoddard.cpp:43-48)
+    return m;
+}
+
+// testGoddard.cpp:115-156: re-grid on the bang / singular / off structure, free switching times
+int singular_stage(goddard &g, shooting &sh, int dim)
+{
+    std::vector<real> vt(kMulti + 1);
+    std::vector<model::mstate> vX(kMulti + 1);
+    sh.GetSolution(vt, vX);
+    const real ti = 0, tf = vt[kMulti], s1 = 0.0227, s2 = 0.08;
+    vt[0] = ti; vt[1] = s1 / 2; vt[2] = s1; vt[3] = (s2 + s1) / 2; vt[4] = s2; vt[5] = (s2 + tf) / 2; vt[6] = tf;
+    for (int i = 0; i <= kMulti; i++) vX[i] = sh.Move(vt[i]);
+    std::vector<int> mode_t(kMulti + 1, model::CONTINUOUS);
+    mode_t[0] = model::FIXED; mode_t[2] = model::FREE; mode_t[4] = model::FREE; mode_t[kMulti] = model::FREE;
+    std::vector<std::vector<int> > mode_X(kMulti + 1, std::vector<int>(dim, model::CONTINUOUS));
+    mode_X[0] = std::vector<int>(dim, model::FIXED);
+    mode_X[kMulti] = final_modes(dim);
+    sh.SetMode(mode_t, mode_X);
+    sh.InitShooting(vt, vX);
+    g.SetParameterDataName("mu2", 0.0);
+    g.SetParameterDataName("singularControl", -1);
+    return sh.SolveOCP(0.0);
+}
+}  // namespace
+
 int main(int argc, char **argv)
 {
-    const int stepNbr = argc > 1 ? std::atoi(argv[1]) : 10;
-    const int nMulti = argc > 2 ? std::atoi(argv[2]) : 6;
-    const bool dedup = argc > 3 ? std::atoi(argv[3]) != 0 : true;
-    const std::string trace = argc > 4 ? argv[4] : "";
+    if (argc < 5) {
+        std::fprintf(stderr, "usage: goddard_flow full <stepNbr> <dedup> <xtol> [trace] | stage <k> <stepNbr> <dedup> <xtol> <zfile>\n");
+        return 64;
+    }
+    const bool single = std::strcmp(argv[1], "stage") == 0;
+    const int a = single ? 3 : 2;
+    const int stage = single ? std::atoi(argv[2]) : 0;
+    const int stepNbr = std::atoi(argv[a]);
+    const bool dedup = std::atoi(argv[a + 1]) != 0;
+    const double xtol = std::atof(argv[a + 2]);
+    const std::string extra = argc > a + 3 ? argv[a + 3] : "";
 
-    goddard my_goddard(trace, stepNbr);
+    goddard my_goddard(single ? std::string("") : extra, stepNbr);
     const int dim = my_goddard.GetDim();
     my_goddard.SetParameterDataName("mu2", 1.0);
-
-    shooting my_shooting(my_goddard, nMulti, 1);
-    my_shooting.SetPrecision(1e-6);
+    shooting my_shooting(my_goddard, kMulti, 1);
+    my_shooting.SetPrecision(xtol);
     my_shooting.SetJacobianDedup(dedup);
+    my_shooting.SetMode(model::FREE, final_modes(dim));
 
-    std::vector<real> vt(nMulti + 1);
-    std::vector<model::mstate> vX(nMulti + 1);
-
-    const int mode_tf = model::FREE;
-    std::vector<int> mode_Xf(dim, model::FIXED);
-    mode_Xf[3] = mode_Xf[4] = mode_Xf[5] = mode_Xf[6] = model::FREE;     // final velocity and mass free
-    my_shooting.SetMode(mode_tf, mode_Xf);
-
-    const real ti = 0;
-    model::mstate Xi(2 * dim);
-    Xi[0] = 0.999949994; Xi[1] = 0.0001; Xi[2] = 0.01;
-    Xi[3] = Xi[4] = Xi[5] = 1e-10;
-    Xi[6] = 1.0;
-    for (int k = 7; k < 14; k++) Xi[k] = 0.1;
-    real tf = 0.1;
     model::mstate Xf(2 * dim);
     Xf[0] = 1.01;
-    my_shooting.InitShooting(ti, Xi, tf, Xf);
+    if (!single) {
+        model::mstate Xi(2 * dim);
+        Xi[0] = 0.999949994; Xi[1] = 0.0001; Xi[2] = 0.01;
+        Xi[3] = Xi[4] = Xi[5] = 1e-10;
+        Xi[6] = 1.0;
+        for (int k = 7; k < 14; k++) Xi[k] = 0.1;
+        my_shooting.InitShooting(0.0, Xi, 0.1, Xf);
 
-    int info = 1;
-    my_goddard.SetParameterDataName("KD", 0.0);
-    info = my_shooting.SolveOCP(0.0);
-    report("no_drag", info, my_shooting, 2 * dim * nMulti + 1);
-    if (info == 1) {
-        info = my_shooting.SolveOCP(1.0, "KD", 310.0);
-        report("drag_continuation", info, my_shooting, 2 * dim * nMulti + 1);
+        my_goddard.SetParameterDataName("KD", 0.0);
+        int info = my_shooting.SolveOCP(0.0);
+        report("no_drag", info, my_shooting);
+        if (info == 1) { info = my_shooting.SolveOCP(1.0, "KD", 310.0); report("drag_continuation", info, my_shooting); }
+        if (info == 1) { info = my_shooting.SolveOCP(1.0, "mu2", 0.2); report("mu2_continuation", info, my_shooting); }
+        if (info == 1) { info = singular_stage(my_goddard, my_shooting, dim); report("singular_arc", info, my_shooting); }
+        if (info == 1 && !extra.empty()) my_shooting.Trace();
+        return info == 1 ? 0 : 2;
     }
-    if (info == 1) {
-        info = my_shooting.SolveOCP(1.0, "mu2", 0.2);
-        report("mu2_continuation", info, my_shooting, 2 * dim * nMulti + 1);
-    }
-    if (info != 1 || nMulti != 6) return info == 1 ? 0 : 2;
 
-    // bang - singular - off structure with free switching times (testGoddard.cpp:115-156)
-    my_shooting.GetSolution(vt, vX);
-    tf = vt[nMulti];
-    const real s1 = 0.0227, s2 = 0.08;
-    vt[0] = ti; vt[1] = s1 / 2; vt[2] = s1; vt[3] = (s2 + s1) / 2; vt[4] = s2; vt[5] = (s2 + tf) / 2; vt[6] = tf;
-    for (int i = 0; i <= nMulti; i++) vX[i] = my_shooting.Move(vt[i]);
-    std::vector<int> mode_t(nMulti + 1, model::CONTINUOUS);
-    mode_t[0] = model::FIXED; mode_t[2] = model::FREE; mode_t[4] = model::FREE; mode_t[nMulti] = mode_tf;
-    std::vector<std::vector<int> > mode_X(nMulti + 1, std::vector<int>(dim, model::CONTINUOUS));
-    mode_X[0] = std::vector<int>(dim, model::FIXED);
-    mode_X[nMulti] = mode_Xf;
-    my_shooting.SetMode(mode_t, mode_X);
+    // single stage: restore the unknowns the reference program holds before its k-th solve
+    std::ifstream in(extra.c_str());
+    std::vector<real> z;
+    for (real v; in >> v;) z.push_back(v);
+    if ((int)z.size() != 2 * dim * kMulti + 1) { std::fprintf(stderr, "zfile must hold %d values\n", 2 * dim * kMulti + 1); return 64; }
+    std::vector<real> vt(kMulti + 1);
+    std::vector<model::mstate> vX(kMulti + 1, model::mstate(2 * dim));
+    const real tf = z.back();
+    for (int i = 0; i <= kMulti; i++) vt[i] = 0.0 + i * (tf - 0.0) / kMulti;
+    for (int i = 0; i < kMulti; i++) vX[i].assign(z.begin() + 2 * dim * i, z.begin() + 2 * dim * (i + 1));
+    vX[kMulti] = Xf;
     my_shooting.InitShooting(vt, vX);
-    my_goddard.SetParameterDataName("mu2", 0.0);
-    my_goddard.SetParameterDataName("singularControl", -1);
-    info = my_shooting.SolveOCP(0.0);
-    report("singular_arc", info, my_shooting, 2 * dim * nMulti + 3);
-    if (!trace.empty()) my_shooting.Trace();
+    int info = 0;
+    switch (stage) {
+    case 1: my_goddard.SetParameterDataName("KD", 0.0); info = my_shooting.SolveOCP(0.0); report("no_drag", info, my_shooting); break;
+    case 2: my_goddard.SetParameterDataName("KD", 0.0); info = my_shooting.SolveOCP(1.0, "KD", 310.0); report("drag_continuation", info, my_shooting); break;
+    case 3: info = my_shooting.SolveOCP(1.0, "mu2", 0.2); report("mu2_continuation", info, my_shooting); break;
+    case 4: my_goddard.SetParameterDataName("mu2", 0.2); info = singular_stage(my_goddard, my_shooting, dim); report("singular_arc", info, my_shooting); break;
+    default: return 64;
+    }
     return info == 1 ? 0 : 2;
 }

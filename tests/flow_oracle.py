@@ -230,3 +230,66 @@ def goddard_test_flow(solver="scipy", step_nbr=10, M=6):
     info = sh.solve()
     stages.append(dict(stage="singular_arc", info=info, nfev=sh.nfev, z=sh.z.copy()))
     return stages
+
+
+def goddard_initial_guess(step_nbr=10, M=6):
+    """The unknown vector testGoddard.cpp holds after InitShooting (interior nodes seeded with KD = 310)."""
+    o = Oracle(MODEL_GODDARD, step_nbr=step_nbr)
+    o.set_param("mu2", 1.0)
+    sh = OracleShooting(o, M, "scipy")
+    mode_xf = np.zeros(7, dtype=np.int32)
+    mode_xf[3:7] = FREE
+    sh.set_mode_final(FREE, mode_xf)
+    Xi = np.array([0.999949994, 1e-4, 0.01, 1e-10, 1e-10, 1e-10, 1.0] + [0.1] * 7)
+    Xf = np.zeros(14)
+    Xf[0] = 1.01
+    sh.init_uniform(0.0, Xi, 0.1, Xf)
+    return sh.z.copy()
+
+
+def goddard_single_stage(k, z_init, xtol, solver="scipy", step_nbr=10, backend=None):
+    """One solve of the testGoddard flow (k = 1..4) started from the unknowns z_init -- the oracle-side
+    twin of `goddard_flow stage k ...` (tests/cpp/goddard_flow.cpp).  `backend`: optional object with the
+    Oracle interface (set_param / traj / residual / timeline ...) to run the same flow on another engine."""
+    M = 6
+    o = backend if backend is not None else Oracle(MODEL_GODDARD, step_nbr=step_nbr)
+    o.set_param("mu2", 1.0)
+    o.set_param("KD", 310.0)
+    sh = OracleShooting(o, M, solver)
+    sh.xtol = xtol
+    mode_xf = np.zeros(7, dtype=np.int32)
+    mode_xf[3:7] = FREE
+    sh.set_mode_final(FREE, mode_xf)
+    Xf = np.zeros(14)
+    Xf[0] = 1.01
+    tf = z_init[-1]
+    vt = np.array([0.0 + i * (tf - 0.0) / M for i in range(M + 1)])
+    sh.init_nodes(vt, np.vstack([np.asarray(z_init[:84]).reshape(M, 14), Xf]))
+    if k == 1:
+        o.set_param("KD", 0.0)
+        info = sh.solve()
+        nfev = sh.nfev
+    elif k == 2:
+        o.set_param("KD", 0.0)
+        info = sh.solve_param(1.0, lambda v: o.set_param("KD", v), 0.0, 310.0)
+        nfev = sh.stage_fev
+    elif k == 3:
+        info = sh.solve_param(1.0, lambda v: o.set_param("mu2", v), 1.0, 0.2)
+        nfev = sh.stage_fev
+    else:
+        o.set_param("mu2", 0.2)
+        vt, vX = sh.get_solution()
+        tf = vt[M]
+        s1, s2 = 0.0227, 0.08
+        vt = np.array([0.0, s1 / 2, s1, (s2 + s1) / 2, s2, (s2 + tf) / 2, tf])
+        vX = np.stack([sh.move(t) for t in vt])
+        mode_x = np.full((M + 1, 7), CONTINUOUS, dtype=np.int32)
+        mode_x[0] = FIXED
+        mode_x[M] = mode_xf
+        sh.set_mode([FIXED, CONTINUOUS, FREE, CONTINUOUS, FREE, CONTINUOUS, FREE], mode_x)
+        sh.init_nodes(vt, vX)
+        o.set_param("mu2", 0.0)
+        o.set_param("singularControl", -1.0)
+        info = sh.solve()
+        nfev = sh.nfev
+    return dict(info=int(info), nfev=int(nfev), z=sh.z.copy())
