@@ -207,18 +207,25 @@ class Context:
         k = min(rows.value, cap)
         return times[:k].copy(), dense[:k].copy()
 
-    def eval_batch(self, what, t, X, sw=None):
+    def eval_batch(self, what, t, X, sw=None, is_jac=0):
         X = _f64(X)
         B = X.shape[0]
         t = _f64(np.broadcast_to(t, (B,)))
-        out_len = {EVAL_RHS: X.shape[1], EVAL_CONTROL: 3, EVAL_HAMILTONIAN: 1}[what]
+        out_len = {EVAL_RHS: X.shape[1], EVAL_CONTROL: 3, EVAL_HAMILTONIAN: (self.s + 1) if is_jac else 1}[what]
         out = np.empty((B, out_len))
         swp = None
         if sw is not None:
             sw = _f64(sw)
             swp = _d(sw)
-        self._chk(self.L.socp_eval_batch(self.h, what, B, _d(t), swp, _d(X), X.shape[1], _d(out), 0))
+        self._chk(self.L.socp_eval_batch(self.h, what, B, _d(t), swp, _d(X), X.shape[1], _d(out), int(is_jac)))
         return out
+
+    def var_jacobian(self, z):
+        """Analytic (variational) shooting Jacobian J[row, col] (hybrj path)."""
+        z = _f64(z)
+        Jcm = np.empty((self.n, self.n))
+        self._chk(self.L.socp_var_jacobian(self.h, _d(z), _d(Jcm)))
+        return Jcm.T.copy()
 
     # -- shooting problem
     def problem_set(self, mode_t, mode_x, time, xnode):

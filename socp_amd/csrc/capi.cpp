@@ -273,9 +273,17 @@ int socp_integrate_batch_dev(socp_ctx *c, int B, const double *d_t0, const doubl
 {
     if (!c) return SOCP_ERR_ARG;
     if (B < 0 || (B > 0 && (!d_t0 || !d_tf || !d_X0 || !d_Xf))) return fail(c, SOCP_ERR_ARG, "integrate_batch: null argument");
-    if (is_jac) return fail(c, SOCP_ERR_UNSUPPORTED, "integrate_batch: variational state (is_jac=1) not available in this build");
-    if (int rc = check_variant(c)) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
+    if (is_jac) {
+        // variational state: one wavefront per trajectory (doubleIntegrator; goddard has modelOrder 0 only)
+        if (c->model_id != SOCP_MODEL_DOUBLE_INTEGRATOR)
+            return fail(c, SOCP_ERR_UNSUPPORTED, "integrate_batch: this model has no variational equations (modelOrder 0)");
+        if (d_Xf == d_X0) return fail(c, SOCP_ERR_ARG, "integrate_batch: is_jac=1 needs distinct input and output");
+        c->n_traj += B; c->n_launch += 1;
+        HIP_TRY(c, var_traj(c->model_id, c->stream, c->P, B, d_t0, d_tf, d_X0, d_Xf));
+        return SOCP_OK;
+    }
+    if (int rc = check_variant(c)) return rc;
     HIP_TRY(c, run_traj(c, B, d_t0, d_tf, d_sw, d_X0, d_Xf));
     return SOCP_OK;
 }
@@ -342,11 +350,20 @@ int socp_eval_batch(socp_ctx *c, int what, int B, const double *t, const double 
     if (!c) return SOCP_ERR_ARG;
     if (B < 0 || (B > 0 && (!t || !X || !out))) return fail(c, SOCP_ERR_ARG, "eval_batch: null argument");
     if (what < SOCP_EVAL_RHS || what > SOCP_EVAL_HAMILTONIAN) return fail(c, SOCP_ERR_ARG, "eval_batch: unknown quantity");
-    if (is_jac) return fail(c, SOCP_ERR_UNSUPPORTED, "eval_batch: is_jac=1 not available in this build");
-    if (len != c->S) return fail(c, SOCP_ERR_ARG, "eval_batch: state length must be 2*dim");
+    const int L = (c->S + 1) * c->S;
+    const bool var = is_jac && what != SOCP_EVAL_CONTROL;
+    if (var && c->model_id != SOCP_MODEL_DOUBLE_INTEGRATOR)
+        return fail(c, SOCP_ERR_UNSUPPORTED, "eval_batch: this model has no variational equations (modelOrder 0)");
+    if (var && what == SOCP_EVAL_RHS && len != L) return fail(c, SOCP_ERR_ARG, "eval_batch: augmented state length must be (2*dim+1)*2*dim");
+    if (!(var && what == SOCP_EVAL_RHS) && len < c->S) return fail(c, SOCP_ERR_ARG, "eval_batch: state length must be at least 2*dim");
     if (B == 0) return SOCP_OK;
     HIP_TRY(c, hipSetDevice(c->device));
-    const int out_len = what == SOCP_EVAL_RHS ? c->S : (what == SOCP_EVAL_CONTROL ? 3 : 1);
+    const int out_len = var ? (what == SOCP_EVAL_RHS ? L : c->S + 1)
+                            : (what == SOCP_EVAL_RHS ? c->S : (what == SOCP_EVAL_CONTROL ? 3 : 1));
+    if (!var && len != c->S) {
+        // a longer (augmented) vector may be passed for Control / Hamiltonian: only the state part is read
+        return fail(c, SOCP_ERR_ARG, "eval_batch: pass the 2*dim state part for is_jac=0 evaluations");
+    }
     HIP_TRY(c, c->s_t0.reserve(sizeof(double) * B));
     HIP_TRY(c, c->s_in.reserve(sizeof(double) * (size_t)B * len));
     HIP_TRY(c, c->s_out.reserve(sizeof(double) * (size_t)B * out_len));
@@ -359,7 +376,9 @@ int socp_eval_batch(socp_ctx *c, int what, int B, const double *t, const double 
         dsw = c->s_sw.as<double>();
     }
     c->n_launch += 1;
-    hipError_t e = use_fast(c)
+    hipError_t e = var
+        ? var_eval(c->model_id, c->stream, c->P, what == SOCP_EVAL_RHS ? 0 : 1, B, c->s_in.as<double>(), len, c->s_out.as<double>())
+        : use_fast(c)
         ? eval_fast(c->model_id, c->stream, c->P, what, B, c->s_t0.as<double>(), dsw, c->s_in.as<double>(), c->s_out.as<double>())
         : eval_exact(c->model_id, c->stream, c->P, what, B, c->s_t0.as<double>(), dsw, c->s_in.as<double>(), c->s_out.as<double>());
     HIP_TRY(c, e);
@@ -617,9 +636,28 @@ int socp_fd_jacobian(socp_ctx *c, const double *z, const double *fvec, double ep
     return SOCP_OK;
 }
 
-int socp_var_jacobian(socp_ctx *c, const double *, double *)
+int socp_var_jacobian(socp_ctx *c, const double *z, double *fjac)
 {
-    return fail(c, SOCP_ERR_UNSUPPORTED, "var_jacobian: variational Jacobian not available in this build");
+    if (!c) return SOCP_ERR_ARG;
+    if (!c->has_problem) return fail(c, SOCP_ERR_ARG, "var_jacobian: no problem set");
+    if (!z || !fjac) return fail(c, SOCP_ERR_ARG, "var_jacobian: null argument");
+    if (c->model_id != SOCP_MODEL_DOUBLE_INTEGRATOR)
+        return fail(c, SOCP_ERR_UNSUPPORTED, "var_jacobian: this model has no variational equations (modelOrder 0)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t n = c->n, M = c->M, L = (size_t)(c->S + 1) * c->S;
+    HIP_TRY(c, c->s_in.reserve(sizeof(double) * n));
+    HIP_TRY(c, c->s_aux.reserve(sizeof(double) * 2 * M * L));
+    HIP_TRY(c, c->s_t0.reserve(sizeof(double) * M));
+    HIP_TRY(c, c->s_tf.reserve(sizeof(double) * M));
+    HIP_TRY(c, c->s_out.reserve(sizeof(double) * n * n));
+    HIP_TRY(c, hipMemcpyAsync(c->s_in.p, z, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    double *Xaug = c->s_aux.as<double>(), *Xtf = Xaug + M * L;
+    c->n_traj += (long long)M; c->n_launch += 3;
+    HIP_TRY(c, var_jacobian(c->model_id, c->stream, c->P, c->pb, c->s_in.as<double>(), Xaug, Xtf,
+                            c->s_t0.as<double>(), c->s_tf.as<double>(), c->s_out.as<double>()));
+    HIP_TRY(c, hipMemcpyAsync(fjac, c->s_out.p, sizeof(double) * n * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SOCP_OK;
 }
 
 }  // extern "C"

@@ -8,3 +8,40 @@
 #define SOCP_GODDARD_SMOOTH GoddardExactSmooth
 #define SOCP_DINT DIntExact
 #include "launch_impl.hpp"
+
+// ---- variational path (compiled here: no contraction) -------------------------------------------
+#include "variational.hpp"
+
+namespace socp {
+
+hipError_t var_traj(int model_id, hipStream_t st, const ModelParams &P, int B, const double *t0, const double *tf,
+                    const double *X0, double *Xf)
+{
+    if (model_id != 2) return hipErrorInvalidValue;
+    if (B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(traj_var_wave_kernel<DIntVar>, dim3(B), dim3(64), 0, st, P, t0, tf, X0, Xf);
+    return hipGetLastError();
+}
+
+hipError_t var_jacobian(int model_id, hipStream_t st, const ModelParams &P, const ProblemDev &pb, const double *z,
+                        double *Xaug, double *Xtf, double *t0, double *tf, double *fjac)
+{
+    if (model_id != 2) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(var_prepare_kernel<DIntVar>, dim3(pb.M), dim3(64), 0, st, pb, z, Xaug, t0, tf);
+    hipLaunchKernelGGL(traj_var_wave_kernel<DIntVar>, dim3(pb.M), dim3(64), 0, st, P, t0, tf, Xaug, Xtf);
+    hipError_t e = hipMemsetAsync(fjac, 0, sizeof(double) * (size_t)pb.n * pb.n, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(var_assemble_kernel<DIntVar>, dim3((pb.M + 63) / 64), dim3(64), 0, st, P, pb, z, Xtf, fjac);
+    return hipGetLastError();
+}
+
+hipError_t var_eval(int model_id, hipStream_t st, const ModelParams &P, int what, int B, const double *X, int len,
+                    double *out)
+{
+    if (model_id != 2) return hipErrorInvalidValue;
+    if (B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(var_eval_kernel<DIntVar>, dim3((B + 63) / 64), dim3(64), 0, st, P, what, B, X, len, out);
+    return hipGetLastError();
+}
+
+}  // namespace socp

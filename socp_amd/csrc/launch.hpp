@@ -24,6 +24,13 @@ namespace socp {
 
 SOCP_DECLARE_LAUNCHERS(exact)
 // flavour-independent: Jacobian from the rows of fdrows (differences and one division per entry)
+// variational (hybrj) path: double integrator only; reference operation order
+hipError_t var_traj(int model_id, hipStream_t st, const ModelParams &P, int B, const double *t0, const double *tf,
+                    const double *X0, double *Xf);
+hipError_t var_jacobian(int model_id, hipStream_t st, const ModelParams &P, const ProblemDev &pb, const double *z,
+                        double *Xaug, double *Xtf, double *t0, double *tf, double *fjac);
+hipError_t var_eval(int model_id, hipStream_t st, const ModelParams &P, int what, int B, const double *X, int len,
+                    double *out);
 hipError_t fd_diff(hipStream_t st, int n, int np, const double *z, double eps, const double *rows, double *fjac);
 
 SOCP_DECLARE_LAUNCHERS(fast)

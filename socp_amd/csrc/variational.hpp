@@ -1,0 +1,266 @@
+// variational.hpp -- the hybrj path on the device: integration of the augmented
+// state [X ; dX/dX0] with ONE WAVEFRONT PER TRAJECTORY and assembly of the analytic shooting Jacobian.
+//
+// Augmented state layout (shooting.cpp:1003-1005): L = (s+1)*s doubles, X[0..s) the
+// state, X[s*(k+1)+i] = dX_k/dX0_i.  For the double integrator s = 12, L = 156: lane l of the wave
+// owns elements l, l+64, l+128.  Every RK4 stage publishes the stage vector to LDS, and each lane
+// then reads what its elements need from there: the sensitivity rows of OTHER state components
+// (d/dt R = (df/dX) R couples rows), and the three costates the control law reads.  Operation
+// order per element is the reference's (odeTools.cpp:89-98; doubleIntegrator.cpp:113-213), the
+// translation unit is compiled -ffp-contract=off; the path contains no exp, so results are
+// bit-identical to the x86 path.
+#pragma once
+#include "dev_common.hpp"
+#include "models_exact.hpp"
+
+namespace socp {
+
+// ---- double integrator: variational right-hand side and dH/dX ---------------------------------
+struct DIntVar : DIntExact {
+    static constexpr int L = (S + 1) * S;
+
+    // element e of Model(t, Y, isJac = 1) (doubleIntegrator.cpp:113-213).  df/dX is constant and has
+    // one nonzero per row (:155-166): rows 0-2 -> +R[row+3], rows 3-5 -> -R[row+6], rows 6-8 -> 0,
+    // rows 9-11 -> -R[row-3]; the reference sums the zero terms too, which changes nothing finite.
+    __device__ static __forceinline__ double aug_rhs(const ModelParams &P, int e, const double *Y)
+    {
+        if (e < S) {
+            if (e < 3) return Y[e + 3];
+            if (e < 6) {
+                double X[S];
+#pragma unroll
+                for (int k = 0; k < S; k++) X[k] = Y[k];
+                double u[3];
+                control_only(P, 0, 0, 0, X, u);
+                return P.p[DP_AMAX] * u[e - 3];
+            }
+            if (e < 9) return 0.0;
+            return -Y[e - 3];
+        }
+        const int i = (e - S) / S, j = (e - S) - i * S;
+        if (i < 3) return 0.0 + 1.0 * Y[S + S * (i + 3) + j];
+        if (i < 6) return 0.0 + (-1.0) * Y[S + S * (i + 6) + j];
+        if (i < 9) return 0.0;
+        return 0.0 + (-1.0) * Y[S + S * (i - 3) + j];
+    }
+
+    // doubleIntegrator.cpp:293-297: {0,0,0, p_x,p_y,p_z, vx,vy,vz, -p_vx,-p_vy,-p_vz, 0}
+    __device__ static __forceinline__ void dhamiltonian(const ModelParams &, const double *X, double (&dH)[S + 1])
+    {
+        dH[0] = 0; dH[1] = 0; dH[2] = 0;
+        dH[3] = X[6]; dH[4] = X[7]; dH[5] = X[8];
+        dH[6] = X[3]; dH[7] = X[4]; dH[8] = X[5];
+        dH[9] = -X[9]; dH[10] = -X[10]; dH[11] = -X[11];
+        dH[12] = 0;
+    }
+};
+
+// K_var: B augmented trajectories, one wave each.  X0, Xf: [B][L].
+template <class Mdl>
+__global__ __launch_bounds__(64) void traj_var_wave_kernel(ModelParams P, const double *__restrict__ t0,
+                                                           const double *__restrict__ tf,
+                                                           const double *__restrict__ X0,
+                                                           double *__restrict__ Xf)
+{
+    constexpr int L = Mdl::L;
+    constexpr int K = (L + 63) / 64;
+    __shared__ double Y[L];
+    const int lane = threadIdx.x;
+    const long b = blockIdx.x;
+    double X[K], F1[K], Fs[K], F[K], V[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int e = lane + 64 * k;
+        X[k] = e < L ? X0[b * L + e] : 0.0;
+    }
+    // publish a stage vector, then evaluate this lane's elements of the variational RHS
+    auto stage = [&](const double (&v)[K], double (&out)[K]) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < K; k++) { const int e = lane + 64 * k; if (e < L) Y[e] = v[k]; }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < K; k++) { const int e = lane + 64 * k; out[k] = e < L ? Mdl::aug_rhs(P, e, Y) : 0.0; }
+    };
+    const double ta = t0[b], tb = tf[b];
+    const double dt = (tb - ta) / P.step_nbr;
+    double t = ta;
+    while (t < (tb - dt / 2)) {                         // wave-uniform: same t in every lane
+        const double step = (t + dt > tb) ? (tb - t) : dt;
+        const double h2 = step / 2.0;
+        stage(X, F1);
+#pragma unroll
+        for (int k = 0; k < K; k++) V[k] = X[k] + h2 * F1[k];
+        stage(V, Fs);
+#pragma unroll
+        for (int k = 0; k < K; k++) V[k] = X[k] + h2 * Fs[k];
+        stage(V, F);
+#pragma unroll
+        for (int k = 0; k < K; k++) { V[k] = X[k] + step * F[k]; Fs[k] = Fs[k] + F[k]; }
+        stage(V, F);
+        const double h6 = step / 6.0;
+#pragma unroll
+        for (int k = 0; k < K; k++) X[k] = X[k] + h6 * (F1[k] + (F[k] + 2.0 * Fs[k]));
+        t += dt;
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) { const int e = lane + 64 * k; if (e < L) Xf[b * L + e] = X[k]; }
+}
+
+// K_vprep: augmented initial states and segment bounds of one unknown vector z:
+// Xaug[i] = [z_i ; I] (shooting.cpp:1003-1005,1060-1064), t0[i], tf[i] from the timeline.
+template <class Mdl>
+__global__ void var_prepare_kernel(ProblemDev pb, const double *__restrict__ z, double *__restrict__ Xaug,
+                                   double *__restrict__ t0, double *__restrict__ tf)
+{
+    constexpr int S = Mdl::S, L = Mdl::L;
+    const int i = blockIdx.x;
+    for (int e = threadIdx.x; e < L; e += blockDim.x) {
+        double v;
+        if (e < S) v = z[S * i + e];
+        else { const int k = (e - S) / S, c = (e - S) - k * S; v = (k == c) ? 1.0 : 0.0; }
+        Xaug[(long)i * L + e] = v;
+    }
+    if (threadIdx.x == 0) { t0[i] = node_time(pb, z, i); tf[i] = node_time(pb, z, i + 1); }
+}
+
+// K_vasm: analytic shooting Jacobian from the integrated augmented states (shooting.cpp:996-1130 with
+// the blocks of model.hpp:104-120,149-183,305-326 and shooting.cpp:1524-1555), one thread per segment,
+// written column-major (the hand-over layout, shooting.cpp:889-893) into a zeroed n x n matrix.
+// The reference's quirks are kept: only d/dt_end terms exist, and at a FREE interior time the copy loop
+// of shooting.cpp:1070 also drops the time term one block to the right.
+template <class Mdl>
+__global__ void var_assemble_kernel(ModelParams P, ProblemDev pb, const double *__restrict__ z,
+                                    const double *__restrict__ Xtf_all, double *__restrict__ fjac)
+{
+    constexpr int S = Mdl::S, D = Mdl::D, L = Mdl::L;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int M = pb.M, n = pb.n;
+    if (i >= M) return;
+    auto J = [&](int row, int col) -> double & { return fjac[row + (long)n * col]; };
+    const double t1 = node_time(pb, z, i), t2 = node_time(pb, z, i + 1);
+    const double *Xtf = Xtf_all + (long)i * L;
+    const int index = S * (i + 1);
+    auto ident = [](int k, int c) -> double { return k == c ? 1.0 : 0.0; };   // sensitivity block of [z ; I]
+
+    if (i == 0) {
+        const int *mx = pb.mode_x;
+        const int col_t = pb.ft_row[0];
+        double X1[S], fx[S], dH[S + 1];
+#pragma unroll
+        for (int k = 0; k < S; k++) X1[k] = z[k];
+        for (int k = 0; k < D; k++) {
+            const int src = (mx[k] == 1) ? (k + D) : k;                       // row of dX/dX0 copied (model.hpp:104-120)
+            for (int j = 0; j < S; j++) J(k, j) = ident(src, j);
+        }
+        if (col_t >= 0) {                                                     // InitialHFunction, model.hpp:256-289
+            Mdl::rhs(P, 0, 0, t1, X1, fx);
+            Mdl::dhamiltonian(P, X1, dH);
+            for (int k = 0; k < D; k++) J(k, col_t) = (mx[k] == 1) ? fx[k + D] : fx[k];
+            for (int c = 0; c < S; c++) {
+                double acc = 0;
+                for (int k = 0; k < S; k++) acc += dH[k] * ident(k, c);
+                J(col_t, c) = acc;
+            }
+            double acc = 0;
+            for (int k = 0; k < S; k++) acc += dH[k] * fx[k];
+            J(col_t, col_t) = acc + dH[S];
+        }
+    }
+    if (i < M - 1) {
+        const int *mx = pb.mode_x + (i + 1) * D;
+        const int col_t = pb.ft_row[i + 1];
+        double Xs[S], Xp[S], fxt[S], fxp[S];
+#pragma unroll
+        for (int k = 0; k < S; k++) { Xs[k] = Xtf[k]; Xp[k] = z[index + k]; }
+        Mdl::rhs(P, 0, 0, t2, Xs, fxt);
+        Mdl::rhs(P, 0, 0, t2, Xp, fxp);
+        for (int j = 0; j < D; j++) {
+            if (mx[j] == 0) {                                                 // FIXED (shooting.cpp:1524-1533)
+                for (int c = 0; c < S; c++) {
+                    J(index + j, index - S + c) = Xtf[S * (j + 1) + c];
+                    J(index + j + D, index + c) = ident(j, c);
+                    J(index + j, index + c) = 0.0;
+                    J(index + j + D, index - S + c) = 0.0;
+                }
+                if (col_t >= 0) { J(index + j, col_t) = fxt[j]; J(index + j + D, col_t) = fxp[j]; }
+            } else {                                                          // CONTINUOUS (:1544-1555)
+                for (int c = 0; c < S; c++) {
+                    J(index + j, index - S + c) = Xtf[S * (j + 1) + c];
+                    J(index + j, index + c) = -ident(j, c);
+                    J(index + j + D, index - S + c) = Xtf[S * (j + D + 1) + c];
+                    J(index + j + D, index + c) = -ident(j + D, c);
+                }
+                if (col_t >= 0) { J(index + j, col_t) = fxt[j] - fxp[j]; J(index + j + D, col_t) = fxt[j + D] - fxp[j + D]; }
+            }
+        }
+        if (col_t >= 0) {
+            // shooting.cpp:1070: the copy loop runs one entry past the 4d block, so the time term also
+            // lands at column index + 2d of the same rows (== col_t when that node is the last interior one)
+            const int spill = index + S;
+            if (spill < n && spill != col_t)
+                for (int k = 0; k < S; k++) J(index + k, spill) = J(index + k, col_t);
+            // model.hpp:305-326 SwitchingTimesFunction, isJac = 1
+            double dH[S + 1], dHp[S + 1];
+            Mdl::dhamiltonian(P, Xs, dH);
+            Mdl::dhamiltonian(P, Xp, dHp);
+            for (int c = 0; c < S; c++) {
+                double a = 0, b = 0;
+                for (int k = 0; k < S; k++) {
+                    a += dH[k] * Xtf[S * (k + 1) + c];
+                    b -= dHp[k] * ident(k, c);
+                }
+                J(col_t, index - S + c) = a;
+                J(col_t, index + c) = b;
+            }
+            double acc = 0;
+            for (int k = 0; k < S; k++) acc += dH[k] * fxt[k] - dHp[k] * fxp[k];
+            J(col_t, col_t) = acc + (dH[S] - dHp[S]);
+        }
+    }
+    if (i == M - 1) {
+        const int *mx = pb.mode_x + M * D;
+        const int col_t = pb.ft_row[M];
+        for (int k = 0; k < D; k++) {
+            const int src = (mx[k] == 1) ? (k + D + 1) : (k + 1);
+            for (int j = 0; j < S; j++) J(D + k, S * i + j) = Xtf[S * src + j];
+        }
+        if (col_t >= 0) {                                                     // FinalHFunction, model.hpp:149-183
+            double Xs[S], fx[S], dH[S + 1];
+#pragma unroll
+            for (int k = 0; k < S; k++) Xs[k] = Xtf[k];
+            Mdl::rhs(P, 0, 0, t2, Xs, fx);
+            Mdl::dhamiltonian(P, Xs, dH);
+            for (int k = 0; k < D; k++) J(D + k, col_t) = (mx[k] == 1) ? fx[k + D] : fx[k];
+            for (int c = 0; c < S; c++) {
+                double acc = 0;
+                for (int k = 0; k < S; k++) acc += dH[k] * Xtf[S * (k + 1) + c];
+                J(col_t, S * i + c) = acc;
+            }
+            double acc = 0;
+            for (int k = 0; k < S; k++) acc += dH[k] * fx[k];
+            J(col_t, col_t) = acc + dH[S];
+        }
+    }
+}
+
+// K_veval: Model(t, X, isJac = 1) on an augmented state and Hamiltonian(t, X, isJac = 1), one point
+// per thread (host mirror's virtuals; not hot)
+template <class Mdl>
+__global__ void var_eval_kernel(ModelParams P, int what, int B, const double *__restrict__ Xin, int len,
+                                double *__restrict__ out)
+{
+    constexpr int S = Mdl::S, L = Mdl::L;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const double *X = Xin + (long)b * len;
+    if (what == 0) {
+        for (int e = 0; e < L; e++) out[(long)b * L + e] = Mdl::aug_rhs(P, e, X);
+    } else {
+        double dH[S + 1];
+        Mdl::dhamiltonian(P, X, dH);
+        for (int k = 0; k <= S; k++) out[(long)b * (S + 1) + k] = dH[k];
+    }
+}
+
+}  // namespace socp

@@ -293,3 +293,60 @@ def goddard_single_stage(k, z_init, xtol, solver="scipy", step_nbr=10, backend=N
         info = sh.solve()
         nfev = sh.nfev
     return dict(info=int(info), nfev=int(nfev), z=sh.z.copy())
+
+
+def dint_basic_flow(solver="scipy", model_order=1, xtol=1e-8):
+    """tests/testDoubleIntegrator.cpp:24-145 on the oracle (hybrj when model_order == 1)."""
+    o = Oracle(MODEL_DINT)
+    sh = OracleShooting(o, 1, solver, use_jac=bool(model_order))
+    sh.xtol = xtol
+    sh.set_mode_final(FREE, np.zeros(6, dtype=np.int32))
+    Xi = np.zeros(12)
+    Xi[6:] = 0.01
+    Xf = np.zeros(12)
+    Xf[0], Xf[1] = 10.0, 15.0
+    sh.init_uniform(0.0, Xi, 10.0, Xf)
+    out = []
+    info = sh.solve()
+    out.append(dict(stage="solve", info=int(info), nfev=int(sh.nfev), njev=int(sh.njev), z=sh.z.copy()))
+    Xf2 = Xf.copy()
+    Xf2[1] = 20.0
+    sh.timed = np.array([0.0, 10.0])
+    sh.Xd = np.vstack([Xi, Xf2])
+    info = sh.solve_data(1.0)
+    out.append(dict(stage="data_continuation", info=int(info), nfev=int(sh.nfev), njev=int(sh.njev), z=sh.z.copy()))
+    if info == 1:
+        info = sh.solve_param(1.0, lambda v: o.m.p.__setitem__(2, v), 0.01, 0.02)
+    out.append(dict(stage="muT_continuation", info=int(info), nfev=int(sh.nfev), njev=int(sh.njev), z=sh.z.copy()))
+    return out
+
+
+def dint_wp_flow(solver="scipy", model_order=1, xtol=1e-8, M=2):
+    """tests/testDoubleIntegrator_WP.cpp:26-152 on the oracle."""
+    o = Oracle(MODEL_DINT)
+    sh = OracleShooting(o, M, solver, use_jac=bool(model_order))
+    sh.xtol = xtol
+    mode_t = [FIXED] + [FREE] * M
+    mode_x = np.zeros((M + 1, 6), dtype=np.int32)
+    mode_x[1:M, 3:6] = CONTINUOUS
+    sh.set_mode(mode_t, mode_x)
+    vt = np.array([60.0 * i / M for i in range(M + 1)])
+    vX = np.zeros((M + 1, 12))
+    for i in range(M + 1):
+        vX[i, 0] = 20.0 * i / M
+        if i < M:
+            vX[i, 6:] = 0.001
+    sh.init_nodes(vt, vX)
+    out = []
+    info = sh.solve()
+    out.append(dict(stage="solve", info=int(info), nfev=int(sh.nfev), njev=int(sh.njev), z=sh.z.copy()))
+    if M == 2:
+        vX2 = vX.copy()
+        vX2[1, 1], vX2[2, 1], vX2[2, 2] = 15.0, 5.0, 10.0
+        sh.set_desired(vt, vX2)
+        info = sh.solve_data(1.0)
+        out.append(dict(stage="data_continuation", info=int(info), nfev=int(sh.nfev), njev=int(sh.njev), z=sh.z.copy()))
+        if info == 1:
+            info = sh.solve_param(1.0, lambda v: o.m.p.__setitem__(2, v), 0.01, 0.02)
+        out.append(dict(stage="muT_continuation", info=int(info), nfev=int(sh.nfev), njev=int(sh.njev), z=sh.z.copy()))
+    return out

@@ -32,3 +32,15 @@ def test_golden_matches_survey_record():
     z2 = np.array(GOLD[1]["z"])
     p = np.array([-8.121947733, 7.775439382e-3, 0.7775438809, -0.4779369965, 5.715013318e-4, 5.715009222e-2, 9.958404873e-2])
     assert np.allclose(z2[7:14], p, rtol=1e-9, atol=0)
+
+
+def test_double_integrator_flows_match_survey_record(built):
+    """testDoubleIntegrator (nfev, njev) = (32,4), (14,1), (127,2); testDoubleIntegrator_WP first
+    solve ier = 4, then (60,5), (115,4) -- through scipy.fsolve, whose wrapper adds two calls."""
+    from flow_oracle import dint_basic_flow, dint_wp_flow
+    for solver in ("scipy", "socp"):
+        b = dint_basic_flow(solver, 1)
+        assert [(s["info"], s["nfev"] + 2, s["njev"]) for s in b] == [(1, 32, 4), (1, 14, 1), (1, 127, 2)]
+        w = dint_wp_flow(solver, 1)
+        assert w[0]["info"] == 4
+        assert [(s["info"], s["nfev"] + 2, s["njev"]) for s in w[1:]] == [(1, 60, 5), (1, 115, 4)]
