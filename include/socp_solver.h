@@ -58,6 +58,18 @@ const double *socp_hybr_x(const socp_hybr *s);
 const double *socp_hybr_fvec(const socp_hybr *s);
 double socp_hybr_epsfcn(const socp_hybr *s);
 
+/* ---- lock-step multi-start (BASELINE config 4; the sequential continuation loops of
+ * shooting.cpp:598-778 solve one problem at a time -- a sweep over P independent starts does not have to).
+ * P starts Z0[P][n] of the problem currently set on ctx (socp_problem_set); each start runs its own
+ * hybrd state machine with the reference's knobs; per round all residual requests are one
+ * socp_residual_batch_dev launch and all Jacobian requests one socp_fd_jacobian_multi_dev launch.
+ * Outputs per start: final iterate Zout[P][n], MINPACK info, nfev, |F| at the final iterate;
+ * rounds = number of launch rounds.  Host pointers. */
+struct socp_ctx;
+int socp_multistart_solve(struct socp_ctx *ctx, int P, const double *Z0, double xtol, int maxfev, double epsfcn,
+                          double factor, int dedup, double *Zout, int *info, int *nfev, double *fnorm,
+                          long long *rounds);
+
 #ifdef __cplusplus
 }
 #endif

@@ -80,6 +80,8 @@ def lib():
         L.socp_fd_rows_dev.argtypes = [_vp, C.c_int, _vp, C.c_double, _vp]
         L.socp_fd_rows.argtypes = [_vp, C.c_int, _dp, C.c_double, _dp]
         L.socp_fd_diff_dev.argtypes = [_vp, C.c_int, _vp, C.c_double, _vp, _vp]
+        L.socp_multistart_solve.argtypes = [_vp, C.c_int, _dp, C.c_double, C.c_int, C.c_double, C.c_double, C.c_int,
+                                            _dp, _ip, _ip, _dp, C.POINTER(C.c_longlong)]
         L.hybrd.argtypes = [FCN, _vp, C.c_int, _dp, _dp, C.c_double, C.c_int, C.c_int, C.c_int, C.c_double,
                             _dp, C.c_int, C.c_double, C.c_int, _ip, _dp, C.c_int, _dp, C.c_int, _dp,
                             _dp, _dp, _dp, _dp]
@@ -282,6 +284,20 @@ class Context:
     def fd_jacobian_multi_dev(self, np_, d_Z, d_Fvec, epsfcn, d_Fjac, dedup=False):
         self._chk(self.L.socp_fd_jacobian_multi_dev(self.h, int(np_), _vp(d_Z), _vp(d_Fvec), float(epsfcn),
                                                     _vp(d_Fjac), int(bool(dedup))))
+
+    def multistart_solve(self, Z0, xtol=1e-8, maxfev=10000, epsfcn=1e-15, factor=1.0, dedup=True):
+        """Lock-step hybrd solves of the rows of Z0.  Returns dict(z, info, nfev, fnorm, rounds)."""
+        Z0 = _f64(Z0).reshape(-1, self.n)
+        P = Z0.shape[0]
+        Z = np.empty_like(Z0)
+        info = np.zeros(P, dtype=np.int32)
+        nfev = np.zeros(P, dtype=np.int32)
+        fnorm = np.zeros(P)
+        rounds = C.c_longlong(0)
+        self._chk(self.L.socp_multistart_solve(self.h, P, _d(Z0), float(xtol), int(maxfev), float(epsfcn), float(factor),
+                                               int(bool(dedup)), _d(Z), info.ctypes.data_as(_ip),
+                                               nfev.ctypes.data_as(_ip), _d(fnorm), C.byref(rounds)))
+        return dict(z=Z, info=info, nfev=nfev, fnorm=fnorm, rounds=rounds.value)
 
     def fd_jacobian_dev(self, d_z, d_fvec, epsfcn, d_fjac, dedup=False):
         self._chk(self.L.socp_fd_jacobian_dev(self.h, _vp(d_z), _vp(d_fvec), float(epsfcn), _vp(d_fjac),

@@ -1,0 +1,128 @@
+// multistart.cpp -- lock-step Newton solves of many independent starts of ONE shooting problem
+// (BASELINE config 4): every start owns a resumable hybrd state machine
+// (minpack.cpp); per round all pending residual requests are ONE residual launch and all pending
+// Jacobian requests ONE forward-difference launch, instead of P serial host solvers each launching
+// 15-trajectory batches.  Each start follows exactly the iterates it would follow alone.
+#include "../../include/socp_hip.h"
+#include "../../include/socp_solver.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace {
+struct PinnedBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    bool reserve(size_t bytes)
+    {
+        if (bytes <= cap) return true;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return false;
+        cap = bytes;
+        return true;
+    }
+    ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+    double *d() const { return static_cast<double *>(p); }
+};
+struct DevBuf {
+    void *p = nullptr;
+    bool alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8) == hipSuccess; }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    double *d() const { return static_cast<double *>(p); }
+};
+}  // namespace
+
+extern "C" int socp_multistart_solve(socp_ctx *ctx, int P, const double *Z0, double xtol, int maxfev, double epsfcn,
+                                     double factor, int dedup, double *Zout, int *info, int *nfev, double *fnorm,
+                                     long long *rounds_out)
+{
+    if (!ctx || P < 0 || (P > 0 && (!Z0 || !Zout || !info))) return SOCP_ERR_ARG;
+    const int n = socp_problem_num_param(ctx);
+    if (n <= 0) return SOCP_ERR_ARG;
+    if (P == 0) return SOCP_OK;
+
+    std::vector<socp_hybr *> solver(P, nullptr);
+    for (int p = 0; p < P; p++) {
+        solver[p] = socp_hybr_create(n, xtol, maxfev, epsfcn, 1, factor, 0);
+        socp_hybr_start(solver[p], Z0 + (size_t)p * n, nullptr);
+    }
+    auto cleanup = [&]() { for (socp_hybr *s : solver) socp_hybr_destroy(s); };
+
+    const size_t rowB = sizeof(double) * n, jacB = rowB * n;
+    PinnedBuf hX, hF, hJx, hJf, hJ;
+    DevBuf dX, dF, dJx, dJf, dJ;
+    if (!hX.reserve(rowB * P) || !hF.reserve(rowB * P) || !hJx.reserve(rowB * P) || !hJf.reserve(rowB * P) || !hJ.reserve(jacB * P) ||
+        !dX.alloc(rowB * P) || !dF.alloc(rowB * P) || !dJx.alloc(rowB * P) || !dJf.alloc(rowB * P) || !dJ.alloc(jacB * P)) {
+        cleanup();
+        return SOCP_ERR_HIP;
+    }
+
+    std::vector<int> flag(P, 0), reqF, reqJ;
+    std::vector<double *> outF(P), outJ(P);
+    std::vector<char> active(P, 1);
+    long long rounds = 0;
+    int rc = SOCP_OK;
+    for (;;) {
+        reqF.clear(); reqJ.clear();
+        for (int p = 0; p < P; p++) {
+            if (!active[p]) continue;
+            const double *xe = nullptr;
+            double *out = nullptr;
+            const int req = socp_hybr_advance(solver[p], flag[p], &xe, &out);
+            flag[p] = 0;
+            if (req == SOCP_REQ_DONE) { active[p] = 0; continue; }
+            if (req == SOCP_REQ_FVEC) {
+                std::memcpy(hX.d() + (size_t)reqF.size() * n, xe, rowB);
+                outF[reqF.size()] = out;
+                reqF.push_back(p);
+            } else {
+                std::memcpy(hJx.d() + (size_t)reqJ.size() * n, xe, rowB);
+                std::memcpy(hJf.d() + (size_t)reqJ.size() * n, socp_hybr_fvec(solver[p]), rowB);
+                outJ[reqJ.size()] = out;
+                reqJ.push_back(p);
+            }
+        }
+        if (reqF.empty() && reqJ.empty()) break;
+        rounds++;
+        const int kF = (int)reqF.size(), kJ = (int)reqJ.size();
+        // both launches are enqueued before either result is awaited
+        if (kF) {
+            if (hipMemcpy(dX.p, hX.p, rowB * kF, hipMemcpyHostToDevice) != hipSuccess) { rc = SOCP_ERR_HIP; break; }
+            if ((rc = socp_residual_batch_dev(ctx, kF, dX.d(), dF.d())) != SOCP_OK) break;
+        }
+        if (kJ) {
+            if (hipMemcpy(dJx.p, hJx.p, rowB * kJ, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(dJf.p, hJf.p, rowB * kJ, hipMemcpyHostToDevice) != hipSuccess) { rc = SOCP_ERR_HIP; break; }
+            if ((rc = socp_fd_jacobian_multi_dev(ctx, kJ, dJx.d(), dJf.d(), epsfcn, dJ.d(), dedup)) != SOCP_OK) break;
+        }
+        if ((rc = socp_ctx_synchronize(ctx)) != SOCP_OK) break;
+        if (kF) {
+            if (hipMemcpy(hF.p, dF.p, rowB * kF, hipMemcpyDeviceToHost) != hipSuccess) { rc = SOCP_ERR_HIP; break; }
+            for (int k = 0; k < kF; k++) std::memcpy(outF[k], hF.d() + (size_t)k * n, rowB);
+        }
+        if (kJ) {
+            if (hipMemcpy(hJ.p, dJ.p, jacB * kJ, hipMemcpyDeviceToHost) != hipSuccess) { rc = SOCP_ERR_HIP; break; }
+            for (int k = 0; k < kJ; k++) std::memcpy(outJ[k], hJ.d() + (size_t)k * n * n, jacB);
+        }
+    }
+    if (rc == SOCP_OK) {
+        for (int p = 0; p < P; p++) {
+            std::memcpy(Zout + (size_t)p * n, socp_hybr_x(solver[p]), rowB);
+            info[p] = socp_hybr_info(solver[p]);
+            if (nfev) nfev[p] = socp_hybr_nfev(solver[p]);
+            if (fnorm) {
+                const double *f = socp_hybr_fvec(solver[p]);
+                double s = 0;
+                for (int i = 0; i < n; i++) s += f[i] * f[i];
+                fnorm[p] = std::sqrt(s);
+            }
+        }
+    }
+    if (rounds_out) *rounds_out = rounds;
+    cleanup();
+    return rc;
+}

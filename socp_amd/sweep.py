@@ -1,0 +1,130 @@
+"""Multi-start sweep (BASELINE config 4): P independent initial-costate starts of one shooting problem,
+sharded over the ranks of a torch.distributed job -- one process per GPU -- solved locally in lock-step
+(socp_multistart_solve) with NO data-path collective, then ONE small all_gather of the per-start
+records {z*[n], |F|, info, nfev} (RCCL over xGMI when the backend is nccl; n = 14 -> 136 B per start).
+
+    python -m torch.distributed.run --nproc-per-node N -m socp_amd.sweep --starts 4096 --rk4-steps 10000
+
+Rank r owns the contiguous block of starts [r*P/W, (r+1)*P/W): the gathered table is in start order.
+"""
+import argparse
+import json
+import os
+import time
+
+import numpy as np
+
+X0_STATE = np.array([0.999949994, 1e-4, 0.01, 1e-10, 1e-10, 1e-10, 1.0])          # testGoddard.cpp:53-59
+PSTAR = np.array([-8.121947733, 7.775439382e-3, 0.7775438809, -0.4779369965, 5.715013318e-4,
+                  5.715009222e-2, 9.958404873e-2])
+TF = 0.2640825
+GODDARD_PARAMS = [3.5, 7.0, 310.0, 500.0, 1.0, 1.0, 1.0, -1.0]
+
+
+def goddard_starts(P, eps, seed=20250905):
+    """p = p*(1 + eps*xi), xi ~ U(-1,1); the SAME table on every rank (seeded), sliced by shard()."""
+    rng = np.random.Generator(np.random.MT19937(seed))
+    xi = rng.uniform(-1.0, 1.0, size=(P, 7))
+    Z = np.empty((P, 14))
+    Z[:, :7] = X0_STATE
+    Z[:, 7:] = PSTAR * (1.0 + eps * xi)
+    return Z
+
+
+def shard(P, rank, world):
+    """Contiguous block of rank `rank`: sizes differ by at most one."""
+    base, rem = divmod(P, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def goddard_single_shooting_problem(ctx, tf=TF):
+    """BASELINE config 2/4 problem: n = 14, fixed tf, final velocity and mass free."""
+    from . import capi
+    mode_x = np.zeros((2, 7), dtype=np.int32)
+    mode_x[1, 3:7] = capi.FREE
+    X = np.zeros((2, 14))
+    X[0, :7] = X0_STATE
+    X[1, 0] = 1.01
+    return ctx.problem_set([capi.FIXED, capi.FIXED], mode_x, np.array([0.0, tf]), X)
+
+
+def run_sweep(Z0, solve_local, dist=None, device=None):
+    """Shard the rows of Z0 over the ranks, solve, gather.  `solve_local(Zblock)` returns a dict with
+    z [k][n], info [k], nfev [k], fnorm [k].  Returns (table [P][n+3] in start order, local dict)."""
+    import torch
+    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    P, n = Z0.shape
+    lo, hi = shard(P, rank, world)
+    local = solve_local(Z0[lo:hi])
+    rec = np.concatenate([local["z"], local["fnorm"][:, None], local["info"][:, None].astype(float),
+                          local["nfev"][:, None].astype(float)], axis=1)
+    if world == 1:
+        return rec, local
+    # equal-size records for all_gather: pad the short shards by one row
+    kmax = max(shard(P, r, world)[1] - shard(P, r, world)[0] for r in range(world))
+    buf = torch.zeros((kmax, n + 3), dtype=torch.float64, device=device or "cpu")
+    buf[:hi - lo] = torch.from_numpy(rec).to(buf.device)
+    parts = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(parts, buf)
+    table = np.concatenate([parts[r].cpu().numpy()[:shard(P, r, world)[1] - shard(P, r, world)[0]] for r in range(world)])
+    return table, local
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--starts", type=int, default=4096)
+    ap.add_argument("--eps", type=float, default=1e-3)
+    ap.add_argument("--rk4-steps", type=int, default=10000)
+    ap.add_argument("--xtol", type=float, default=1e-8)
+    ap.add_argument("--variant", choices=["exact", "fast"], default="fast")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from . import capi
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    ctx = capi.Context(capi.MODEL_GODDARD, device=local_rank)
+    ctx.set_params(GODDARD_PARAMS)
+    ctx.set_step_number(args.rk4_steps)
+    ctx.set_variant(capi.VARIANT_LANE_FAST if args.variant == "fast" else capi.VARIANT_LANE_EXACT)
+    goddard_single_shooting_problem(ctx)
+    Z0 = goddard_starts(args.starts, args.eps)
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    table, local = run_sweep(Z0, lambda Zb: ctx.multistart_solve(Zb, xtol=args.xtol), dist if world > 1 else None, dev)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    traj = torch.tensor([float(ctx.counters()[0])], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(traj)
+    if rank == 0:
+        info = table[:, -2].astype(int)
+        print(json.dumps({"sweep": "goddard_single_shooting_n14", "starts": args.starts, "eps": args.eps, "n_gpus": world,
+                          "rk4_steps": args.rk4_steps, "variant": args.variant, "xtol": args.xtol, "wall_s": wall,
+                          "converged": int(np.sum(info == 1)), "info_histogram": {str(k): int(np.sum(info == k)) for k in np.unique(info)},
+                          "trajectories": int(traj.item()), "trajectories_per_s": traj.item() / wall,
+                          "solves_per_s": args.starts / wall, "rounds_rank0": int(local["rounds"]),
+                          "mean_nfev": float(np.mean(table[:, -1]))}), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

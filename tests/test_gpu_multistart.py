@@ -1,0 +1,43 @@
+"""GPU: lock-step multi-start solver -- every start must follow exactly the iterates it follows alone."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_lockstep_equals_one_by_one():
+    from socp_amd import capi, sweep
+    ctx = capi.Context(capi.MODEL_GODDARD)
+    ctx.set_params(sweep.GODDARD_PARAMS)
+    ctx.set_step_number(50)
+    assert sweep.goddard_single_shooting_problem(ctx) == 14
+    Z0 = sweep.goddard_starts(37, 1e-3)
+    Z0[5, 7:] *= 1.5                      # far outside the basin: must fail without disturbing others
+    batch = ctx.multistart_solve(Z0, xtol=1e-8)
+    assert batch["rounds"] > 0
+    for p in (0, 5, 17, 36):
+        def fd(x, fvec, eps):
+            return ctx.fd_jacobian(x, fvec, epsfcn=eps, dedup=True)
+        alone = capi.hybrd(lambda v: ctx.residual(v), Z0[p], xtol=1e-8, epsfcn=1e-15, fdjac=fd)
+        assert alone["info"] == batch["info"][p] and alone["nfev"] == batch["nfev"][p]
+        assert np.array_equal(alone["x"], batch["z"][p])
+    ok = batch["info"] == 1
+    assert ok.sum() >= 35 and batch["info"][5] != 1
+    assert np.all(batch["fnorm"][ok] < 1e-6)
+    # converged starts agree on the solution (one BVP, one root in the basin)
+    zs = batch["z"][ok]
+    assert np.max(np.abs(zs - zs[0])) <= 1e-6 * np.max(np.abs(zs[0]))
+    ctx.close()
+
+
+def test_sweep_single_process_on_gpu():
+    from socp_amd import capi, sweep
+    ctx = capi.Context(capi.MODEL_GODDARD)
+    ctx.set_params(sweep.GODDARD_PARAMS)
+    ctx.set_step_number(20)
+    ctx.set_variant(capi.VARIANT_LANE_FAST)
+    sweep.goddard_single_shooting_problem(ctx)
+    Z0 = sweep.goddard_starts(64, 1e-3)
+    table, local = sweep.run_sweep(Z0, lambda Zb: ctx.multistart_solve(Zb, xtol=1e-8))
+    assert table.shape == (64, 17) and np.all(table[:, -2] == 1)
+    ctx.close()
