@@ -119,7 +119,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--starts", type=int, default=8192, help="independent shooting problems per GPU")
     ap.add_argument("--rk4-steps", type=int, default=10000)
-    ap.add_argument("--variant", choices=["exact", "fast"], default="exact")
+    ap.add_argument("--variant", choices=["exact", "fast"], default="fast",
+                    help="fast: restructured arithmetic (<= 1e-8 vs the reference order after 1e4 steps, converged "
+                         "solutions within 1e-8: tests/test_gpu_parity.py, test_host_flow.py); exact: reference operation order")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="0 disables the CPU baseline leg")
     ap.add_argument("--single-problem", action="store_true",
                     help="also time ONE problem (15 trajectories) per launch: the latency-bound case")

@@ -100,6 +100,7 @@ def main():
     ctx.set_variant(capi.VARIANT_LANE_FAST if args.variant == "fast" else capi.VARIANT_LANE_EXACT)
     goddard_single_shooting_problem(ctx)
     Z0 = goddard_starts(args.starts, args.eps)
+    n_unknown = Z0.shape[1]
 
     if world > 1:
         dist.barrier()
@@ -115,7 +116,10 @@ def main():
         dist.all_reduce(traj)
     if rank == 0:
         info = table[:, -2].astype(int)
-        print(json.dumps({"sweep": "goddard_single_shooting_n14", "starts": args.starts, "eps": args.eps, "n_gpus": world,
+        conv = table[info == 1, :n_unknown]
+        spread = float(np.max(np.abs(conv - np.median(conv, axis=0))) / np.max(np.abs(conv))) if len(conv) else None
+        print(json.dumps({"solution_spread_rel": spread, "max_fnorm_converged": float(np.max(table[info == 1, -3])) if len(conv) else None,
+                          "sweep": "goddard_single_shooting_n14", "starts": args.starts, "eps": args.eps, "n_gpus": world,
                           "rk4_steps": args.rk4_steps, "variant": args.variant, "xtol": args.xtol, "wall_s": wall,
                           "converged": int(np.sum(info == 1)), "info_histogram": {str(k): int(np.sum(info == k)) for k in np.unique(info)},
                           "trajectories": int(traj.item()), "trajectories_per_s": traj.item() / wall,

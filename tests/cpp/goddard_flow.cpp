@@ -3,7 +3,7 @@
 // {stage, info, nfev, n, trajectories, z[...]} instead of "OK = info".
 //
 //   goddard_flow full  <stepNbr> <dedup> <xtol> [tracefile]      whole flow from the trivial guess
-//   goddard_flow stage <k> <stepNbr> <dedup> <xtol> <zfile>      ONE solve (k = 1..4) started from the
+//   goddard_flow stage <k> <stepNbr> <dedup> <xtol> <zfile> [tracefile]   ONE solve (k = 1..4) started from the
 //                       85 unknowns in <zfile> (node states + tf), the state testGoddard.cpp is in
 //                       just before its k-th SolveOCP call
 // Run by tests/test_host_flow.py on the GPU box; expected solutions are in tests/golden/.
@@ -76,7 +76,8 @@ int main(int argc, char **argv)
     const double xtol = std::atof(argv[a + 2]);
     const std::string extra = argc > a + 3 ? argv[a + 3] : "";
 
-    goddard my_goddard(single ? std::string("") : extra, stepNbr);
+    const std::string trace = single ? (argc > a + 4 ? argv[a + 4] : "") : extra;
+    goddard my_goddard(trace, stepNbr);
     const int dim = my_goddard.GetDim();
     my_goddard.SetParameterDataName("mu2", 1.0);
     shooting my_shooting(my_goddard, kMulti, 1);
@@ -100,7 +101,7 @@ int main(int argc, char **argv)
         if (info == 1) { info = my_shooting.SolveOCP(1.0, "KD", 310.0); report("drag_continuation", info, my_shooting); }
         if (info == 1) { info = my_shooting.SolveOCP(1.0, "mu2", 0.2); report("mu2_continuation", info, my_shooting); }
         if (info == 1) { info = singular_stage(my_goddard, my_shooting, dim); report("singular_arc", info, my_shooting); }
-        if (info == 1 && !extra.empty()) my_shooting.Trace();
+        if (info == 1 && !trace.empty()) my_shooting.Trace();
         return info == 1 ? 0 : 2;
     }
 
@@ -124,5 +125,6 @@ int main(int argc, char **argv)
     case 4: my_goddard.SetParameterDataName("mu2", 0.2); info = singular_stage(my_goddard, my_shooting, dim); report("singular_arc", info, my_shooting); break;
     default: return 64;
     }
+    if (info == 1 && !trace.empty()) my_shooting.Trace();
     return info == 1 ? 0 : 2;
 }

@@ -89,3 +89,31 @@ def test_dedup_integrates_fewer_trajectories(tmp_path):
     assert full[0]["info"] == ded[0]["info"] == 1
     assert full[0]["z"] == ded[0]["z"] and full[0]["nfev"] == ded[0]["nfev"]      # bit-identical solve
     assert ded[0]["trajectories"] < 0.5 * full[0]["trajectories"]
+
+
+def test_trace_replay(tmp_path):
+    """shooting::Trace (shooting.cpp:496-544): t, X[0..14), u[3], H, switching function per row, one
+    row per RK4 step plus the segment's first row (goddard.cpp:320-340) -- 6 segments x 11 rows.  Values
+    are checked against the oracle along the stored solution."""
+    from oracle.oracle import Oracle, MODEL_GODDARD
+    trace = tmp_path / "trace.dat"
+    g = SINGLE[(4, 1e-6)]
+    # full flow may stop early on the chaotic first solve; replay the last stage from its golden start
+    zf = tmp_path / "z.txt"
+    zf.write_text(" ".join(repr(v) for v in SINGLE[(3, 1e-6)]["init_z"]))
+    exe = os.path.join(BIN, "goddard_flow")
+    out = subprocess.run([exe, "stage", 3, 10, 1, 1e-6, str(zf), str(trace)], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, SOCP_VARIANT="exact"))
+    assert out.returncode == 0, out.stderr
+    rows = np.loadtxt(trace)
+    assert rows.shape == (66, 20)
+    o = Oracle(MODEL_GODDARD, step_nbr=10)
+    o.set_param("mu2", 0.2)
+    for r in rows[::7]:
+        t, X, u, H, sw = r[0], r[1:15], r[15:18], r[18], r[19]
+        assert np.allclose(u, o.control(t, X), rtol=1e-5, atol=1e-9)        # text output has 6 significant digits
+        assert abs(H - o.hamiltonian(t, X)[0]) <= 1e-4 * max(1.0, abs(H))
+        assert abs(sw - (1.0 - 7.0 * X[13] - 3.5 / X[6] * np.linalg.norm(X[10:13]))) <= 1e-4
+    # rows of one segment are consecutive RK4 steps: time increases by (t_{i+1} - t_i)/10
+    seg = rows[:11, 0]
+    assert np.allclose(np.diff(seg), (seg[-1] - seg[0]) / 10, rtol=1e-4)
