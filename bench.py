@@ -123,6 +123,9 @@ def main():
                     help="fast: restructured arithmetic (<= 1e-8 vs the reference order after 1e4 steps, converged "
                          "solutions within 1e-8: tests/test_gpu_parity.py, test_host_flow.py); exact: reference operation order")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="0 disables the CPU baseline leg")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo + --share-device0: rehearse the multi-rank path on a one-GPU box (collectives on CPU tensors)")
+    ap.add_argument("--share-device0", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--single-problem", action="store_true",
                     help="also time ONE problem (15 trajectories) per launch: the latency-bound case")
     args = ap.parse_args()
@@ -136,11 +139,20 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        if args.share_device0:
+            local_rank = 0
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    if args.share_device0:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")      # where collective buffers live
 
     ctx = setup_context(local_rank, args.rk4_steps, args.variant)
     stream = torch.cuda.Stream(device=dev)   # a real (non-default) HIP stream owned by torch
@@ -177,7 +189,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
 
-    t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t_max = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
     elapsed_max = float(t_max.item())
@@ -189,7 +201,7 @@ def main():
     # multi-start sweep is this small gather of per-rank records -- after the timed region.
     finite = int(torch.isfinite(d_J).all(dim=(1, 2)).sum().item())
     rec = torch.tensor([float(rank), float(finite), float(torch.nan_to_num(d_J).abs().sum().item())],
-                       dtype=torch.float64, device=dev)
+                       dtype=torch.float64, device=cdev)
     if world > 1:
         gathered = [torch.empty_like(rec) for _ in range(world)]
         dist.all_gather(gathered, rec)
