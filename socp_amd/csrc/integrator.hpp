@@ -21,23 +21,43 @@ struct Lane {
     __device__ static __forceinline__ void rk4(const ModelParams &P, double sw0, double sw1,
                                               double t, double (&X)[S], double step)
     {
-        double F1[S], Fs[S], F[S], Y[S];
-        const double h2 = step / 2.0;
-        const double th = t + step / 2.0;
-        Mdl::rhs(P, sw0, sw1, t, X, F1);
+        if constexpr (Mdl::kRefOrder) {
+            double F1[S], Fs[S], F[S], Y[S];
+            const double h2 = step / 2.0;
+            const double th = t + step / 2.0;
+            Mdl::rhs(P, sw0, sw1, t, X, F1);
 #pragma unroll
-        for (int i = 0; i < S; i++) Y[i] = X[i] + h2 * F1[i];
-        Mdl::rhs(P, sw0, sw1, th, Y, Fs);                 // F2
+            for (int i = 0; i < S; i++) Y[i] = X[i] + h2 * F1[i];
+            Mdl::rhs(P, sw0, sw1, th, Y, Fs);                 // F2
 #pragma unroll
-        for (int i = 0; i < S; i++) Y[i] = X[i] + h2 * Fs[i];
-        Mdl::rhs(P, sw0, sw1, th, Y, F);                  // F3
+            for (int i = 0; i < S; i++) Y[i] = X[i] + h2 * Fs[i];
+            Mdl::rhs(P, sw0, sw1, th, Y, F);                  // F3
 #pragma unroll
-        for (int i = 0; i < S; i++) { Y[i] = X[i] + step * F[i]; Fs[i] = Fs[i] + F[i]; }   // F2 + F3
-        Mdl::rhs(P, sw0, sw1, t + step, Y, F);            // F4
-        // reference order divides by 6.0; the throughput flavour multiplies by the rounded 1/6
-        const double h6 = Mdl::kRefOrder ? step / 6.0 : step * (1.0 / 6.0);
+            for (int i = 0; i < S; i++) { Y[i] = X[i] + step * F[i]; Fs[i] = Fs[i] + F[i]; }   // F2 + F3
+            Mdl::rhs(P, sw0, sw1, t + step, Y, F);            // F4
+            const double h6 = step / 6.0;
 #pragma unroll
-        for (int i = 0; i < S; i++) X[i] = X[i] + h6 * (F1[i] + (F[i] + 2.0 * Fs[i]));
+            for (int i = 0; i < S; i++) X[i] = X[i] + h6 * (F1[i] + (F[i] + 2.0 * Fs[i]));
+        } else {
+            // throughput flavour: running sum acc = F1 + 2 F2 + 2 F3 (+ F4) instead of keeping F1 and
+            // F2+F3 alive -- 14 fewer live doubles, which is what lets three waves share a SIMD
+            double A[S], F[S], Y[S];
+            const double h2 = 0.5 * step;
+            const double th = t + h2;
+            Mdl::rhs(P, sw0, sw1, t, X, A);
+#pragma unroll
+            for (int i = 0; i < S; i++) Y[i] = X[i] + h2 * A[i];
+            Mdl::rhs(P, sw0, sw1, th, Y, F);
+#pragma unroll
+            for (int i = 0; i < S; i++) { Y[i] = X[i] + h2 * F[i]; A[i] = A[i] + 2.0 * F[i]; }
+            Mdl::rhs(P, sw0, sw1, th, Y, F);
+#pragma unroll
+            for (int i = 0; i < S; i++) { Y[i] = X[i] + step * F[i]; A[i] = A[i] + 2.0 * F[i]; }
+            Mdl::rhs(P, sw0, sw1, t + step, Y, F);
+            const double h6 = step * (1.0 / 6.0);
+#pragma unroll
+            for (int i = 0; i < S; i++) X[i] = X[i] + h6 * (A[i] + F[i]);
+        }
     }
 
     // model.hpp:395-414 / goddard.cpp:298-317 (dt) + odeTools.cpp:128-146 (loop): t is
@@ -62,8 +82,11 @@ struct Lane {
 // consecutive lanes on consecutive doubles (coalesced) and transposed through LDS so that each
 // lane ends up with its own row in registers.
 // ---------------------------------------------------------------------------------------------
-template <class Mdl>
-__global__ __launch_bounds__(64) void traj_lane_kernel(ModelParams P, int B,
+// WPE = cap on waves per SIMD (amdgpu_waves_per_eu max): the launcher picks ceil(waves / 1024) so that a
+// grid smaller than the chip is spread one (or two) waves per SIMD instead of being packed three deep on
+// a fraction of the SIMDs (launch_impl.hpp).
+template <class Mdl, int WPE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, WPE))) void traj_lane_kernel(ModelParams P, int B,
                                                        const double *__restrict__ t0,
                                                        const double *__restrict__ tf,
                                                        const double *__restrict__ sw,
@@ -211,8 +234,8 @@ __device__ __forceinline__ void segment_residual(const ModelParams &P, const Pro
 }
 
 // K_res: Z[B][n] -> F[B][n]; trajectory index T = row*M + segment.
-template <class Mdl>
-__global__ __launch_bounds__(64, 2) void residual_lane_kernel(ModelParams P, ProblemDev pb, int B,
+template <class Mdl, int WPE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, WPE))) void residual_lane_kernel(ModelParams P, ProblemDev pb, int B,
                                                               const double *__restrict__ Z,
                                                               double *__restrict__ F)
 {
@@ -237,8 +260,8 @@ __device__ __forceinline__ double fd_step(double zj, double eps)
 // integrate; the unknown vector of column j is z with z_j + h_j generated on the fly, so the
 // perturbation matrix never exists in HBM: reads are z[n] and fvec[n] per problem (cache
 // resident), writes are the Jacobian entries fjac[row + n*j] = (F_j[row] - fvec[row]) / h_j.
-template <class Mdl>
-__global__ __launch_bounds__(64, 2) void fdjac_lane_kernel(ModelParams P, ProblemDev pb, int np, int T,
+template <class Mdl, int WPE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, WPE))) void fdjac_lane_kernel(ModelParams P, ProblemDev pb, int np, int T,
                                                            const int2 *__restrict__ pairs,
                                                            const double *__restrict__ Zb,
                                                            const double *__restrict__ Fvec,
@@ -261,8 +284,8 @@ __global__ __launch_bounds__(64, 2) void fdjac_lane_kernel(ModelParams P, Proble
 // K_fdr: the (n+1) residual rows of a forward-difference Jacobian -- row 0 at z, row j+1 at
 // z + h_j e_j -- for `np` problems in ONE launch (no dependency between base and perturbed
 // trajectories).  Rows[np][n+1][n]; the perturbation matrix is generated on the fly.
-template <class Mdl>
-__global__ __launch_bounds__(64, 2) void fdrows_lane_kernel(ModelParams P, ProblemDev pb, int np,
+template <class Mdl, int WPE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, WPE))) void fdrows_lane_kernel(ModelParams P, ProblemDev pb, int np,
                                                             const double *__restrict__ Zb, double eps,
                                                             double *__restrict__ Rows)
 {

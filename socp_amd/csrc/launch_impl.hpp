@@ -10,15 +10,46 @@ namespace socp {
 
 static inline unsigned blocks_for(long n) { return (unsigned)((n + 63) / 64); }
 
+// Fill-the-chip placement.  Workgroups here are single waves that keep their trajectory in registers for
+// milliseconds.  The dispatcher packs them as deep as registers allow (3 per SIMD at <= 168 VGPRs) and a CU
+// does not balance single-wave workgroups over its 4 SIMDs, so a grid of W < 3072 waves would time-slice
+// three waves on some SIMDs while others idle (measured: 960 waves took 2x, 1920 waves 3x the single-wave
+// time).  Every hot kernel is therefore instantiated with an occupancy cap WPE in {1,2,3}
+// (amdgpu_waves_per_eu) and the launcher picks WPE = ceil(W / 1024 SIMDs): up to 1024 waves run one per
+// SIMD, up to 2048 two per SIMD, beyond that three.
+constexpr int kNumSIMD = 1024;
+
+static inline int wpe_for(long waves)
+{
+    const long k = (waves + kNumSIMD - 1) / kNumSIMD;
+    return k < 1 ? 1 : (k > 3 ? 3 : (int)k);
+}
+
+#define SOCP_LAUNCH_MDL(KERNEL, MDL, WAVES, GRID, ST, ...)                                               \
+    do {                                                                                                \
+        switch (wpe_for(WAVES)) {                                                                       \
+        case 1: hipLaunchKernelGGL((KERNEL<MDL, 1>), dim3(GRID), dim3(64), 0, ST, __VA_ARGS__); break;  \
+        case 2: hipLaunchKernelGGL((KERNEL<MDL, 2>), dim3(GRID), dim3(64), 0, ST, __VA_ARGS__); break;  \
+        default: hipLaunchKernelGGL((KERNEL<MDL, 3>), dim3(GRID), dim3(64), 0, ST, __VA_ARGS__); break; \
+        }                                                                                               \
+    } while (0)
+
 // model_id 1 = Goddard (smooth-law specialisation when mu2 > 0, parameter slot 6), 2 = double integrator
-#define SOCP_DISPATCH(KERNEL, GRID, ST, ...)                                                        \
-    do {                                                                                            \
-        if (model_id == 1 && P.p[6] > 0)                                                            \
-            hipLaunchKernelGGL(KERNEL<SOCP_GODDARD_SMOOTH>, dim3(GRID), dim3(64), 0, ST, __VA_ARGS__); \
-        else if (model_id == 1)                                                                     \
-            hipLaunchKernelGGL(KERNEL<SOCP_GODDARD>, dim3(GRID), dim3(64), 0, ST, __VA_ARGS__);        \
-        else                                                                                        \
-            hipLaunchKernelGGL(KERNEL<SOCP_DINT>, dim3(GRID), dim3(64), 0, ST, __VA_ARGS__);           \
+#define SOCP_DISPATCH_HOT(KERNEL, GRID, ST, ...)                                                        \
+    do {                                                                                                \
+        if (model_id == 1 && P.p[6] > 0) SOCP_LAUNCH_MDL(KERNEL, SOCP_GODDARD_SMOOTH, GRID, GRID, ST, __VA_ARGS__); \
+        else if (model_id == 1) SOCP_LAUNCH_MDL(KERNEL, SOCP_GODDARD, GRID, GRID, ST, __VA_ARGS__);     \
+        else SOCP_LAUNCH_MDL(KERNEL, SOCP_DINT, GRID, GRID, ST, __VA_ARGS__);                           \
+    } while (0)
+
+#define SOCP_DISPATCH(KERNEL, GRID, ST, ...)                                                            \
+    do {                                                                                                \
+        if (model_id == 1 && P.p[6] > 0)                                                                \
+            hipLaunchKernelGGL(KERNEL<SOCP_GODDARD_SMOOTH>, dim3(GRID), dim3(64), 0, ST, __VA_ARGS__);  \
+        else if (model_id == 1)                                                                         \
+            hipLaunchKernelGGL(KERNEL<SOCP_GODDARD>, dim3(GRID), dim3(64), 0, ST, __VA_ARGS__);         \
+        else                                                                                            \
+            hipLaunchKernelGGL(KERNEL<SOCP_DINT>, dim3(GRID), dim3(64), 0, ST, __VA_ARGS__);            \
     } while (0)
 
 hipError_t SOCP_CAT(traj_, SOCP_FLAVOUR)(int model_id, hipStream_t st, const ModelParams &P, int B,
@@ -26,7 +57,7 @@ hipError_t SOCP_CAT(traj_, SOCP_FLAVOUR)(int model_id, hipStream_t st, const Mod
                                          const double *X0, double *Xf)
 {
     if (B <= 0) return hipSuccess;
-    SOCP_DISPATCH(traj_lane_kernel, blocks_for(B), st, P, B, t0, tf, sw, X0, Xf);
+    SOCP_DISPATCH_HOT(traj_lane_kernel, blocks_for(B), st, P, B, t0, tf, sw, X0, Xf);
     return hipGetLastError();
 }
 
@@ -35,7 +66,7 @@ hipError_t SOCP_CAT(residual_, SOCP_FLAVOUR)(int model_id, hipStream_t st, const
 {
     if (B <= 0) return hipSuccess;
     const long T = (long)B * pb.M;
-    SOCP_DISPATCH(residual_lane_kernel, blocks_for(T), st, P, pb, B, Z, F);
+    SOCP_DISPATCH_HOT(residual_lane_kernel, blocks_for(T), st, P, pb, B, Z, F);
     return hipGetLastError();
 }
 
@@ -45,7 +76,7 @@ hipError_t SOCP_CAT(fdjac_, SOCP_FLAVOUR)(int model_id, hipStream_t st, const Mo
 {
     if (T <= 0 || np <= 0) return hipSuccess;
     const long total = (long)np * T;
-    SOCP_DISPATCH(fdjac_lane_kernel, blocks_for(total), st, P, pb, np, T, pairs, z, fvec, eps, fjac);
+    SOCP_DISPATCH_HOT(fdjac_lane_kernel, blocks_for(total), st, P, pb, np, T, pairs, z, fvec, eps, fjac);
     return hipGetLastError();
 }
 
@@ -54,7 +85,7 @@ hipError_t SOCP_CAT(fdrows_, SOCP_FLAVOUR)(int model_id, hipStream_t st, const M
 {
     if (np <= 0) return hipSuccess;
     const long total = (long)np * (pb.n + 1) * pb.M;
-    SOCP_DISPATCH(fdrows_lane_kernel, blocks_for(total), st, P, pb, np, z, eps, rows);
+    SOCP_DISPATCH_HOT(fdrows_lane_kernel, blocks_for(total), st, P, pb, np, z, eps, rows);
     return hipGetLastError();
 }
 
