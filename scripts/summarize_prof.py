@@ -18,7 +18,8 @@ import sys
 
 def counters(d, kernel):
     out = collections.defaultdict(list)
-    for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+    files = sorted(glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True), key=os.path.getmtime)
+    for f in files[-1:]:                 # the most recent run only
         for r in csv.DictReader(open(f)):
             if kernel in r["Kernel_Name"] and float(r["Grid_Size"]) > 4096:
                 out[r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -32,7 +33,8 @@ def main():
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
     os.makedirs(root, exist_ok=True)
     lines = []
-    for f in glob.glob(os.path.join(stats_dir, "**", "*_kernel_stats.csv"), recursive=True):
+    stats = sorted(glob.glob(os.path.join(stats_dir, "**", "*_kernel_stats.csv"), recursive=True), key=os.path.getmtime)
+    for f in stats[-1:]:
         for i, r in enumerate(csv.reader(open(f))):
             if i == 0 or "socp::" in r[0]:
                 lines.append(",".join('"%s"' % c if i and j == 0 else c for j, c in enumerate(r)))
