@@ -33,11 +33,13 @@ extern "C" {
 /* in-tree device dynamics (twins of src/models/goddard, src/models/doubleIntegrator) */
 #define SOCP_MODEL_GODDARD            1   /* dim 7, goddard.cpp:48-295 */
 #define SOCP_MODEL_DOUBLE_INTEGRATOR  2   /* dim 6, doubleIntegrator.cpp:49-300 */
+#define SOCP_MODEL_COVID19            3   /* dim 4, covid19.cpp:53-165 (control dimension 1) */
 
 /* packed parameter block, refreshed before every Newton solve (parameters are mutated by the
  * continuation loop through a raw real&, shooting.cpp:695-707) */
 #define SOCP_GODDARD_NPARAMS 8   /* C, b, KD, kr, u_max, mu1, mu2, singularControl (goddard.hpp:28-37) */
 #define SOCP_DINT_NPARAMS    3   /* u_max, a_max, muT (doubleIntegrator.hpp:24-28) */
+#define SOCP_COVID_NPARAMS   8   /* R0, Tinf, Tinc, N, Imax, muI, umin, umax (covid19.hpp parameters_struct) */
 
 /* time / state modes, model.hpp:34-38 */
 #define SOCP_FIXED      0
@@ -52,7 +54,7 @@ extern "C" {
 
 /* what socp_eval_batch computes */
 #define SOCP_EVAL_RHS         0   /* odeTools.hpp:82  Model(t, X, isJac)      -> len(X) values  */
-#define SOCP_EVAL_CONTROL     1   /* model.hpp:375    Control(t, X)           -> 3 values       */
+#define SOCP_EVAL_CONTROL     1   /* model.hpp:375    Control(t, X)           -> control dim (3, 3, 1) */
 #define SOCP_EVAL_HAMILTONIAN 2   /* model.hpp:384    Hamiltonian(t, X, 0)    -> 1 value        */
 
 typedef struct socp_ctx socp_ctx;
@@ -67,6 +69,13 @@ const char *socp_last_error(const socp_ctx *ctx);   /* ctx may be NULL: last cre
 int socp_ctx_set_params(socp_ctx *ctx, const double *params, int nparams);
 int socp_ctx_get_params(const socp_ctx *ctx, double *params, int nparams);
 int socp_ctx_set_step_number(socp_ctx *ctx, int step_nbr);      /* model::stepNbr, model.hpp:367 */
+/* integrator of every later call: SOCP_INT_RK4 = the reference's default fixed-step loop
+ * (odeTools.cpp:135-145); SOCP_INT_DOPRI5 = what it runs when built with -D_USE_BOOST (odeTools.cpp:129-134),
+ * abs = rel tolerance `tol` = odeTools::odeIntTol (set from the solver's xtol by shooting::SetPrecision,
+ * shooting.cpp:447-450); initial step (tf - t0)/stepNbr.  Per-lane step control; reference-order RHS. */
+#define SOCP_INT_RK4    0
+#define SOCP_INT_DOPRI5 1
+int socp_ctx_set_integrator(socp_ctx *ctx, int kind, double tol);
 int socp_ctx_set_switching_times(socp_ctx *ctx, const double *sw, int nsw);  /* goddard.cpp:373-377 */
 int socp_ctx_set_variant(socp_ctx *ctx, int variant);
 /* enqueue on the caller's hipStream_t (NULL is the device's default stream); use_own != 0 switches
@@ -74,6 +83,7 @@ int socp_ctx_set_variant(socp_ctx *ctx, int variant);
 int socp_ctx_set_stream(socp_ctx *ctx, void *hip_stream, int use_own);
 int socp_ctx_synchronize(socp_ctx *ctx);
 int socp_ctx_dims(const socp_ctx *ctx, int *dim, int *state_len, int *state_len_jac);
+int socp_ctx_control_dim(const socp_ctx *ctx);
 
 /* counters since creation: trajectories integrated, kernel launches */
 int socp_ctx_counters(const socp_ctx *ctx, long long *trajectories, long long *launches);

@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(HERE, "_build", "libsocp_oracle.so")
 REF_SO = os.path.join(HERE, "_ref", "libsocp_ref.so")
 
-MODEL_GODDARD, MODEL_DINT = 1, 2
+MODEL_GODDARD, MODEL_DINT, MODEL_COVID = 1, 2, 3
 FIXED, FREE, CONTINUOUS = 0, 1, 2
 GODDARD_PARAM_NAMES = ["C", "b", "KD", "kr", "u_max", "mu1", "mu2", "singularControl"]
 
@@ -112,7 +112,7 @@ class Oracle:
         X = np.ascontiguousarray(X, dtype=np.float64)
         u = np.empty(3)
         self.lib.orc_control(C.byref(self.m), C.c_double(t), _d(X), _d(u))
-        return u
+        return u[:self.lib.orc_control_dim(C.byref(self.m))].copy()
 
     def hamiltonian(self, t, X, is_jac=0):
         X = np.ascontiguousarray(X, dtype=np.float64)
@@ -135,6 +135,15 @@ class Oracle:
         Xf = np.empty_like(X0)
         self.lib.orc_model_int(C.byref(self.m), C.c_double(t0), _d(X0), C.c_double(tf), int(is_jac), _d(Xf))
         return Xf
+
+    def traj_dopri5(self, t0, X0, tf, tol):
+        """Adaptive Dormand-Prince segment, initial step (tf - t0)/stepNbr. Returns (Xf, accepted, rejected)."""
+        X = np.array(X0, dtype=np.float64)
+        rej = C.c_long(0)
+        self.lib.orc_integrate_dopri5.restype = C.c_long
+        n = self.lib.orc_integrate_dopri5(C.byref(self.m), _d(X), C.c_double(t0), C.c_double(tf),
+                                          C.c_double((tf - t0) / self.m.step_nbr), C.c_double(tol), C.byref(rej))
+        return X, n, rej.value
 
     def integrate_batch(self, t0, tf, X0, aux_sw=None, is_jac=0):
         X0 = np.ascontiguousarray(X0, dtype=np.float64)
@@ -206,8 +215,11 @@ class Ref:
         L.ref_dint_new.restype = C.c_void_p
         L.ref_goddard_traj_batch.restype = C.c_double
         self.model_id = model_id
+        L.ref_covid_new.restype = C.c_void_p
         if model_id == MODEL_GODDARD:
             self.h = C.c_void_p(L.ref_goddard_new(int(step_nbr)))
+        elif model_id == MODEL_COVID:
+            self.h = C.c_void_p(L.ref_covid_new())
         else:
             self.h = C.c_void_p(L.ref_dint_new(int(model_order)))
         self.dim = L.ref_model_dim(self.h)
@@ -226,6 +238,9 @@ class Ref:
         if self.model_id == MODEL_GODDARD:
             for nme, v in zip(GODDARD_PARAM_NAMES, params):
                 self.set_param(nme, v)
+        elif self.model_id == MODEL_COVID:
+            p = np.ascontiguousarray(params, dtype=np.float64)
+            assert self.lib.ref_covid_set(self.h, _d(p)) == 0
         else:
             self.lib.ref_dint_set(self.h, C.c_double(params[0]), C.c_double(params[1]), C.c_double(params[2]))
 

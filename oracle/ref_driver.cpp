@@ -3,7 +3,7 @@
  *
  * Compiled by oracle/Makefile together with the reference sources where they lie
  * (/root/reference/src/socp/odeTools.cpp, models/goddard/goddard.cpp,
- * models/doubleIntegrator/doubleIntegrator.cpp) into oracle/_ref/libsocp_ref.so.
+ * models/doubleIntegrator/doubleIntegrator.cpp, models/covid19/covid19.cpp) into oracle/_ref/libsocp_ref.so.
  * Those three files need nothing the image lacks.  No reference source is copied
  * into this repository: this file only calls the reference's public interface
  * (model.hpp:77 ComputeTraj, odeTools.hpp:82 Model, model.hpp:375 Control,
@@ -21,12 +21,14 @@
 
 #include "models/goddard/goddard.hpp"
 #include "models/doubleIntegrator/doubleIntegrator.hpp"
+#include "models/covid19/covid19.hpp"
 
 namespace {
 struct RefModel {
     model *m = nullptr;
     goddard *g = nullptr;
     doubleIntegrator *di = nullptr;
+    covid19 *cv = nullptr;
 };
 
 model::mstate to_vec(const double *X, int len) { return model::mstate(X, X + len); }
@@ -48,6 +50,24 @@ void *ref_dint_new(int model_order)
     r->di = new doubleIntegrator(model_order, std::string(""));
     r->m = r->di;
     return r;
+}
+
+void *ref_covid_new()
+{
+    RefModel *r = new RefModel;
+    r->cv = new covid19(std::string(""));
+    r->m = r->cv;
+    return r;
+}
+
+/* p = {R0, Tinf, Tinc, N, Imax, muI, umin, umax} */
+int ref_covid_set(void *h, const double *p)
+{
+    RefModel *r = static_cast<RefModel *>(h);
+    if (!r->cv) return -1;
+    covid19::parameters_struct &q = r->cv->GetParameterData();
+    q.R0 = p[0]; q.Tinf = p[1]; q.Tinc = p[2]; q.N = p[3]; q.Imax = p[4]; q.muI = p[5]; q.umin = p[6]; q.umax = p[7];
+    return 0;
 }
 
 void ref_model_free(void *h)

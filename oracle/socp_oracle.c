@@ -28,12 +28,20 @@ void orc_model_init(orc_model *m, int model_id)
         m->p[GP_C] = 3.5;  m->p[GP_B] = 7.0;   m->p[GP_KD] = 310.0; m->p[GP_KR] = 500.0;
         m->p[GP_UMAX] = 1.0; m->p[GP_MU1] = 1.0; m->p[GP_MU2] = 0.0; m->p[GP_SING] = -1.0;
         m->nsw = 2; m->sw[0] = 0.0227; m->sw[1] = 0.08;
+    } else if (model_id == ORC_MODEL_COVID19) {
+        /* covid19.cpp:25-38; ModelInt uses its own data->stepNbr = 1000 (:36, :171-173) */
+        m->dim = 4;
+        m->step_nbr = 1000;
+        m->p[CP_R0] = 4; m->p[CP_TINF] = 10; m->p[CP_TINC] = 5; m->p[CP_N] = 1;
+        m->p[CP_IMAX] = 0.1; m->p[CP_MUI] = 1; m->p[CP_UMIN] = -10; m->p[CP_UMAX] = 20;
     } else {
         m->dim = 6;
         m->step_nbr = 30;
         m->p[DP_UMAX] = 1.0; m->p[DP_AMAX] = 1.0; m->p[DP_MUT] = 0.01;
     }
 }
+
+int orc_control_dim(const orc_model *m) { return m->model_id == ORC_MODEL_COVID19 ? 1 : 3; }
 
 int orc_state_len(const orc_model *m, int is_jac)
 {
@@ -240,9 +248,56 @@ static void dint_hamiltonian(const orc_model *m, const double *X, int is_jac, do
     }
 }
 
+/* covid19.cpp:97-126 */
+static double covid_control(const orc_model *m, const double *X)
+{
+    double S = X[0], I = X[2], pS = X[4], pE = X[5];
+    double u = (pE - pS)*S*I / m->p[CP_TINF] / m->p[CP_N] * m->p[CP_R0];
+    if (u <= m->p[CP_UMIN]) u = m->p[CP_UMIN];
+    if (u >= m->p[CP_UMAX]) u = m->p[CP_UMAX];
+    return u;
+}
+
+/* covid19.cpp:53-95 */
+static void covid_model(const orc_model *m, const double *X, double *Xdot)
+{
+    double S = X[0], E = X[1], I = X[2], R = X[3], pS = X[4], pE = X[5], pI = X[6], pR = X[7];
+    double R0 = m->p[CP_R0], Tinf = m->p[CP_TINF], Tinc = m->p[CP_TINC], N = m->p[CP_N];
+    double u = covid_control(m, X);
+    double Rt = R0 * (1 - u);
+    double Ipen = 0;
+    if (I >= m->p[CP_IMAX]) Ipen = -m->p[CP_MUI]*(I - m->p[CP_IMAX]);
+    Xdot[0] = -Rt / Tinf / N*S*I;
+    Xdot[1] = Rt / Tinf / N*S*I - E / Tinc;
+    Xdot[2] = E / Tinc - I / Tinf;
+    Xdot[3] = I / Tinf;
+    Xdot[4] = (pS - pE)*R*I / Tinf / N;
+    Xdot[5] = (pE - pI) / Tinc;
+    Xdot[6] = (pS - pE)*R*S / Tinf / N + (pI - pR) / Tinf + Ipen;
+    Xdot[7] = 0;
+}
+
+/* covid19.cpp:128-165 */
+static double covid_hamiltonian(const orc_model *m, const double *X)
+{
+    double S = X[0], E = X[1], I = X[2], pS = X[4], pE = X[5], pI = X[6], pR = X[7];
+    double R0 = m->p[CP_R0], Tinf = m->p[CP_TINF], Tinc = m->p[CP_TINC], N = m->p[CP_N];
+    double u = covid_control(m, X);
+    double Rt = R0 * (1 - u);
+    double Ipen = 0;
+    if (I >= m->p[CP_IMAX]) Ipen = m->p[CP_MUI]*(I - m->p[CP_IMAX])*(I - m->p[CP_IMAX]) / 2;
+    double H = u*u / 2 + Ipen
+        + pS * (-Rt / Tinf / N*S*I)
+        + pE * (Rt / Tinf / N*S*I - E / Tinc)
+        + pI * (E / Tinc - I / Tinf)
+        + pR * (I / Tinf);
+    return H;
+}
+
 void orc_control(const orc_model *m, double t, const double *X, double *u3)
 {
     if (m->model_id == ORC_MODEL_GODDARD) goddard_control(m, t, X, u3);
+    else if (m->model_id == ORC_MODEL_COVID19) u3[0] = covid_control(m, X);
     else dint_control(m, X, u3);
 }
 
@@ -251,6 +306,7 @@ void orc_control(const orc_model *m, double t, const double *X, double *u3)
 void orc_rhs(const orc_model *m, double t, const double *X, int is_jac, double *Xdot)
 {
     if (m->model_id == ORC_MODEL_GODDARD) goddard_model(m, t, X, Xdot);
+    else if (m->model_id == ORC_MODEL_COVID19) covid_model(m, X, Xdot);
     else if (is_jac) dint_model_jac(m, X, Xdot);
     else dint_f(m, X, Xdot);
 }
@@ -258,6 +314,7 @@ void orc_rhs(const orc_model *m, double t, const double *X, int is_jac, double *
 void orc_hamiltonian(const orc_model *m, double t, const double *X, int is_jac, double *H)
 {
     if (m->model_id == ORC_MODEL_GODDARD) H[0] = goddard_hamiltonian(m, t, X);
+    else if (m->model_id == ORC_MODEL_COVID19) H[0] = covid_hamiltonian(m, X);
     else dint_hamiltonian(m, X, is_jac, H);
 }
 
@@ -273,7 +330,7 @@ void orc_rk4_step(const orc_model *m, double t, double *X, double step, int is_j
 {
     int n = orc_state_len(m, is_jac);
     /* goddard's Model returns a 2d vector whatever isJac is (goddard.cpp:49) */
-    if (m->model_id == ORC_MODEL_GODDARD) n = 2 * m->dim;
+    if (m->model_id != ORC_MODEL_DOUBLE_INTEGRATOR) n = 2 * m->dim;
     double F1[ORC_MAX_LEN], F2[ORC_MAX_LEN], F3[ORC_MAX_LEN], F4[ORC_MAX_LEN], Y[ORC_MAX_LEN];
     double h2 = step / 2.0;
 
@@ -302,6 +359,84 @@ long orc_integrate(const orc_model *m, double *X, double t0, double tf, double d
         t += dt;
         steps++;
     }
+    return steps;
+}
+
+/* ---- Dormand-Prince 5(4), controlled, as Boost.Odeint drives it [ext] ------------------------------
+ * runge_kutta_dopri5::do_step_impl: stage sums a1*x1 + a2*x2 + ... left to right (scale_sumN);
+ * default_error_checker: max_i |err_i| / (eps_abs + eps_rel*(|x_i| + dt*|dxdt_i|)) with the OLD state;
+ * default_step_adjuster: reject -> dt *= max(0.9 err^(-1/3), 1/5); accept and err < 0.5 ->
+ * dt *= 0.9 max(5^-5, err)^(-1/5); integrate_adaptive with a dense-output stepper: step while
+ * t + dt <= tf, then re-initialise with dt = tf - t (which also drops the FSAL derivative). */
+static int dopri5_try_step(const orc_model *m, int n, const double *x, const double *k1, double *t, double *dt,
+                           double tol, double *xnew, double *knew)
+{
+    static const double a2 = 1.0 / 5, a3 = 3.0 / 10, a4 = 4.0 / 5, a5 = 8.0 / 9;
+    static const double b21 = 1.0 / 5, b31 = 3.0 / 40, b32 = 9.0 / 40, b41 = 44.0 / 45, b42 = -56.0 / 15, b43 = 32.0 / 9,
+        b51 = 19372.0 / 6561, b52 = -25360.0 / 2187, b53 = 64448.0 / 6561, b54 = -212.0 / 729,
+        b61 = 9017.0 / 3168, b62 = -355.0 / 33, b63 = 46732.0 / 5247, b64 = 49.0 / 176, b65 = -5103.0 / 18656,
+        c1 = 35.0 / 384, c3 = 500.0 / 1113, c4 = 125.0 / 192, c5 = -2187.0 / 6784, c6 = 11.0 / 84;
+    static const double dc1 = 35.0 / 384 - 5179.0 / 57600, dc3 = 500.0 / 1113 - 7571.0 / 16695, dc4 = 125.0 / 192 - 393.0 / 640,
+        dc5 = -2187.0 / 6784 - -92097.0 / 339200, dc6 = 11.0 / 84 - 187.0 / 2100, dc7 = -1.0 / 40;
+    double k2[ORC_MAX_LEN], k3[ORC_MAX_LEN], k4[ORC_MAX_LEN], k5[ORC_MAX_LEN], k6[ORC_MAX_LEN], y[ORC_MAX_LEN];
+    const double h = *dt, tt = *t;
+    for (int i = 0; i < n; i++) y[i] = 1.0 * x[i] + h * b21 * k1[i];
+    orc_rhs(m, tt + h * a2, y, 0, k2);
+    for (int i = 0; i < n; i++) y[i] = 1.0 * x[i] + h * b31 * k1[i] + h * b32 * k2[i];
+    orc_rhs(m, tt + h * a3, y, 0, k3);
+    for (int i = 0; i < n; i++) y[i] = 1.0 * x[i] + h * b41 * k1[i] + h * b42 * k2[i] + h * b43 * k3[i];
+    orc_rhs(m, tt + h * a4, y, 0, k4);
+    for (int i = 0; i < n; i++) y[i] = 1.0 * x[i] + h * b51 * k1[i] + h * b52 * k2[i] + h * b53 * k3[i] + h * b54 * k4[i];
+    orc_rhs(m, tt + h * a5, y, 0, k5);
+    for (int i = 0; i < n; i++) y[i] = 1.0 * x[i] + h * b61 * k1[i] + h * b62 * k2[i] + h * b63 * k3[i] + h * b64 * k4[i] + h * b65 * k5[i];
+    orc_rhs(m, tt + h, y, 0, k6);
+    for (int i = 0; i < n; i++) xnew[i] = 1.0 * x[i] + h * c1 * k1[i] + h * c3 * k3[i] + h * c4 * k4[i] + h * c5 * k5[i] + h * c6 * k6[i];
+    orc_rhs(m, tt + h, xnew, 0, knew);
+    double err = 0;
+    for (int i = 0; i < n; i++) {
+        double e = h * dc1 * k1[i] + h * dc3 * k3[i] + h * dc4 * k4[i] + h * dc5 * k5[i] + h * dc6 * k6[i] + h * dc7 * knew[i];
+        e = fabs(e) / (tol + tol * (1.0 * fabs(x[i]) + 1.0 * h * fabs(k1[i])));
+        if (e > err || e != e) err = e;
+    }
+    if (!(err <= 1.0)) {                                   /* reject (also on NaN) */
+        double f = 0.9 * pow(err, -1.0 / 3.0);
+        if (!(f > 0.2)) f = 0.2;
+        *dt = h * f;
+        return 0;
+    }
+    *t = tt + h;
+    if (err < 0.5) {
+        double e = err > pow(5.0, -5.0) ? err : pow(5.0, -5.0);
+        *dt = h * (0.9 * pow(e, -1.0 / 5.0));
+    }
+    return 1;
+}
+
+long orc_integrate_dopri5(const orc_model *m, double *X, double t0, double tf, double dt, double tol, long *rejected)
+{
+    const int n = 2 * m->dim;
+    const double eps = DBL_EPSILON;
+    double k1[ORC_MAX_LEN], xn[ORC_MAX_LEN], kn[ORC_MAX_LEN];
+    double t = t0, h = dt;
+    long steps = 0, rej = 0;
+    int have_k1 = 0;
+    if (!(h > 0)) { if (rejected) *rejected = 0; return 0; }          /* zero-length / backward: nothing to do */
+    while (tf - t > eps) {                                            /* less_with_sign(t, tf, dt) */
+        while (t + h - tf <= eps) {                                   /* less_eq_with_sign(t + dt, tf, dt) */
+            if (!have_k1) { orc_rhs(m, t, X, 0, k1); have_k1 = 1; }
+            int tries = 0;
+            while (!dopri5_try_step(m, n, X, k1, &t, &h, tol, xn, kn)) {
+                rej++;
+                if (++tries >= 500) { if (rejected) *rejected = rej; return -1; }   /* odeint's step_adjustment_error */
+            }
+            memcpy(X, xn, sizeof(double) * n);
+            memcpy(k1, kn, sizeof(double) * n);
+            steps++;
+        }
+        h = tf - t;                                                   /* initialize(x, t, tf - t) */
+        have_k1 = 0;
+    }
+    if (rejected) *rejected = rej;
     return steps;
 }
 

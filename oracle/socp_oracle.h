@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-enum { ORC_MODEL_GODDARD = 1, ORC_MODEL_DOUBLE_INTEGRATOR = 2 };
+enum { ORC_MODEL_GODDARD = 1, ORC_MODEL_DOUBLE_INTEGRATOR = 2, ORC_MODEL_COVID19 = 3 };
 enum { ORC_FIXED = 0, ORC_FREE = 1, ORC_CONTINUOUS = 2 };   /* model.hpp:34-38 */
 
 #define ORC_MAX_PARAMS 8
@@ -32,6 +32,8 @@ enum { ORC_FIXED = 0, ORC_FREE = 1, ORC_CONTINUOUS = 2 };   /* model.hpp:34-38 *
 enum { GP_C = 0, GP_B, GP_KD, GP_KR, GP_UMAX, GP_MU1, GP_MU2, GP_SING };
 /* doubleIntegrator parameter slots (doubleIntegrator.hpp:24-28) */
 enum { DP_UMAX = 0, DP_AMAX, DP_MUT };
+/* covid19 parameter slots (covid19.hpp parameters_struct) */
+enum { CP_R0 = 0, CP_TINF, CP_TINC, CP_N, CP_IMAX, CP_MUI, CP_UMIN, CP_UMAX };
 
 typedef struct {
     int model_id;                 /* ORC_MODEL_* */
@@ -54,6 +56,7 @@ typedef struct {
 /* ---- model layer ---- */
 void orc_model_init(orc_model *m, int model_id);      /* defaults of the reference ctors */
 int  orc_state_len(const orc_model *m, int is_jac);   /* 2d or (2d+1)*2d */
+int  orc_control_dim(const orc_model *m);              /* 3, 3, 1 */
 void orc_control(const orc_model *m, double t, const double *X, double *u3);
 void orc_rhs(const orc_model *m, double t, const double *X, int is_jac, double *Xdot);
 /* is_jac==0: writes H[0]; is_jac==1: writes dH/dX (2d+1 values) */
@@ -65,6 +68,12 @@ void orc_rk4_step(const orc_model *m, double t, double *X, double step, int is_j
 /* returns number of RK4 steps taken */
 long orc_integrate(const orc_model *m, double *X, double t0, double tf, double dt, int is_jac);
 long orc_model_int(const orc_model *m, double t0, const double *X0, double tf, int is_jac, double *Xf);
+/* Adaptive integration as the reference does it when built with -D_USE_BOOST (odeTools.cpp:129-134):
+ * boost::numeric::odeint::integrate_adaptive(make_dense_output<runge_kutta_dopri5>(tol, tol), ...).
+ * [ext] Boost.Odeint is not vendored and absent offline: restated from its published algorithm
+ * (controlled Dormand-Prince 5(4) with FSAL); validated by tolerance only.
+ * Returns accepted steps; *rejected (may be NULL) counts rejected trial steps. */
+long orc_integrate_dopri5(const orc_model *m, double *X, double t0, double tf, double dt, double tol, long *rejected);
 /* batch of independent trajectories, one per row; aux_sw may be NULL, else [B][2] */
 void orc_integrate_batch(const orc_model *m, int B, const double *t0, const double *tf,
                          const double *aux_sw, const double *X0, double *Xf, int is_jac);

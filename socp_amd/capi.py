@@ -12,11 +12,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_build", "libsocp_hip.so")
 
 OK, ERR_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4
-MODEL_GODDARD, MODEL_DOUBLE_INTEGRATOR = 1, 2
+MODEL_GODDARD, MODEL_DOUBLE_INTEGRATOR, MODEL_COVID19 = 1, 2, 3
 FIXED, FREE, CONTINUOUS = 0, 1, 2
 VARIANT_AUTO, VARIANT_LANE_EXACT, VARIANT_LANE_FAST, VARIANT_WAVE = 0, 1, 2, 3
 EVAL_RHS, EVAL_CONTROL, EVAL_HAMILTONIAN = 0, 1, 2
 REQ_DONE, REQ_FVEC, REQ_JAC = 0, 1, 2
+INT_RK4, INT_DOPRI5 = 0, 1
 GODDARD_PARAM_NAMES = ["C", "b", "KD", "kr", "u_max", "mu1", "mu2", "singularControl"]
 
 _dp = C.POINTER(C.c_double)
@@ -59,10 +60,12 @@ def lib():
         L.socp_ctx_set_params.argtypes = [_vp, _dp, C.c_int]
         L.socp_ctx_get_params.argtypes = [_vp, _dp, C.c_int]
         L.socp_ctx_set_step_number.argtypes = [_vp, C.c_int]
+        L.socp_ctx_set_integrator.argtypes = [_vp, C.c_int, C.c_double]
         L.socp_ctx_set_switching_times.argtypes = [_vp, _dp, C.c_int]
         L.socp_ctx_set_variant.argtypes = [_vp, C.c_int]
         L.socp_ctx_set_stream.argtypes = [_vp, _vp, C.c_int]
         L.socp_ctx_dims.argtypes = [_vp, _ip, _ip, _ip]
+        L.socp_ctx_control_dim.argtypes = [_vp]
         L.socp_ctx_counters.argtypes = [_vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
         L.socp_integrate_batch.argtypes = [_vp, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_int]
         L.socp_integrate_batch_dev.argtypes = [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int]
@@ -122,6 +125,7 @@ class Context:
         dim, s, sj = C.c_int(), C.c_int(), C.c_int()
         self.L.socp_ctx_dims(self.h, C.byref(dim), C.byref(s), C.byref(sj))
         self.model_id, self.dim, self.s, self.s_jac = model_id, dim.value, s.value, sj.value
+        self.nu = self.L.socp_ctx_control_dim(self.h)
         self.n = None
 
     def close(self):
@@ -145,7 +149,7 @@ class Context:
         self._chk(self.L.socp_ctx_set_params(self.h, _d(p), len(p)))
 
     def get_params(self):
-        n = 8 if self.model_id == MODEL_GODDARD else 3
+        n = 3 if self.model_id == MODEL_DOUBLE_INTEGRATOR else 8
         p = np.empty(n)
         self._chk(self.L.socp_ctx_get_params(self.h, _d(p), n))
         return p
@@ -157,6 +161,10 @@ class Context:
 
     def set_step_number(self, n):
         self._chk(self.L.socp_ctx_set_step_number(self.h, int(n)))
+
+    def set_integrator(self, kind, tol=1e-8):
+        """kind: 0 = fixed-step RK4, 1 = adaptive Dormand-Prince 5(4) with abs = rel tolerance tol."""
+        self._chk(self.L.socp_ctx_set_integrator(self.h, int(kind), float(tol)))
 
     def set_switching_times(self, sw):
         sw = _f64(sw)
@@ -213,7 +221,7 @@ class Context:
         X = _f64(X)
         B = X.shape[0]
         t = _f64(np.broadcast_to(t, (B,)))
-        out_len = {EVAL_RHS: X.shape[1], EVAL_CONTROL: 3, EVAL_HAMILTONIAN: (self.s + 1) if is_jac else 1}[what]
+        out_len = {EVAL_RHS: X.shape[1], EVAL_CONTROL: self.nu, EVAL_HAMILTONIAN: (self.s + 1) if is_jac else 1}[what]
         out = np.empty((B, out_len))
         swp = None
         if sw is not None:

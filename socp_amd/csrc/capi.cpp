@@ -41,7 +41,7 @@ struct DevBuf {
 struct socp_ctx {
     int model_id = 0;
     int device = 0;
-    int dim = 0, S = 0;
+    int dim = 0, S = 0, nu = 3;
     int nparams = 0;
     int variant = SOCP_VARIANT_AUTO;
     ModelParams P{};
@@ -88,7 +88,8 @@ int hip_fail(socp_ctx *c, hipError_t e, const char *what)
 bool use_fast(const socp_ctx *c)
 {
     // AUTO keeps the reference operation order: it is the variant every parity claim is made on.
-    return c->variant == SOCP_VARIANT_LANE_FAST;
+    // The adaptive integrator exists in the reference-order translation unit only.
+    return c->variant == SOCP_VARIANT_LANE_FAST && c->P.integrator == SOCP_INT_RK4;
 }
 
 int check_variant(socp_ctx *c)
@@ -140,7 +141,7 @@ int socp_ctx_create(socp_ctx **out, int model_id, int device)
 {
     if (!out) return fail(nullptr, SOCP_ERR_ARG, "socp_ctx_create: null output pointer");
     *out = nullptr;
-    if (model_id != SOCP_MODEL_GODDARD && model_id != SOCP_MODEL_DOUBLE_INTEGRATOR)
+    if (model_id != SOCP_MODEL_GODDARD && model_id != SOCP_MODEL_DOUBLE_INTEGRATOR && model_id != SOCP_MODEL_COVID19)
         return fail(nullptr, SOCP_ERR_UNSUPPORTED, "socp_ctx_create: unknown model id (no device dynamics)");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -161,6 +162,12 @@ int socp_ctx_create(socp_ctx **out, int model_id, int device)
         const double d[8] = {3.5, 7.0, 310.0, 500.0, 1.0, 1.0, 0.0, -1.0};
         std::memcpy(c->P.p, d, sizeof(d));
         c->P.sw0 = 0.0227; c->P.sw1 = 0.08; c->P.step_nbr = 10;
+    } else if (model_id == SOCP_MODEL_COVID19) {
+        // covid19.cpp:25-38 defaults; its ModelInt integrates with its own stepNbr = 1000
+        c->dim = 4; c->nparams = SOCP_COVID_NPARAMS; c->nu = 1;
+        const double d[8] = {4, 10, 5, 1, 0.1, 1, -10, 20};
+        std::memcpy(c->P.p, d, sizeof(d));
+        c->P.sw0 = c->P.sw1 = 0.0; c->P.step_nbr = 1000;
     } else {
         // doubleIntegrator.cpp:26-34 defaults
         c->dim = 6; c->nparams = SOCP_DINT_NPARAMS;
@@ -216,6 +223,16 @@ int socp_ctx_set_step_number(socp_ctx *c, int step_nbr)
     return SOCP_OK;
 }
 
+int socp_ctx_set_integrator(socp_ctx *c, int kind, double tol)
+{
+    if (!c) return SOCP_ERR_ARG;
+    if (kind != SOCP_INT_RK4 && kind != SOCP_INT_DOPRI5) return fail(c, SOCP_ERR_ARG, "set_integrator: unknown integrator");
+    if (kind == SOCP_INT_DOPRI5 && !(tol > 0)) return fail(c, SOCP_ERR_ARG, "set_integrator: tolerance must be positive");
+    c->P.integrator = kind;
+    c->P.tol = tol;
+    return SOCP_OK;
+}
+
 int socp_ctx_set_switching_times(socp_ctx *c, const double *sw, int nsw)
 {
     if (!c || (nsw > 0 && !sw)) return fail(c, SOCP_ERR_ARG, "set_switching_times: null argument");
@@ -258,6 +275,8 @@ int socp_ctx_dims(const socp_ctx *c, int *dim, int *state_len, int *state_len_ja
     return SOCP_OK;
 }
 
+int socp_ctx_control_dim(const socp_ctx *c) { return c ? c->nu : SOCP_ERR_ARG; }
+
 int socp_ctx_counters(const socp_ctx *c, long long *trajectories, long long *launches)
 {
     if (!c) return SOCP_ERR_ARG;
@@ -274,6 +293,8 @@ int socp_integrate_batch_dev(socp_ctx *c, int B, const double *d_t0, const doubl
     if (!c) return SOCP_ERR_ARG;
     if (B < 0 || (B > 0 && (!d_t0 || !d_tf || !d_X0 || !d_Xf))) return fail(c, SOCP_ERR_ARG, "integrate_batch: null argument");
     HIP_TRY(c, hipSetDevice(c->device));
+    if (is_jac && c->P.integrator != SOCP_INT_RK4)
+        return fail(c, SOCP_ERR_UNSUPPORTED, "integrate_batch: the variational state is integrated with fixed-step RK4 only");
     if (is_jac) {
         // variational state: one wavefront per trajectory (doubleIntegrator; goddard has modelOrder 0 only)
         if (c->model_id != SOCP_MODEL_DOUBLE_INTEGRATOR)
@@ -359,7 +380,7 @@ int socp_eval_batch(socp_ctx *c, int what, int B, const double *t, const double 
     if (B == 0) return SOCP_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     const int out_len = var ? (what == SOCP_EVAL_RHS ? L : c->S + 1)
-                            : (what == SOCP_EVAL_RHS ? c->S : (what == SOCP_EVAL_CONTROL ? 3 : 1));
+                            : (what == SOCP_EVAL_RHS ? c->S : (what == SOCP_EVAL_CONTROL ? c->nu : 1));
     if (!var && len != c->S) {
         // a longer (augmented) vector may be passed for Control / Hamiltonian: only the state part is read
         return fail(c, SOCP_ERR_ARG, "eval_batch: pass the 2*dim state part for is_jac=0 evaluations");

@@ -12,7 +12,8 @@ struct ModelParams {
     double p[kMaxParams];
     double sw0, sw1;                   // goddard data->switchingTimes[0..1] when no per-row value is given
     int step_nbr;                      // model::stepNbr (model.hpp:367)
-    int pad;
+    int integrator;                    // 0 = fixed-step RK4 (odeTools.cpp:135-145), 1 = adaptive Dormand-Prince (:129-134)
+    double tol;                        // odeTools::odeIntTol: abs = rel tolerance of the adaptive integrator
 };
 
 // Shooting problem tables (device pointers), built by socp_problem_set.

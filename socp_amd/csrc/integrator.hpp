@@ -60,6 +60,104 @@ struct Lane {
         }
     }
 
+    // ---- adaptive Dormand-Prince 5(4), what the reference runs when built with -D_USE_BOOST:
+    // integrate_adaptive(make_dense_output<runge_kutta_dopri5>(tol, tol), ode, X, t0, tf, dt) (odeTools.cpp:129-134).
+    // [ext] Boost.Odeint is not vendored; restated from its published algorithm: FSAL stages
+    // summed left to right, error max_i |e_i| / (tol + tol (|x_i| + dt |k1_i|)) on the OLD state, reject ->
+    // dt *= max(0.9 err^-1/3, 0.2), accept with err < 0.5 -> dt *= 0.9 max(5^-5, err)^-1/5, stepping while
+    // t + dt <= tf and finishing with dt = tf - t.  Step control is PER LANE: lanes of a wave take different
+    // numbers of steps and wait for the slowest (the loop runs under the exec mask).
+    __device__ static __forceinline__ bool dopri5_try(const ModelParams &P, double sw0, double sw1, double &t, double &dt,
+                                                     const double (&x)[S], const double (&k1)[S], double (&xn)[S], double (&kn)[S])
+    {
+        constexpr double a2 = 1.0 / 5, a3 = 3.0 / 10, a4 = 4.0 / 5, a5 = 8.0 / 9;
+        constexpr double b21 = 1.0 / 5, b31 = 3.0 / 40, b32 = 9.0 / 40, b41 = 44.0 / 45, b42 = -56.0 / 15, b43 = 32.0 / 9,
+                         b51 = 19372.0 / 6561, b52 = -25360.0 / 2187, b53 = 64448.0 / 6561, b54 = -212.0 / 729,
+                         b61 = 9017.0 / 3168, b62 = -355.0 / 33, b63 = 46732.0 / 5247, b64 = 49.0 / 176, b65 = -5103.0 / 18656,
+                         c1 = 35.0 / 384, c3 = 500.0 / 1113, c4 = 125.0 / 192, c5 = -2187.0 / 6784, c6 = 11.0 / 84;
+        constexpr double dc1 = 35.0 / 384 - 5179.0 / 57600, dc3 = 500.0 / 1113 - 7571.0 / 16695, dc4 = 125.0 / 192 - 393.0 / 640,
+                         dc5 = -2187.0 / 6784 - -92097.0 / 339200, dc6 = 11.0 / 84 - 187.0 / 2100, dc7 = -1.0 / 40;
+        double k2[S], k3[S], k4[S], k5[S], k6[S], y[S];
+        const double h = dt, tt = t;
+#pragma unroll
+        for (int i = 0; i < S; i++) y[i] = 1.0 * x[i] + h * b21 * k1[i];
+        Mdl::rhs(P, sw0, sw1, tt + h * a2, y, k2);
+#pragma unroll
+        for (int i = 0; i < S; i++) y[i] = 1.0 * x[i] + h * b31 * k1[i] + h * b32 * k2[i];
+        Mdl::rhs(P, sw0, sw1, tt + h * a3, y, k3);
+#pragma unroll
+        for (int i = 0; i < S; i++) y[i] = 1.0 * x[i] + h * b41 * k1[i] + h * b42 * k2[i] + h * b43 * k3[i];
+        Mdl::rhs(P, sw0, sw1, tt + h * a4, y, k4);
+#pragma unroll
+        for (int i = 0; i < S; i++) y[i] = 1.0 * x[i] + h * b51 * k1[i] + h * b52 * k2[i] + h * b53 * k3[i] + h * b54 * k4[i];
+        Mdl::rhs(P, sw0, sw1, tt + h * a5, y, k5);
+#pragma unroll
+        for (int i = 0; i < S; i++) y[i] = 1.0 * x[i] + h * b61 * k1[i] + h * b62 * k2[i] + h * b63 * k3[i] + h * b64 * k4[i] + h * b65 * k5[i];
+        Mdl::rhs(P, sw0, sw1, tt + h, y, k6);
+#pragma unroll
+        for (int i = 0; i < S; i++) xn[i] = 1.0 * x[i] + h * c1 * k1[i] + h * c3 * k3[i] + h * c4 * k4[i] + h * c5 * k5[i] + h * c6 * k6[i];
+        Mdl::rhs(P, sw0, sw1, tt + h, xn, kn);
+        double err = 0;
+#pragma unroll
+        for (int i = 0; i < S; i++) {
+            double e = h * dc1 * k1[i] + h * dc3 * k3[i] + h * dc4 * k4[i] + h * dc5 * k5[i] + h * dc6 * k6[i] + h * dc7 * kn[i];
+            e = fabs(e) / (P.tol + P.tol * (1.0 * fabs(x[i]) + 1.0 * h * fabs(k1[i])));
+            if (e > err || e != e) err = e;
+        }
+        if (!(err <= 1.0)) {
+            double f = 0.9 * pow(err, -1.0 / 3.0);
+            if (!(f > 0.2)) f = 0.2;
+            dt = h * f;
+            return false;
+        }
+        t = tt + h;
+        if (err < 0.5) {
+            const double floor5 = 1.0 / 3125.0;                 // 5^-5
+            const double e = err > floor5 ? err : floor5;
+            dt = h * (0.9 * pow(e, -1.0 / 5.0));
+        }
+        return true;
+    }
+
+    __device__ static __forceinline__ void integrate_dopri5(const ModelParams &P, double sw0, double sw1,
+                                                           double t0, double tf, double (&X)[S])
+    {
+        const double eps = 2.220446049250313e-16;
+        double t = t0, h = (tf - t0) / P.step_nbr;
+        if (!(h > 0)) return;                                   // zero-length / backward segment: no step
+        double k1[S], xn[S], kn[S];
+        bool have_k1 = false;
+        int budget = 1 << 22;                                   // every lane reaches an exit: bounded total work
+        while (tf - t > eps && budget > 0) {
+            while (t + h - tf <= eps && budget > 0) {
+                if (!have_k1) { Mdl::rhs(P, sw0, sw1, t, X, k1); have_k1 = true; }
+                int tries = 0;
+                bool ok;
+                do {
+                    ok = dopri5_try(P, sw0, sw1, t, h, X, k1, xn, kn);
+                    budget--;
+                } while (!ok && ++tries < 500);
+                if (!ok) {                                       // odeint throws step_adjustment_error: poison the result
+#pragma unroll
+                    for (int i = 0; i < S; i++) X[i] = __builtin_nan("");
+                    return;
+                }
+#pragma unroll
+                for (int i = 0; i < S; i++) { X[i] = xn[i]; k1[i] = kn[i]; }
+            }
+            h = tf - t;
+            have_k1 = false;
+        }
+    }
+
+    template <int INTEG>
+    __device__ static __forceinline__ void integrate_with(const ModelParams &P, double sw0, double sw1,
+                                                         double t0, double tf, double (&X)[S])
+    {
+        if constexpr (INTEG == 1) integrate_dopri5(P, sw0, sw1, t0, tf, X);
+        else integrate(P, sw0, sw1, t0, tf, X);
+    }
+
     // model.hpp:395-414 / goddard.cpp:298-317 (dt) + odeTools.cpp:128-146 (loop): t is
     // accumulated by t += dt, the last step is clamped to tf - t, and a segment with
     // tf <= t0 + dt/2 (zero length or backward) takes no step at all.
@@ -85,7 +183,7 @@ struct Lane {
 // WPE = cap on waves per SIMD (amdgpu_waves_per_eu max): the launcher picks ceil(waves / 1024) so that a
 // grid smaller than the chip is spread one (or two) waves per SIMD instead of being packed three deep on
 // a fraction of the SIMDs (launch_impl.hpp).
-template <class Mdl, int WPE>
+template <class Mdl, int WPE, int INTEG = 0>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, WPE))) void traj_lane_kernel(ModelParams P, int B,
                                                        const double *__restrict__ t0,
                                                        const double *__restrict__ tf,
@@ -111,7 +209,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, WPE))) vo
         const long b = row0 + lane;
         const double s0 = sw ? sw[2 * b] : P.sw0;
         const double s1 = sw ? sw[2 * b + 1] : P.sw1;
-        Lane<Mdl>::integrate(P, s0, s1, t0[b], tf[b], X);
+        Lane<Mdl>::template integrate_with<INTEG>(P, s0, s1, t0[b], tf[b], X);
 #pragma unroll
         for (int k = 0; k < S; k++) tile[lane * LD + k] = X[k];
     }
@@ -159,7 +257,7 @@ __global__ void traj_dense_kernel(ModelParams P, double t0, double tf, double sw
 //   i == M-1   : F[d..2d)           final rows (+ H row when tf is FREE)
 // `Emit` receives (row index, value).
 // ---------------------------------------------------------------------------------------------
-template <class Mdl, class ZRead, class Emit>
+template <class Mdl, int INTEG, class ZRead, class Emit>
 __device__ __forceinline__ void segment_residual(const ModelParams &P, const ProblemDev &pb,
                                                  const ZRead &z, int i, Emit &&emit)
 {
@@ -197,7 +295,7 @@ __device__ __forceinline__ void segment_residual(const ModelParams &P, const Pro
 #pragma unroll
         for (int k = 0; k < S; k++) X[k] = z(S * i + k);
     }
-    Lane<Mdl>::integrate(P, sw0, sw1, t1, t2, X);          // shooting.cpp:943 Move(t1, X1, t2)
+    Lane<Mdl>::template integrate_with<INTEG>(P, sw0, sw1, t1, t2, X);     // shooting.cpp:943 Move(t1, X1, t2)
 
     if (i < M - 1) {
         double Xp[S];
@@ -234,7 +332,7 @@ __device__ __forceinline__ void segment_residual(const ModelParams &P, const Pro
 }
 
 // K_res: Z[B][n] -> F[B][n]; trajectory index T = row*M + segment.
-template <class Mdl, int WPE>
+template <class Mdl, int WPE, int INTEG = 0>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, WPE))) void residual_lane_kernel(ModelParams P, ProblemDev pb, int B,
                                                               const double *__restrict__ Z,
                                                               double *__restrict__ F)
@@ -246,7 +344,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, WPE))) vo
     const double *zr = Z + b * pb.n;
     double *fr = F + b * pb.n;
     auto z = [=](int k) -> double { return zr[k]; };
-    segment_residual<Mdl>(P, pb, z, i, [=](int row, double v) { fr[row] = v; });
+    segment_residual<Mdl, INTEG>(P, pb, z, i, [=](int row, double v) { fr[row] = v; });
 }
 
 // MINPACK fdjac1 step: h = eps*|z_j|, or eps when that is zero
@@ -260,7 +358,7 @@ __device__ __forceinline__ double fd_step(double zj, double eps)
 // integrate; the unknown vector of column j is z with z_j + h_j generated on the fly, so the
 // perturbation matrix never exists in HBM: reads are z[n] and fvec[n] per problem (cache
 // resident), writes are the Jacobian entries fjac[row + n*j] = (F_j[row] - fvec[row]) / h_j.
-template <class Mdl, int WPE>
+template <class Mdl, int WPE, int INTEG = 0>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, WPE))) void fdjac_lane_kernel(ModelParams P, ProblemDev pb, int np, int T,
                                                            const int2 *__restrict__ pairs,
                                                            const double *__restrict__ Zb,
@@ -278,13 +376,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, WPE))) vo
     const double zj = zb[j] + h;
     auto z = [=](int k) -> double { const double v = zb[k]; return k == j ? zj : v; };
     double *col = Fjac + prob * (long)pb.n * pb.n + (long)pb.n * j;
-    segment_residual<Mdl>(P, pb, z, i, [=](int row, double v) { col[row] = (v - fvec[row]) / h; });
+    segment_residual<Mdl, INTEG>(P, pb, z, i, [=](int row, double v) { col[row] = (v - fvec[row]) / h; });
 }
 
 // K_fdr: the (n+1) residual rows of a forward-difference Jacobian -- row 0 at z, row j+1 at
 // z + h_j e_j -- for `np` problems in ONE launch (no dependency between base and perturbed
 // trajectories).  Rows[np][n+1][n]; the perturbation matrix is generated on the fly.
-template <class Mdl, int WPE>
+template <class Mdl, int WPE, int INTEG = 0>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, WPE))) void fdrows_lane_kernel(ModelParams P, ProblemDev pb, int np,
                                                             const double *__restrict__ Zb, double eps,
                                                             double *__restrict__ Rows)
@@ -301,7 +399,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, WPE))) vo
     const double zj = j >= 0 ? zb[j] + fd_step(zb[j], eps) : 0.0;
     auto z = [=](int k) -> double { const double v = zb[k]; return k == j ? zj : v; };
     double *out = Rows + (prob * (pb.n + 1) + row) * (long)pb.n;
-    segment_residual<Mdl>(P, pb, z, i, [=](int r, double v) { out[r] = v; });
+    segment_residual<Mdl, INTEG>(P, pb, z, i, [=](int r, double v) { out[r] = v; });
 }
 
 #ifdef SOCP_DEFINE_COMMON
@@ -346,7 +444,7 @@ __global__ __launch_bounds__(64) void eval_lane_kernel(ModelParams P, int what, 
     } else if (what == 1) {
         double u[3];
         Mdl::control_only(P, s0, s1, t[b], X, u);
-        out[3L * b] = u[0]; out[3L * b + 1] = u[1]; out[3L * b + 2] = u[2];
+        for (int k = 0; k < Mdl::NU; k++) out[(long)Mdl::NU * b + k] = u[k];
     } else {
         out[b] = Mdl::hamiltonian(P, s0, s1, t[b], X);
     }

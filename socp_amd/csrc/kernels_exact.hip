@@ -3,9 +3,11 @@
 // CPU oracle at the few-ulp level.
 #include "models_exact.hpp"
 #define SOCP_FLAVOUR exact
+#define SOCP_HAVE_DOPRI5 1      // adaptive Dormand-Prince instantiations live here (reference-order RHS)
 #define SOCP_DEFINE_COMMON 1   // fd_diff lives in the no-contraction TU
 #define SOCP_GODDARD GoddardExact
 #define SOCP_GODDARD_SMOOTH GoddardExactSmooth
+#define SOCP_COVID CovidExact
 #define SOCP_DINT DIntExact
 #include "launch_impl.hpp"
 

@@ -5,5 +5,6 @@
 #define SOCP_FLAVOUR fast
 #define SOCP_GODDARD GoddardFast
 #define SOCP_GODDARD_SMOOTH GoddardFastSmooth
+#define SOCP_COVID CovidFast
 #define SOCP_DINT DIntFast
 #include "launch_impl.hpp"

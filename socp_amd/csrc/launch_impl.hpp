@@ -25,8 +25,18 @@ static inline int wpe_for(long waves)
     return k < 1 ? 1 : (k > 3 ? 3 : (int)k);
 }
 
+// SOCP_HAVE_DOPRI5: this translation unit also carries the adaptive-integrator instantiations (one wave per
+// SIMD: seven stage vectors live in registers)
+#ifdef SOCP_HAVE_DOPRI5
+#define SOCP_LAUNCH_ADAPTIVE(KERNEL, MDL, GRID, ST, ...) \
+    if (P.integrator == 1) { hipLaunchKernelGGL((KERNEL<MDL, 1, 1>), dim3(GRID), dim3(64), 0, ST, __VA_ARGS__); break; }
+#else
+#define SOCP_LAUNCH_ADAPTIVE(KERNEL, MDL, GRID, ST, ...)
+#endif
+
 #define SOCP_LAUNCH_MDL(KERNEL, MDL, WAVES, GRID, ST, ...)                                               \
     do {                                                                                                \
+        SOCP_LAUNCH_ADAPTIVE(KERNEL, MDL, GRID, ST, __VA_ARGS__)                                        \
         switch (wpe_for(WAVES)) {                                                                       \
         case 1: hipLaunchKernelGGL((KERNEL<MDL, 1>), dim3(GRID), dim3(64), 0, ST, __VA_ARGS__); break;  \
         case 2: hipLaunchKernelGGL((KERNEL<MDL, 2>), dim3(GRID), dim3(64), 0, ST, __VA_ARGS__); break;  \
@@ -39,6 +49,7 @@ static inline int wpe_for(long waves)
     do {                                                                                                \
         if (model_id == 1 && P.p[6] > 0) SOCP_LAUNCH_MDL(KERNEL, SOCP_GODDARD_SMOOTH, GRID, GRID, ST, __VA_ARGS__); \
         else if (model_id == 1) SOCP_LAUNCH_MDL(KERNEL, SOCP_GODDARD, GRID, GRID, ST, __VA_ARGS__);     \
+        else if (model_id == 3) SOCP_LAUNCH_MDL(KERNEL, SOCP_COVID, GRID, GRID, ST, __VA_ARGS__);       \
         else SOCP_LAUNCH_MDL(KERNEL, SOCP_DINT, GRID, GRID, ST, __VA_ARGS__);                           \
     } while (0)
 
@@ -48,6 +59,8 @@ static inline int wpe_for(long waves)
             hipLaunchKernelGGL(KERNEL<SOCP_GODDARD_SMOOTH>, dim3(GRID), dim3(64), 0, ST, __VA_ARGS__);  \
         else if (model_id == 1)                                                                         \
             hipLaunchKernelGGL(KERNEL<SOCP_GODDARD>, dim3(GRID), dim3(64), 0, ST, __VA_ARGS__);         \
+        else if (model_id == 3)                                                                         \
+            hipLaunchKernelGGL(KERNEL<SOCP_COVID>, dim3(GRID), dim3(64), 0, ST, __VA_ARGS__);           \
         else                                                                                            \
             hipLaunchKernelGGL(KERNEL<SOCP_DINT>, dim3(GRID), dim3(64), 0, ST, __VA_ARGS__);            \
     } while (0)
@@ -105,6 +118,8 @@ hipError_t SOCP_CAT(dense_, SOCP_FLAVOUR)(int model_id, hipStream_t st, const Mo
 {
     if (model_id == 1)
         hipLaunchKernelGGL(traj_dense_kernel<SOCP_GODDARD>, dim3(1), dim3(64), 0, st, P, t0, tf, sw0, sw1, X0, dense, times, cap, rows);
+    else if (model_id == 3)
+        hipLaunchKernelGGL(traj_dense_kernel<SOCP_COVID>, dim3(1), dim3(64), 0, st, P, t0, tf, sw0, sw1, X0, dense, times, cap, rows);
     else
         hipLaunchKernelGGL(traj_dense_kernel<SOCP_DINT>, dim3(1), dim3(64), 0, st, P, t0, tf, sw0, sw1, X0, dense, times, cap, rows);
     return hipGetLastError();

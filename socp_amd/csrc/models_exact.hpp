@@ -14,6 +14,7 @@ namespace socp {
 
 enum { GP_C = 0, GP_B, GP_KD, GP_KR, GP_UMAX, GP_MU1, GP_MU2, GP_SING };
 enum { DP_UMAX = 0, DP_AMAX, DP_MUT };
+enum { CP_R0 = 0, CP_TINF, CP_TINC, CP_N, CP_IMAX, CP_MUI, CP_UMIN, CP_UMAX };
 
 // SMOOTH = true: specialised for the quadratic-cost law mu2 > 0 (goddard.cpp:137-145); the host
 // selects it from the parameter block, so the kernel carries no bang/singular/off code.  Both
@@ -22,6 +23,7 @@ template <bool SMOOTH>
 struct GoddardExactT {
     static constexpr int D = 7;
     static constexpr int S = 14;
+    static constexpr int NU = 3;
     static constexpr bool kRefOrder = true;
 
     // quantities both Model() and Control() derive from the state (goddard.cpp:66-76,121-130)
@@ -192,6 +194,7 @@ using GoddardExactSmooth = GoddardExactT<true>;   // mu2 > 0 only
 struct DIntExact {
     static constexpr int D = 6;
     static constexpr int S = 12;
+    static constexpr int NU = 3;
     static constexpr bool kRefOrder = true;
 
     // doubleIntegrator.cpp:218-259
@@ -235,6 +238,71 @@ struct DIntExact {
     }
 
     // model.hpp:299-304 default: H(t, X-) - H(t, X+)
+    __device__ static double switching_fn(const ModelParams &P, double sw0, double sw1, double t,
+                                          const double (&X)[S], const double (&Xp)[S])
+    {
+        return hamiltonian(P, sw0, sw1, t, X) - hamiltonian(P, sw0, sw1, t, Xp);
+    }
+};
+
+// SEIR epidemic model with a social-distancing control (covid19.cpp:53-165), dim 4.  IEEE operations
+// only (no exp / sqrt): bit-identical to the x86 path.
+struct CovidExact {
+    static constexpr int D = 4;
+    static constexpr int S = 8;
+    static constexpr int NU = 1;
+    static constexpr bool kRefOrder = true;
+
+    // covid19.cpp:97-126
+    __device__ static __forceinline__ double control_scalar(const ModelParams &P, const double (&X)[S])
+    {
+        double u = (X[5] - X[4])*X[0]*X[2] / P.p[CP_TINF] / P.p[CP_N] * P.p[CP_R0];
+        if (u <= P.p[CP_UMIN]) u = P.p[CP_UMIN];
+        if (u >= P.p[CP_UMAX]) u = P.p[CP_UMAX];
+        return u;
+    }
+    __device__ static void control_only(const ModelParams &P, double, double, double, const double (&X)[S], double (&u)[3])
+    {
+        u[0] = control_scalar(P, X); u[1] = 0; u[2] = 0;
+    }
+
+    // covid19.cpp:53-95
+    __device__ static __forceinline__ void rhs(const ModelParams &P, double, double, double,
+                                              const double (&X)[S], double (&dX)[S])
+    {
+        const double Sx = X[0], E = X[1], I = X[2], R = X[3], pS = X[4], pE = X[5], pI = X[6], pR = X[7];
+        const double R0 = P.p[CP_R0], Tinf = P.p[CP_TINF], Tinc = P.p[CP_TINC], N = P.p[CP_N];
+        const double u = control_scalar(P, X);
+        const double Rt = R0 * (1 - u);
+        double Ipen = 0;
+        if (I >= P.p[CP_IMAX]) Ipen = -P.p[CP_MUI]*(I - P.p[CP_IMAX]);
+        dX[0] = -Rt / Tinf / N*Sx*I;
+        dX[1] = Rt / Tinf / N*Sx*I - E / Tinc;
+        dX[2] = E / Tinc - I / Tinf;
+        dX[3] = I / Tinf;
+        dX[4] = (pS - pE)*R*I / Tinf / N;
+        dX[5] = (pE - pI) / Tinc;
+        dX[6] = (pS - pE)*R*Sx / Tinf / N + (pI - pR) / Tinf + Ipen;
+        dX[7] = 0;
+    }
+
+    // covid19.cpp:128-165
+    __device__ static double hamiltonian(const ModelParams &P, double, double, double, const double (&X)[S])
+    {
+        const double Sx = X[0], E = X[1], I = X[2], pS = X[4], pE = X[5], pI = X[6], pR = X[7];
+        const double R0 = P.p[CP_R0], Tinf = P.p[CP_TINF], Tinc = P.p[CP_TINC], N = P.p[CP_N];
+        const double u = control_scalar(P, X);
+        const double Rt = R0 * (1 - u);
+        double Ipen = 0;
+        if (I >= P.p[CP_IMAX]) Ipen = P.p[CP_MUI]*(I - P.p[CP_IMAX])*(I - P.p[CP_IMAX]) / 2;
+        return u*u / 2 + Ipen
+            + pS * (-Rt / Tinf / N*Sx*I)
+            + pE * (Rt / Tinf / N*Sx*I - E / Tinc)
+            + pI * (E / Tinc - I / Tinf)
+            + pR * (I / Tinf);
+    }
+
+    // model.hpp:299-304 default
     __device__ static double switching_fn(const ModelParams &P, double sw0, double sw1, double t,
                                           const double (&X)[S], const double (&Xp)[S])
     {

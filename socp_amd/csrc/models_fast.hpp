@@ -40,6 +40,7 @@ template <bool SMOOTH>
 struct GoddardFastT {
     static constexpr int D = 7;
     static constexpr int S = 14;
+    static constexpr int NU = 3;
     static constexpr bool kRefOrder = false;
 
     __device__ static __forceinline__ void rhs(const ModelParams &P, double sw0, double sw1, double t,
@@ -134,5 +135,6 @@ using GoddardFastSmooth = GoddardFastT<true>;
 // The double integrator has one division per control component and one rare square root: nothing
 // to restructure beyond what contraction gives.
 using DIntFast = DIntExact;
+using CovidFast = CovidExact;     // IEEE +,-,*,/ only: nothing to restructure
 
 }  // namespace socp

@@ -31,7 +31,7 @@ socp_ctx *model::DeviceContext() const
     // poke stepNbr / switching times directly: re-pack on every use, never cache
     double p[16];
     const int np = DeviceParams(p, 16);
-    if (socp_ctx_set_params(deviceCtx_, p, np) != SOCP_OK || socp_ctx_set_step_number(deviceCtx_, stepNbr) != SOCP_OK)
+    if (socp_ctx_set_params(deviceCtx_, p, np) != SOCP_OK || socp_ctx_set_step_number(deviceCtx_, DeviceStepNumber()) != SOCP_OK)
         throw std::runtime_error(std::string("model: ") + socp_last_error(deviceCtx_));
     const std::vector<real> sw = DeviceSwitchingTimes();
     socp_ctx_set_switching_times(deviceCtx_, sw.data(), (int)sw.size());
@@ -42,7 +42,7 @@ model::mstate model::DeviceEval(int what, real const &t, mstate const &X, int is
 {
     socp_ctx *ctx = DeviceContext();
     const int s = 2 * dim;
-    const int out_len = what == SOCP_EVAL_RHS ? (int)X.size() : (what == SOCP_EVAL_CONTROL ? 3 : (isJac ? s + 1 : 1));
+    const int out_len = what == SOCP_EVAL_RHS ? (int)X.size() : (what == SOCP_EVAL_CONTROL ? socp_ctx_control_dim(ctx) : (isJac ? s + 1 : 1));
     mstate out(out_len);
     if (socp_eval_batch(ctx, what, 1, &t, nullptr, X.data(), (int)X.size(), out.data(), isJac) != SOCP_OK)
         throw std::runtime_error(std::string("model: ") + socp_last_error(ctx));

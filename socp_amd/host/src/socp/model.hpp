@@ -62,6 +62,8 @@ public:
     virtual int DeviceModelId() const { return 0; }
     // packed parameter block in the order the device twin expects; returns the count
     virtual int DeviceParams(double *out, int cap) const { (void)out; (void)cap; return 0; }
+    // number of RK4 steps per segment the device integrates with (covid19 keeps its own, covid19.cpp:36)
+    virtual int DeviceStepNumber() const { return stepNbr; }
     // switching times the control law reads (goddard); empty otherwise
     virtual std::vector<real> DeviceSwitchingTimes() const { return std::vector<real>(); }
     // lazily created device context with parameters, step number and switching times refreshed

@@ -50,9 +50,9 @@ void odeTools::RK4(real const &, odeVector &, real const &, modelStruct const &)
 void odeTools::integrate(modelStruct const &_model, odeVector &X, double const &t0, double const &tf, double const &dt)
 {
     model *m = device_model(_model.m_ode);
-    const double dt_model = (tf - t0) / m->stepNbr;
+    const double dt_model = (tf - t0) / m->DeviceStepNumber();
     if (!(dt == dt_model))
-        throw std::runtime_error("odeTools::integrate: dt must equal (tf - t0)/stepNbr for the device path");
+        throw std::runtime_error("odeTools::integrate: dt must equal (tf - t0)/DeviceStepNumber() for the device path");
     socp_ctx *ctx = m->DeviceContext();
     odeVector Xf(X.size());
     if (socp_integrate_batch(ctx, 1, &t0, &tf, nullptr, X.data(), Xf.data(), _model.m_isJac) != SOCP_OK)
@@ -64,13 +64,13 @@ void odeTools::integrate(modelStruct const &_model, odeVector &X, double const &
 void odeTools::integrate(modelStruct const &_model, odeVector &X, double const &t0, double const &tf, double const &dt, observerStruct const &_observer)
 {
     model *m = device_model(_model.m_ode);
-    const double dt_model = (tf - t0) / m->stepNbr;
+    const double dt_model = (tf - t0) / m->DeviceStepNumber();
     if (!(dt == dt_model))
-        throw std::runtime_error("odeTools::integrate: dt must equal (tf - t0)/stepNbr for the device path");
+        throw std::runtime_error("odeTools::integrate: dt must equal (tf - t0)/DeviceStepNumber() for the device path");
     if (_model.m_isJac) throw std::runtime_error("odeTools::integrate: tracing the variational state is not supported");
     socp_ctx *ctx = m->DeviceContext();
     const int S = (int)X.size();
-    const int cap = m->stepNbr + 2;
+    const int cap = m->DeviceStepNumber() + 2;
     std::vector<double> dense((size_t)cap * S), times(cap);
     int rows = 0;
     if (socp_integrate_dense(ctx, t0, tf, nullptr, X.data(), dense.data(), times.data(), cap, &rows) != SOCP_OK)

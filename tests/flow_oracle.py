@@ -350,3 +350,36 @@ def dint_wp_flow(solver="scipy", model_order=1, xtol=1e-8, M=2):
             info = sh.solve_param(1.0, lambda v: o.m.p.__setitem__(2, v), 0.01, 0.02)
         out.append(dict(stage="muT_continuation", info=int(info), nfev=int(sh.nfev), njev=int(sh.njev), z=sh.z.copy()))
     return out
+
+
+def covid_flow(solver="scipy", xtol=1e-8, stages=3, step_nbr=1000):
+    """tests/testCovid19.cpp:30-108 on the oracle: M = 20, fixed tf, S/E/I free at tf, R pinned; solve,
+    then data continuation of the target R(tf) 0.6 -> 0.7 in steps of 0.1 and of tf 30 -> 365 in steps of
+    0.01 (shooting.cpp:598-692)."""
+    from oracle.oracle import MODEL_COVID
+    o = Oracle(MODEL_COVID, step_nbr=step_nbr)
+    o.m.p[0], o.m.p[1], o.m.p[2] = 3.4, 14.0, 5.0          # R0, Tinf, Tinc (testCovid19.cpp:41-43)
+    M = 20
+    sh = OracleShooting(o, M, solver)
+    sh.xtol = xtol
+    sh.set_mode_final(FIXED, np.array([FREE, FREE, FREE, FIXED], dtype=np.int32))
+    Xi = np.array([0.93, 0.003, 0.01, 0.057, -0.001, 0.001, 0.0, 0.0])
+    Xf = np.zeros(8)
+    Xf[3] = 0.6
+    sh.init_uniform(0.0, Xi, 30.0, Xf)
+    out = []
+    info = sh.solve()
+    out.append(dict(stage="solve", info=int(info), nfev=int(sh.nfev), z=sh.z.copy()))
+    if stages > 1:
+        Xf2 = Xf.copy()
+        Xf2[3] = 0.7
+        sh.timed[0], sh.timed[M] = 0.0, 30.0
+        sh.Xd[0], sh.Xd[M] = Xi, Xf2
+        info = sh.solve_data(0.1)
+        out.append(dict(stage="target_continuation", info=int(info), nfev=int(sh.nfev), z=sh.z.copy()))
+    if stages > 2:
+        sh.timed[0], sh.timed[M] = 0.0, 365.0
+        sh.Xd[0], sh.Xd[M] = Xi, Xf2
+        info = sh.solve_data(0.01)
+        out.append(dict(stage="horizon_continuation", info=int(info), nfev=int(sh.nfev), z=sh.z.copy()))
+    return out

@@ -15,7 +15,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
-from oracle.oracle import Ref, have_ref, MODEL_GODDARD, MODEL_DINT  # noqa: E402
+from oracle.oracle import Ref, have_ref, MODEL_GODDARD, MODEL_DINT, MODEL_COVID  # noqa: E402
 
 X0S = np.array([0.999949994, 1e-4, 0.01, 1e-10, 1e-10, 1e-10, 1.0])
 PSTAR = np.array([-8.121947733, 7.775439382e-3, 0.7775438809, -0.4779369965, 5.715013318e-4,
@@ -97,6 +97,20 @@ def main():
         Xi[:, 12 * (k + 1) + k] = 1.0
     out["d_traj_aug_X0"] = Xi
     out["d_traj_aug"] = np.stack([rd.traj(0.0, Xi[i], 7.5, 1) for i in range(3)])
+
+    # covid19 (SEIR): Model / Control / Hamiltonian incl. saturated control and active I-penalty, segments
+    Xc = np.tile(np.array([0.93, 0.003, 0.01, 0.057, -0.001, 0.001, 0.0, 0.0]), (32, 1)) * (1 + 0.5 * rng.uniform(-1, 1, (32, 8)))
+    Xc[:, 2] = rng.uniform(0, 0.3, 32)            # I on both sides of Imax = 0.1
+    Xc[::3, 4:] += rng.uniform(-300, 300, (11, 4))  # large costates: control hits umin / umax
+    rc = Ref(MODEL_COVID)
+    rc.set_params([3.4, 14, 5, 1, 0.1, 1, -10, 20])
+    out["c_X"] = Xc
+    out["c_rhs"] = np.stack([rc.rhs(0.0, Xc[i]) for i in range(32)])
+    out["c_ctl"] = np.stack([rc.control(0.0, Xc[i]) for i in range(32)])
+    out["c_ham"] = np.array([rc.hamiltonian(0.0, Xc[i])[0] for i in range(32)])
+    Xs = np.tile(np.array([0.93, 0.003, 0.01, 0.057, -0.001, 0.001, 0.0, 0.0]), (6, 1)) * (1 + 0.05 * rng.uniform(-1, 1, (6, 8)))
+    out["c_traj_X0"] = Xs
+    out["c_traj"] = np.stack([rc.traj(0.0, Xs[i], 1.5) for i in range(6)])      # 1000 RK4 steps (covid19.cpp:36)
 
     np.savez_compressed(os.path.join(HERE, "reference_vectors.npz"), **out)
     print("wrote", os.path.join(HERE, "reference_vectors.npz"), "with", len(out), "arrays")

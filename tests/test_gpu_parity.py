@@ -296,3 +296,65 @@ def test_fast_residual_c1(gfast, goracle):
     Fc = goracle.residual(prob, z)
     Fg = gfast.residual(z)
     assert np.max(np.abs(Fg - Fc)) <= 1e-11 * np.max(np.abs(Fc))
+
+
+# ---- adaptive Dormand-Prince integrator (what the reference runs with -D_USE_BOOST) ---------------------------
+
+def test_dopri5_against_oracle_and_tolerance(gctx, goracle):
+    """No Boost offline => the specification is the oracle's restatement of odeint's controlled stepper;
+    it is itself checked against a 1e5-step RK4 solution and SciPy's RK45 in tests/test_oracle.py.  The GPU
+    follows the same algorithm with per-lane step control; `pow` in the step controller is the only
+    non-IEEE operation besides exp, so agreement is to ~100 x rounding of a tol-accurate solution."""
+    from socp_amd import capi
+    for c in (gctx, goracle):
+        c.set_param("mu2", 1.0)
+        c.set_param("KD", 310.0)
+    gctx.set_step_number(10)
+    goracle.m.step_nbr = 10
+    B = 70
+    X0 = goddard_costate_batch(B, 1e-3)
+    fine = Oracle_fine_solution(X0[:4])
+    for tol in (1e-6, 1e-9):
+        gctx.set_integrator(capi.INT_DOPRI5, tol)
+        Xg = gctx.integrate_batch(0.0, GODDARD_TF, X0)
+        Xc = np.stack([goracle.traj_dopri5(0.0, X0[b], GODDARD_TF, tol)[0] for b in range(B)])
+        assert np.all(np.isfinite(Xg))
+        assert relerr(Xg, Xc) <= 100 * tol * 1e-2          # same step sequence up to rounding
+        assert relerr(Xg[:4], fine) <= 200 * tol           # and a tol-accurate solution
+    # zero-length and backward segments take no step
+    t0 = np.array([0.1, 0.2]); tf = np.array([0.1, 0.1])
+    assert np.array_equal(gctx.integrate_batch(t0, tf, X0[:2]), X0[:2])
+    gctx.set_integrator(capi.INT_RK4)
+
+
+def Oracle_fine_solution(X0):
+    from oracle.oracle import Oracle, MODEL_GODDARD
+    o = Oracle(MODEL_GODDARD, step_nbr=100000)
+    o.set_param("mu2", 1.0)
+    return np.stack([o.traj(0.0, x, GODDARD_TF) for x in X0])
+
+
+def test_dopri5_residual_and_newton(gctx, goracle):
+    """The shooting residual and a full Newton solve with the adaptive integrator (n = 14)."""
+    from socp_amd import capi
+    for c in (gctx, goracle):
+        c.set_param("mu2", 1.0)
+        c.set_param("KD", 310.0)
+    gctx.set_step_number(10)
+    prob, z = goddard_single_problem()
+    _setup_problem(gctx, prob)
+    gctx.set_integrator(capi.INT_DOPRI5, 1e-10)
+    F = gctx.residual(z)
+    J = gctx.fd_jacobian(z, F, dedup=True)
+    assert np.array_equal(J, gctx.fd_jacobian(z, F, dedup=False))
+    out = capi.hybrd(lambda v: gctx.residual(v), z, xtol=1e-10, epsfcn=1e-15,
+                     fdjac=lambda x, f, e: gctx.fd_jacobian(x, f, epsfcn=e))
+    assert out["info"] == 1
+    # the root of the adaptive problem (local error 1e-10) agrees with the 1e4-step RK4 root it approximates
+    gctx.set_integrator(capi.INT_RK4)
+    gctx.set_step_number(10000)
+    ref = capi.hybrd(lambda v: gctx.residual(v), z, xtol=1e-10, epsfcn=1e-15,
+                     fdjac=lambda x, f, e: gctx.fd_jacobian(x, f, epsfcn=e))
+    assert ref["info"] == 1
+    assert np.max(np.abs(out["x"] - ref["x"])) <= 1e-5 * np.max(np.abs(ref["x"]))
+    gctx.set_step_number(10)

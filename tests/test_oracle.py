@@ -181,3 +181,41 @@ def test_variational_jacobian_matches_fd(built):
     keep = [c for c in range(prob.n) if c != 24]
     assert np.max(np.abs(J[:, keep] - Jfd[:, keep])) <= 1e-6 * max(1.0, np.max(np.abs(Jfd)))
     assert np.max(np.abs(J[:, 24] - Jfd[:, 24])) > 1e-3      # the documented omission is really there
+
+
+def test_covid19_model_and_segments(built):
+    from oracle.oracle import MODEL_COVID
+    o = Oracle(MODEL_COVID, params=[3.4, 14, 5, 1, 0.1, 1, -10, 20])
+    X = GOLD["c_X"]
+    for i in range(32):
+        assert same(o.rhs(0.0, X[i]), GOLD["c_rhs"][i])
+        assert same(o.control(0.0, X[i]), GOLD["c_ctl"][i])
+        assert same(o.hamiltonian(0.0, X[i])[0], GOLD["c_ham"][i])
+    u = GOLD["c_ctl"][:, 0]
+    assert np.any(u == -10) and np.any(u == 20) and np.any((u > -10) & (u < 20))      # all three control regimes
+    for i in range(6):
+        assert same(o.traj(0.0, GOLD["c_traj_X0"][i], 1.5), GOLD["c_traj"][i])
+
+
+def test_dopri5_restatement_converges_like_a_54_pair(built):
+    """[ext] Boost.Odeint absent: the adaptive integrator is a restatement of its published controlled
+    Dormand-Prince stepper.  Checked the only way possible offline: global error vs a 1e5-step RK4 solution
+    falls with the tolerance, and is comparable with SciPy's RK45 (same tableau, different controller)."""
+    from scipy.integrate import solve_ivp
+    o = Oracle(MODEL_GODDARD, step_nbr=10)
+    o.set_param("mu2", 1.0)
+    fine = Oracle(MODEL_GODDARD, step_nbr=100000)
+    fine.set_param("mu2", 1.0)
+    X0 = GOLD["g_traj_X0"][0]
+    ref = fine.traj(0.0, X0, 0.2640825)
+    prev = None
+    for tol in (1e-6, 1e-8, 1e-10):
+        X, steps, rej = o.traj_dopri5(0.0, X0, 0.2640825, tol)
+        err = np.max(np.abs(X - ref))
+        sp = solve_ivp(lambda t, x: o.rhs(t, x), (0.0, 0.2640825), X0, method="RK45", rtol=tol, atol=tol)
+        err_sp = np.max(np.abs(sp.y[:, -1] - ref))
+        assert steps > 0 and err <= 100 * tol and err <= 3 * err_sp
+        if prev is not None:
+            assert err < prev / 20          # two decades of tolerance buy > 1.3 decades of accuracy
+        prev = err
+    assert np.array_equal(o.traj_dopri5(0.1, X0, 0.1, 1e-8)[0], X0)      # zero-length segment: untouched
