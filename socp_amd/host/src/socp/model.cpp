@@ -33,6 +33,8 @@ socp_ctx *model::DeviceContext() const
     const int np = DeviceParams(p, 16);
     if (socp_ctx_set_params(deviceCtx_, p, np) != SOCP_OK || socp_ctx_set_step_number(deviceCtx_, DeviceStepNumber()) != SOCP_OK)
         throw std::runtime_error(std::string("model: ") + socp_last_error(deviceCtx_));
+    if (socp_ctx_set_integrator(deviceCtx_, AdaptiveIntegrator() ? SOCP_INT_DOPRI5 : SOCP_INT_RK4, odeIntTol) != SOCP_OK)
+        throw std::runtime_error(std::string("model: ") + socp_last_error(deviceCtx_));
     const std::vector<real> sw = DeviceSwitchingTimes();
     socp_ctx_set_switching_times(deviceCtx_, sw.data(), (int)sw.size());
     return deviceCtx_;

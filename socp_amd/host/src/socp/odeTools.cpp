@@ -21,6 +21,17 @@ odeTools::odeVector odeTools::AddState(odeVector const &X, odeVector const &Y)
 }
 
 namespace {
+#ifdef _USE_BOOST
+bool g_adaptive = true;
+#else
+bool g_adaptive = false;
+#endif
+}  // namespace
+
+void odeTools::UseAdaptiveIntegrator(bool on) { g_adaptive = on; }
+bool odeTools::AdaptiveIntegrator() { return g_adaptive; }
+
+namespace {
 [[noreturn]] void no_host_rk(const char *name)
 {
     throw std::logic_error(std::string("odeTools::") + name +
@@ -68,6 +79,7 @@ void odeTools::integrate(modelStruct const &_model, odeVector &X, double const &
     if (!(dt == dt_model))
         throw std::runtime_error("odeTools::integrate: dt must equal (tf - t0)/DeviceStepNumber() for the device path");
     if (_model.m_isJac) throw std::runtime_error("odeTools::integrate: tracing the variational state is not supported");
+    if (AdaptiveIntegrator()) throw std::runtime_error("odeTools::integrate: trace replay is available with the fixed-step integrator only");
     socp_ctx *ctx = m->DeviceContext();
     const int S = (int)X.size();
     const int cap = m->DeviceStepNumber() + 2;

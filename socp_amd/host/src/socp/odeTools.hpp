@@ -41,6 +41,12 @@ public:
 
     virtual void SetODEIntPrecision(real const &xtol) { odeIntTol = xtol; }
 
+    // The reference picks its integrator at compile time: fixed-step RK4, or Boost.Odeint's adaptive
+    // Dormand-Prince 5(4) with abs = rel = odeIntTol when built with -D_USE_BOOST (odeTools.cpp:11-15,129-134).
+    // Here the same macro selects the default and the choice can also be made at run time (addition).
+    static void UseAdaptiveIntegrator(bool on);
+    static bool AdaptiveIntegrator();
+
     // dX/dt = Model(t, X); isJac = 1 asks for the variational system (odeTools.hpp:82)
     virtual odeVector Model(real const &t, odeVector const &X, int isJac = 0) const = 0;
     virtual void Trace(real const &t, odeVector const &X, std::stringstream &file) const = 0;

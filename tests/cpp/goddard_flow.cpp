@@ -77,6 +77,7 @@ int main(int argc, char **argv)
     const std::string extra = argc > a + 3 ? argv[a + 3] : "";
 
     const std::string trace = single ? (argc > a + 4 ? argv[a + 4] : "") : extra;
+    if (std::getenv("SOCP_FLOW_ADAPTIVE")) odeTools::UseAdaptiveIntegrator(true);     // the -D_USE_BOOST configuration
     goddard my_goddard(trace, stepNbr);
     const int dim = my_goddard.GetDim();
     my_goddard.SetParameterDataName("mu2", 1.0);

@@ -319,7 +319,10 @@ def test_dopri5_against_oracle_and_tolerance(gctx, goracle):
         Xg = gctx.integrate_batch(0.0, GODDARD_TF, X0)
         Xc = np.stack([goracle.traj_dopri5(0.0, X0[b], GODDARD_TF, tol)[0] for b in range(B)])
         assert np.all(np.isfinite(Xg))
-        assert relerr(Xg, Xc) <= 100 * tol * 1e-2          # same step sequence up to rounding
+        # same algorithm, but `pow` and exp round differently, so a step-size or an accept/reject decision
+        # can differ: two tol-accurate solutions agree at the tolerance level, not at rounding level
+        # (global error of this pair on this problem is ~30 x tol: tests/test_oracle.py)
+        assert relerr(Xg, Xc) <= 100 * tol
         assert relerr(Xg[:4], fine) <= 200 * tol           # and a tol-accurate solution
     # zero-length and backward segments take no step
     t0 = np.array([0.1, 0.2]); tf = np.array([0.1, 0.1])

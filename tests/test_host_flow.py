@@ -125,3 +125,18 @@ def test_trace_replay(tmp_path):
     want = np.array(want)
     # "%g"-style output: 6 significant digits per entry
     assert np.all(np.abs(rows - want) <= 1e-5 * np.abs(want) + 1e-12)
+
+
+def test_flow_with_adaptive_integrator(tmp_path):
+    """The -D_USE_BOOST configuration of the reference (adaptive Dormand-Prince, tolerance = solver xtol,
+    shooting.cpp:447-450) through the host mirror: the KD continuation stage converges, and to the solution
+    of the fixed-step problem up to the discretisation difference between RK4 with 10 steps and a 1e-8 pair."""
+    g = SINGLE[(2, 1e-6)]
+    zf = tmp_path / "z.txt"
+    zf.write_text(" ".join(repr(v) for v in g["init_z"]))
+    exe = os.path.join(BIN, "goddard_flow")
+    out = subprocess.run([exe, "stage", "2", "10", "1", "1e-8", str(zf)], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, SOCP_FLOW_ADAPTIVE="1"))
+    stages = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and stages[0]["info"] == 1, out.stderr
+    assert rel(stages[0]["z"], g["z"]) <= 5e-2
