@@ -42,7 +42,13 @@ def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
-            raise ImportError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
+            # a source-only checkout: compile the HIP library now (hipcc cross-compiles gfx950 anywhere)
+            import subprocess
+            try:
+                subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "csrc")])
+            except Exception as exc:
+                raise ImportError("%s is not built and building it failed (%s): run "
+                                  "`python -c 'import __graft_entry__ as g; g.build()'`" % (LIB_PATH, exc))
         # One HIP runtime per process: the PyTorch wheel bundles its own libamdhip64 (same soname as
         # /opt/rocm's).  Importing torch FIRST makes the loader bind this library to that copy, so
         # torch tensors/streams and our kernels share one runtime; the other order gives two runtimes

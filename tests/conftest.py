@@ -13,6 +13,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _artefacts():
+    """Source-only checkout: build the product libraries and the test programs once."""
+    need = [os.path.join(ROOT, "socp_amd", "_build", n) for n in
+            ("libsocp_hip.so", "libsocp_host.so", "bin/goddard_flow", "bin/dint_flow", "bin/covid_flow")]
+    if not all(os.path.exists(p) for p in need):
+        import __graft_entry__
+        __graft_entry__.build()
+    return True
+
+
 @pytest.fixture(scope="session")
 def built():
     """Make sure the checker library exists (the product library is built by __graft_entry__.build())."""

@@ -1,0 +1,66 @@
+"""GPU: error behaviour of the C-ABI -- bad arguments and unsupported combinations are reported through
+status codes and socp_last_error, never by crashing or by silently computing something else."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_status_codes_and_messages():
+    from socp_amd import capi
+    L = capi.lib()
+    with pytest.raises(capi.SocpError) as e:
+        capi.Context(99)
+    assert e.value.code == capi.ERR_UNSUPPORTED
+    ctx = capi.Context(capi.MODEL_GODDARD)
+    with pytest.raises(capi.SocpError) as e:
+        ctx.set_params([1.0, 2.0])                       # wrong parameter count
+    assert e.value.code == capi.ERR_ARG and "parameter count" in str(e.value)
+    with pytest.raises(capi.SocpError):
+        ctx.set_step_number(0)
+    with pytest.raises(capi.SocpError) as e:
+        ctx.residual_batch(np.zeros((1, 14)))            # no problem set yet
+    assert "no problem" in str(e.value)
+    # CONTINUOUS end node, FREE interior state, bad mode value
+    d = 7
+    with pytest.raises(capi.SocpError):
+        ctx.problem_set([capi.FIXED, capi.CONTINUOUS], np.zeros((2, d), dtype=np.int32), [0.0, 1.0], np.zeros((2, 14)))
+    mx = np.zeros((3, d), dtype=np.int32)
+    mx[1, 0] = capi.FREE
+    with pytest.raises(capi.SocpError) as e:
+        ctx.problem_set([capi.FIXED, capi.CONTINUOUS, capi.FIXED], mx, [0.0, 0.5, 1.0], np.zeros((3, 14)))
+    assert e.value.code == capi.ERR_UNSUPPORTED
+    mx[1, 0] = 7
+    with pytest.raises(capi.SocpError):
+        ctx.problem_set([capi.FIXED, capi.CONTINUOUS, capi.FIXED], mx, [0.0, 0.5, 1.0], np.zeros((3, 14)))
+    # goddard has no variational equations (modelOrder 0)
+    with pytest.raises(capi.SocpError) as e:
+        ctx.integrate_batch(0.0, 0.1, np.zeros((1, 14)), is_jac=1)
+    assert e.value.code == capi.ERR_UNSUPPORTED
+    with pytest.raises(capi.SocpError):
+        ctx.set_integrator(capi.INT_DOPRI5, 0.0)
+    with pytest.raises(capi.SocpError):
+        ctx.set_variant(17)
+    # null pointers
+    assert L.socp_integrate_batch(ctx.h, 4, None, None, None, None, None, 0) == capi.ERR_ARG
+    assert L.socp_ctx_destroy(None) == capi.OK
+    ctx.close()
+
+
+def test_nan_and_empty_inputs_do_not_hang():
+    """NaN states propagate (the reference does the same, SURVEY 8b 'Error conventions'); an empty batch
+    is a no-op; the adaptive integrator poisons a row it cannot step instead of looping."""
+    from socp_amd import capi
+    ctx = capi.Context(capi.MODEL_GODDARD)
+    ctx.set_param("mu2", 1.0)
+    X0 = np.full((3, 14), np.nan)
+    X0[1] = [0.999949994, 1e-4, 0.01, 1e-10, 1e-10, 1e-10, 1.0, -8.12, 7.8e-3, 0.78, -0.48, 5.7e-4, 5.7e-2, 0.0996]
+    Xf = ctx.integrate_batch(0.0, 0.1, X0)
+    assert np.all(np.isnan(Xf[0])) and np.all(np.isfinite(Xf[1])) and np.all(np.isnan(Xf[2]))
+    assert ctx.integrate_batch(0.0, 0.1, np.empty((0, 14))).shape == (0, 14)
+    ctx.set_integrator(capi.INT_DOPRI5, 1e-8)
+    Xa = ctx.integrate_batch(0.0, 0.1, X0)
+    assert np.all(np.isnan(Xa[0])) and np.all(np.isfinite(Xa[1]))
+    ctx.close()
