@@ -20,9 +20,10 @@ def test_status_codes_and_messages():
     assert e.value.code == capi.ERR_ARG and "parameter count" in str(e.value)
     with pytest.raises(capi.SocpError):
         ctx.set_step_number(0)
-    with pytest.raises(capi.SocpError) as e:
-        ctx.residual_batch(np.zeros((1, 14)))            # no problem set yet
-    assert "no problem" in str(e.value)
+    buf = np.zeros(14)
+    dp = buf.ctypes.data_as(C.POINTER(C.c_double))
+    assert L.socp_residual_batch(ctx.h, 1, dp, dp) == capi.ERR_ARG          # no problem set yet
+    assert b"no problem" in L.socp_last_error(ctx.h)
     # CONTINUOUS end node, FREE interior state, bad mode value
     d = 7
     with pytest.raises(capi.SocpError):
