@@ -44,12 +44,9 @@ GODDARD_PARAMS = [3.5, 7.0, 310.0, 500.0, 1.0, 1.0, 1.0, -1.0]
 
 
 def make_starts(P, seed):
-    rng = np.random.Generator(np.random.MT19937(seed))
-    xi = rng.uniform(-1.0, 1.0, size=(P, 7))
-    Z = np.empty((P, 14))
-    Z[:, :7] = X0_STATE
-    Z[:, 7:] = PSTAR * (1.0 + 1e-3 * xi)
-    return Z
+    """Costates p*(1 + 1e-3 xi), xi from raw std::mt19937_64(seed) draws exactly as SURVEY 8d prescribes."""
+    from socp_amd.sweep import goddard_starts
+    return goddard_starts(P, 1e-3, seed)
 
 
 def setup_context(device, steps_rk4, variant):
@@ -95,6 +92,7 @@ def cpu_baseline(steps_rk4, Z, target_seconds):
         X0 = sample_rows(count)
         _, sec = ref.goddard_traj_batch(threads, steps_rk4, GODDARD_PARAMS, 0.0, TF, X0)
         return {"value": count / sec, "unit": "trajectories/s", "cores": threads, "kind": "reference",
+                "per_core": count / sec / threads,
                 "sample": "%d trajectories (FD-batch rows of the first %d starts), %d RK4 steps each, "
                           "reference model::ComputeTraj, one goddard object per std::thread, %.1f s"
                           % (count, (count + ROWS - 1) // ROWS, steps_rk4, sec)}

@@ -166,7 +166,11 @@ struct Lane {
     {
         const double dt = (tf - t0) / P.step_nbr;
         double t = t0;
-        while (t < (tf - dt / 2)) {
+        // The loop takes stepNbr steps (one more or less when rounding moves the last comparison).  The
+        // counter only stops the degenerate case the reference loops on forever -- dt below the spacing of
+        // t, where t += dt no longer advances -- because a wave that never finishes hangs the device.
+        int guard = P.step_nbr + 8;
+        while (t < (tf - dt / 2) && guard-- > 0) {
             const double step = (t + dt > tf) ? (tf - t) : dt;
             rk4(P, sw0, sw1, t, X, step);
             t += dt;
@@ -235,7 +239,8 @@ __global__ void traj_dense_kernel(ModelParams P, double t0, double tf, double sw
     int r = 1;
     const double dt = (tf - t0) / P.step_nbr;
     double t = t0;
-    while (t < (tf - dt / 2)) {
+    int guard = P.step_nbr + 8;
+    while (t < (tf - dt / 2) && guard-- > 0) {
         const double step = (t + dt > tf) ? (tf - t) : dt;
         Lane<Mdl>::rk4(P, sw0, sw1, t, X, step);
         t += dt;

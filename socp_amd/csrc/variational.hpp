@@ -85,7 +85,8 @@ __global__ __launch_bounds__(64) void traj_var_wave_kernel(ModelParams P, const 
     const double ta = t0[b], tb = tf[b];
     const double dt = (tb - ta) / P.step_nbr;
     double t = ta;
-    while (t < (tb - dt / 2)) {                         // wave-uniform: same t in every lane
+    int guard = P.step_nbr + 8;                         // see Lane::integrate: never reached unless t += dt stalls
+    while (t < (tb - dt / 2) && guard-- > 0) {          // wave-uniform: same t in every lane
         const double step = (t + dt > tb) ? (tb - t) : dt;
         const double h2 = step / 2.0;
         stage(X, F1);

@@ -21,10 +21,39 @@ TF = 0.2640825
 GODDARD_PARAMS = [3.5, 7.0, 310.0, 500.0, 1.0, 1.0, 1.0, -1.0]
 
 
+def mt19937_64(seed, count):
+    """`count` raw outputs of std::mt19937_64(seed) (the generator SURVEY 8d prescribes for the synthetic
+    starts), as uint64."""
+    NN, MM = 312, 156
+    M64 = (1 << 64) - 1
+    mt = [0] * NN
+    mt[0] = seed & M64
+    for i in range(1, NN):
+        mt[i] = (6364136223846793005 * (mt[i - 1] ^ (mt[i - 1] >> 62)) + i) & M64
+    out = np.empty(count, dtype=np.uint64)
+    idx, k = NN, 0
+    while k < count:
+        if idx >= NN:
+            for i in range(NN):
+                x = (mt[i] & 0xFFFFFFFF80000000) | (mt[(i + 1) % NN] & 0x7FFFFFFF)
+                mt[i] = mt[(i + MM) % NN] ^ (x >> 1) ^ (0xB5026F5AA96619E9 if x & 1 else 0)
+            idx = 0
+        x = mt[idx]
+        idx += 1
+        x ^= (x >> 29) & 0x5555555555555555
+        x ^= (x << 17) & 0x71D67FFFEDA60000
+        x ^= (x << 37) & 0xFFF7EEE000000000
+        x ^= x >> 43
+        out[k] = x & M64
+        k += 1
+    return out
+
+
 def goddard_starts(P, eps, seed=20250905):
-    """p = p*(1 + eps*xi), xi ~ U(-1,1); the SAME table on every rank (seeded), sliced by shard()."""
-    rng = np.random.Generator(np.random.MT19937(seed))
-    xi = rng.uniform(-1.0, 1.0, size=(P, 7))
+    """p = p*(1 + eps*xi), xi = (x >> 11) * 2^-53 * 2 - 1 from raw std::mt19937_64(seed) draws (SURVEY 8d
+    "Synthetic inputs"); the SAME table on every rank, sliced by shard()."""
+    raw = mt19937_64(seed, 7 * P)
+    xi = ((raw >> np.uint64(11)).astype(np.float64) * 2.0 ** -53 * 2.0 - 1.0).reshape(P, 7)
     Z = np.empty((P, 14))
     Z[:, :7] = X0_STATE
     Z[:, 7:] = PSTAR * (1.0 + eps * xi)

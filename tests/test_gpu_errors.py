@@ -65,3 +65,18 @@ def test_nan_and_empty_inputs_do_not_hang():
     Xa = ctx.integrate_batch(0.0, 0.1, X0)
     assert np.all(np.isnan(Xa[0])) and np.all(np.isfinite(Xa[1]))
     ctx.close()
+
+
+def test_stalled_time_loop_terminates():
+    """dt below the spacing of t: `t += dt` no longer advances and the reference's loop would spin forever
+    (odeTools.cpp:136-145).  On the device the step counter stops it; the launch must return."""
+    from socp_amd import capi
+    ctx = capi.Context(capi.MODEL_GODDARD)
+    ctx.set_param("mu2", 1.0)
+    ctx.set_step_number(10)
+    X0 = np.array([[0.999949994, 1e-4, 0.01, 1e-10, 1e-10, 1e-10, 1.0, -8.12, 7.8e-3, 0.78, -0.48, 5.7e-4, 5.7e-2, 0.0996]])
+    t0 = np.array([1.0e10])
+    tf = t0 + 1.0e-7                      # spacing of doubles at 1e10 is 1.9e-6 > dt = 1e-8
+    Xf = ctx.integrate_batch(t0, tf, X0)
+    assert Xf.shape == (1, 14)
+    ctx.close()
