@@ -8,6 +8,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -53,10 +54,12 @@ extern "C" int socp_multistart_solve(socp_ctx *ctx, int P, const double *Z0, dou
     auto cleanup = [&]() { for (socp_hybr *s : solver) socp_hybr_destroy(s); };
 
     const size_t rowB = sizeof(double) * n, jacB = rowB * n;
+    // Jacobian blocks are P*n*n doubles: stage them in chunks of at most ~256 MiB (pinned + device)
+    const int jchunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)P, ((size_t)256 << 20) / jacB));
     PinnedBuf hX, hF, hJx, hJf, hJ;
     DevBuf dX, dF, dJx, dJf, dJ;
-    if (!hX.reserve(rowB * P) || !hF.reserve(rowB * P) || !hJx.reserve(rowB * P) || !hJf.reserve(rowB * P) || !hJ.reserve(jacB * P) ||
-        !dX.alloc(rowB * P) || !dF.alloc(rowB * P) || !dJx.alloc(rowB * P) || !dJf.alloc(rowB * P) || !dJ.alloc(jacB * P)) {
+    if (!hX.reserve(rowB * P) || !hF.reserve(rowB * P) || !hJx.reserve(rowB * P) || !hJf.reserve(rowB * P) || !hJ.reserve(jacB * jchunk) ||
+        !dX.alloc(rowB * P) || !dF.alloc(rowB * P) || !dJx.alloc(rowB * P) || !dJf.alloc(rowB * P) || !dJ.alloc(jacB * jchunk)) {
         cleanup();
         return SOCP_ERR_HIP;
     }
@@ -89,7 +92,7 @@ extern "C" int socp_multistart_solve(socp_ctx *ctx, int P, const double *Z0, dou
         if (reqF.empty() && reqJ.empty()) break;
         rounds++;
         const int kF = (int)reqF.size(), kJ = (int)reqJ.size();
-        // both launches are enqueued before either result is awaited
+        // the residual launch and the first Jacobian chunk are enqueued before either result is awaited
         if (kF) {
             if (hipMemcpy(dX.p, hX.p, rowB * kF, hipMemcpyHostToDevice) != hipSuccess) { rc = SOCP_ERR_HIP; break; }
             if ((rc = socp_residual_batch_dev(ctx, kF, dX.d(), dF.d())) != SOCP_OK) break;
@@ -97,17 +100,24 @@ extern "C" int socp_multistart_solve(socp_ctx *ctx, int P, const double *Z0, dou
         if (kJ) {
             if (hipMemcpy(dJx.p, hJx.p, rowB * kJ, hipMemcpyHostToDevice) != hipSuccess ||
                 hipMemcpy(dJf.p, hJf.p, rowB * kJ, hipMemcpyHostToDevice) != hipSuccess) { rc = SOCP_ERR_HIP; break; }
-            if ((rc = socp_fd_jacobian_multi_dev(ctx, kJ, dJx.d(), dJf.d(), epsfcn, dJ.d(), dedup)) != SOCP_OK) break;
         }
-        if ((rc = socp_ctx_synchronize(ctx)) != SOCP_OK) break;
-        if (kF) {
-            if (hipMemcpy(hF.p, dF.p, rowB * kF, hipMemcpyDeviceToHost) != hipSuccess) { rc = SOCP_ERR_HIP; break; }
-            for (int k = 0; k < kF; k++) std::memcpy(outF[k], hF.d() + (size_t)k * n, rowB);
+        bool f_collected = (kF == 0);
+        for (int j0 = 0; j0 < kJ || !f_collected; j0 += jchunk) {
+            const int kc = j0 < kJ ? std::min(jchunk, kJ - j0) : 0;
+            if (kc && (rc = socp_fd_jacobian_multi_dev(ctx, kc, dJx.d() + (size_t)j0 * n, dJf.d() + (size_t)j0 * n, epsfcn,
+                                                        dJ.d(), dedup)) != SOCP_OK) break;
+            if ((rc = socp_ctx_synchronize(ctx)) != SOCP_OK) break;
+            if (!f_collected) {
+                if (hipMemcpy(hF.p, dF.p, rowB * kF, hipMemcpyDeviceToHost) != hipSuccess) { rc = SOCP_ERR_HIP; break; }
+                for (int k = 0; k < kF; k++) std::memcpy(outF[k], hF.d() + (size_t)k * n, rowB);
+                f_collected = true;
+            }
+            if (kc) {
+                if (hipMemcpy(hJ.p, dJ.p, jacB * kc, hipMemcpyDeviceToHost) != hipSuccess) { rc = SOCP_ERR_HIP; break; }
+                for (int k = 0; k < kc; k++) std::memcpy(outJ[j0 + k], hJ.d() + (size_t)k * n * n, jacB);
+            }
         }
-        if (kJ) {
-            if (hipMemcpy(hJ.p, dJ.p, jacB * kJ, hipMemcpyDeviceToHost) != hipSuccess) { rc = SOCP_ERR_HIP; break; }
-            for (int k = 0; k < kJ; k++) std::memcpy(outJ[k], hJ.d() + (size_t)k * n * n, jacB);
-        }
+        if (rc != SOCP_OK) break;
     }
     if (rc == SOCP_OK) {
         for (int p = 0; p < P; p++) {

@@ -106,3 +106,15 @@ def test_double_integrator_programs(flow, order):
             assert s["njev"] == g["njev"]
         if g["info"] == 1:
             assert np.max(np.abs(np.array(s["z"]) - np.array(g["z"]))) <= 1e-13 * np.max(np.abs(g["z"]))
+
+
+@pytest.mark.parametrize("order", [1, 0])
+def test_config3_64_segments_history(order):
+    """BASELINE config 3 (doubleIntegrator, 64 segments, n = 832), hybrj and FD/hybrd: from the WP-style
+    guess the CPU path stalls with info = 5; the device path must report the same info, counts and iterate."""
+    rc, stages, err = _run(["wp", order, 1e-8, 64])
+    gold = GOLD["wp_M64_order%d_xtol1e-08" % order]
+    assert len(stages) == 1 and stages[0]["n"] == 832, err
+    s, g = stages[0], gold[0]
+    assert (s["info"], s["nfev"]) == (g["info"], g["nfev"]) and (order == 0 or s["njev"] == g["njev"])
+    assert np.max(np.abs(np.array(s["z"]) - np.array(g["z"]))) <= 1e-13 * np.max(np.abs(g["z"]))
