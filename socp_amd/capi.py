@@ -89,6 +89,7 @@ def lib():
         L.socp_fd_rows_dev.argtypes = [_vp, C.c_int, _vp, C.c_double, _vp]
         L.socp_fd_rows.argtypes = [_vp, C.c_int, _dp, C.c_double, _dp]
         L.socp_fd_diff_dev.argtypes = [_vp, C.c_int, _vp, C.c_double, _vp, _vp]
+        L.socp_plugin_load.argtypes = [C.c_char_p]
         L.socp_multistart_solve.argtypes = [_vp, C.c_int, _dp, C.c_double, C.c_int, C.c_double, C.c_double, C.c_int,
                                             _dp, _ip, _ip, _dp, C.POINTER(C.c_longlong)]
         L.hybrd.argtypes = [FCN, _vp, C.c_int, _dp, _dp, C.c_double, C.c_int, C.c_int, C.c_int, C.c_double,
@@ -111,6 +112,13 @@ def lib():
     return _lib
 
 
+def plugin_load(path):
+    """Load an out-of-tree device model (include/socp_plugin.h); afterwards Context(model_id) works."""
+    rc = lib().socp_plugin_load(os.fsencode(path))
+    if rc != OK:
+        raise SocpError(rc, lib().socp_last_error(None).decode())
+
+
 def _d(a):
     return a.ctypes.data_as(_dp)
 
@@ -122,7 +130,7 @@ def _f64(a):
 class Context:
     """One device context = one model object with its packed parameters (socp_ctx)."""
 
-    def __init__(self, model_id, device=-1):
+    def __init__(self, model_id, device=-1, nparams=None):
         self.L = lib()
         self.h = _vp()
         rc = self.L.socp_ctx_create(C.byref(self.h), int(model_id), int(device))
@@ -133,6 +141,7 @@ class Context:
         self.model_id, self.dim, self.s, self.s_jac = model_id, dim.value, s.value, sj.value
         self.nu = self.L.socp_ctx_control_dim(self.h)
         self.n = None
+        self.nparams = nparams
 
     def close(self):
         if self.h:
@@ -155,7 +164,7 @@ class Context:
         self._chk(self.L.socp_ctx_set_params(self.h, _d(p), len(p)))
 
     def get_params(self):
-        n = 3 if self.model_id == MODEL_DOUBLE_INTEGRATOR else 8
+        n = self.nparams if self.nparams is not None else (3 if self.model_id == MODEL_DOUBLE_INTEGRATOR else 8)
         p = np.empty(n)
         self._chk(self.L.socp_ctx_get_params(self.h, _d(p), n))
         return p

@@ -12,6 +12,11 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+
+#include <map>
+
+#include "../../include/socp_plugin.h"
 #include "launch.hpp"
 
 using namespace socp;
@@ -40,6 +45,7 @@ struct DevBuf {
 
 struct socp_ctx {
     int model_id = 0;
+    const ModelLaunchers *vt = nullptr;   // out-of-tree model: its launch table (socp_plugin.h)
     int device = 0;
     int dim = 0, S = 0, nu = 3;
     int nparams = 0;
@@ -67,6 +73,12 @@ struct socp_ctx {
 };
 
 namespace {
+
+std::map<int, ModelLaunchers> &plugins()
+{
+    static std::map<int, ModelLaunchers> table;
+    return table;
+}
 
 int fail(socp_ctx *c, int code, const std::string &msg)
 {
@@ -103,6 +115,7 @@ hipError_t run_traj(socp_ctx *c, int B, const double *t0, const double *tf, cons
                     const double *X0, double *Xf)
 {
     c->n_traj += B; c->n_launch += 1;
+    if (c->vt) return c->vt->traj(c->stream, c->P, B, t0, tf, sw, X0, Xf);
     return use_fast(c) ? traj_fast(c->model_id, c->stream, c->P, B, t0, tf, sw, X0, Xf)
                        : traj_exact(c->model_id, c->stream, c->P, B, t0, tf, sw, X0, Xf);
 }
@@ -110,6 +123,7 @@ hipError_t run_traj(socp_ctx *c, int B, const double *t0, const double *tf, cons
 hipError_t run_residual(socp_ctx *c, int B, const double *Z, double *F)
 {
     c->n_traj += (long long)B * c->M; c->n_launch += 1;
+    if (c->vt) return c->vt->residual(c->stream, c->P, c->pb, B, Z, F);
     return use_fast(c) ? residual_fast(c->model_id, c->stream, c->P, c->pb, B, Z, F)
                        : residual_exact(c->model_id, c->stream, c->P, c->pb, B, Z, F);
 }
@@ -118,6 +132,7 @@ hipError_t run_fdjac(socp_ctx *c, int np, int T, const int2 *pairs, const double
                      double eps, double *fjac)
 {
     c->n_traj += (long long)np * T; c->n_launch += 1;
+    if (c->vt) return c->vt->fdjac(c->stream, c->P, c->pb, np, T, pairs, z, fvec, eps, fjac);
     return use_fast(c) ? fdjac_fast(c->model_id, c->stream, c->P, c->pb, np, T, pairs, z, fvec, eps, fjac)
                        : fdjac_exact(c->model_id, c->stream, c->P, c->pb, np, T, pairs, z, fvec, eps, fjac);
 }
@@ -125,6 +140,7 @@ hipError_t run_fdjac(socp_ctx *c, int np, int T, const int2 *pairs, const double
 hipError_t run_fdrows(socp_ctx *c, int np, const double *z, double eps, double *rows)
 {
     c->n_traj += (long long)np * (c->n + 1) * c->M; c->n_launch += 1;
+    if (c->vt) return c->vt->fdrows(c->stream, c->P, c->pb, np, z, eps, rows);
     return use_fast(c) ? fdrows_fast(c->model_id, c->stream, c->P, c->pb, np, z, eps, rows)
                        : fdrows_exact(c->model_id, c->stream, c->P, c->pb, np, z, eps, rows);
 }
@@ -141,8 +157,13 @@ int socp_ctx_create(socp_ctx **out, int model_id, int device)
 {
     if (!out) return fail(nullptr, SOCP_ERR_ARG, "socp_ctx_create: null output pointer");
     *out = nullptr;
-    if (model_id != SOCP_MODEL_GODDARD && model_id != SOCP_MODEL_DOUBLE_INTEGRATOR && model_id != SOCP_MODEL_COVID19)
-        return fail(nullptr, SOCP_ERR_UNSUPPORTED, "socp_ctx_create: unknown model id (no device dynamics)");
+    const ModelLaunchers *vt = nullptr;
+    if (model_id >= SOCP_PLUGIN_ID_MIN) {
+        auto it = plugins().find(model_id);
+        if (it != plugins().end()) vt = &it->second;
+    }
+    if (!vt && model_id != SOCP_MODEL_GODDARD && model_id != SOCP_MODEL_DOUBLE_INTEGRATOR && model_id != SOCP_MODEL_COVID19)
+        return fail(nullptr, SOCP_ERR_UNSUPPORTED, "socp_ctx_create: unknown model id (no device dynamics; plugins: socp_plugin_load)");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)
@@ -155,8 +176,13 @@ int socp_ctx_create(socp_ctx **out, int model_id, int device)
 
     socp_ctx *c = new socp_ctx;
     c->model_id = model_id;
+    c->vt = vt;
     c->device = device;
-    if (model_id == SOCP_MODEL_GODDARD) {
+    if (vt) {
+        c->dim = vt->dim; c->nparams = vt->nparams; c->nu = vt->control_dim;
+        std::memcpy(c->P.p, vt->default_params, sizeof(double) * kMaxParams);
+        c->P.sw0 = c->P.sw1 = 0.0; c->P.step_nbr = vt->default_step_nbr;
+    } else if (model_id == SOCP_MODEL_GODDARD) {
         // goddard.cpp:23-40 defaults
         c->dim = 7; c->nparams = SOCP_GODDARD_NPARAMS;
         const double d[8] = {3.5, 7.0, 310.0, 500.0, 1.0, 1.0, 0.0, -1.0};
@@ -353,7 +379,9 @@ int socp_integrate_dense(socp_ctx *c, double t0, double tf, const double *sw, co
     HIP_TRY(c, hipMemcpyAsync(c->s_in.p, X0, sizeof(double) * S, hipMemcpyHostToDevice, c->stream));
     const double s0 = sw ? sw[0] : c->P.sw0, s1 = sw ? sw[1] : c->P.sw1;
     c->n_traj += 1; c->n_launch += 1;
-    hipError_t e = use_fast(c)
+    hipError_t e = c->vt
+        ? c->vt->dense(c->stream, c->P, t0, tf, s0, s1, c->s_in.as<double>(), c->s_out.as<double>(), c->s_t0.as<double>(), cap, c->s_aux.as<int>())
+        : use_fast(c)
         ? dense_fast(c->model_id, c->stream, c->P, t0, tf, s0, s1, c->s_in.as<double>(), c->s_out.as<double>(), c->s_t0.as<double>(), cap, c->s_aux.as<int>())
         : dense_exact(c->model_id, c->stream, c->P, t0, tf, s0, s1, c->s_in.as<double>(), c->s_out.as<double>(), c->s_t0.as<double>(), cap, c->s_aux.as<int>());
     HIP_TRY(c, e);
@@ -399,6 +427,8 @@ int socp_eval_batch(socp_ctx *c, int what, int B, const double *t, const double 
     c->n_launch += 1;
     hipError_t e = var
         ? var_eval(c->model_id, c->stream, c->P, what == SOCP_EVAL_RHS ? 0 : 1, B, c->s_in.as<double>(), len, c->s_out.as<double>())
+        : c->vt
+        ? c->vt->eval(c->stream, c->P, what, B, c->s_t0.as<double>(), dsw, c->s_in.as<double>(), c->s_out.as<double>())
         : use_fast(c)
         ? eval_fast(c->model_id, c->stream, c->P, what, B, c->s_t0.as<double>(), dsw, c->s_in.as<double>(), c->s_out.as<double>())
         : eval_exact(c->model_id, c->stream, c->P, what, B, c->s_t0.as<double>(), dsw, c->s_in.as<double>(), c->s_out.as<double>());
@@ -655,6 +685,29 @@ int socp_fd_jacobian(socp_ctx *c, const double *z, const double *fvec, double ep
     HIP_TRY(c, hipMemcpyAsync(fjac, c->s_out.p, sizeof(double) * n * n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return SOCP_OK;
+}
+
+int socp_register_model(int model_id, const void *table, int table_bytes)
+{
+    if (model_id < SOCP_PLUGIN_ID_MIN) return fail(nullptr, SOCP_ERR_ARG, "register_model: ids below 100 are reserved for in-tree models");
+    if (!table || table_bytes != (int)sizeof(ModelLaunchers)) return fail(nullptr, SOCP_ERR_ARG, "register_model: launch table size mismatch (plugin built against other headers)");
+    const ModelLaunchers *t = static_cast<const ModelLaunchers *>(table);
+    if (t->abi != kPluginAbi || t->dim < 1 || 2 * t->dim > 64 || t->nparams < 0 || t->nparams > kMaxParams || t->default_step_nbr < 1 ||
+        !t->traj || !t->residual || !t->fdjac || !t->fdrows || !t->dense || !t->eval)
+        return fail(nullptr, SOCP_ERR_ARG, "register_model: malformed launch table");
+    plugins()[model_id] = *t;
+    return SOCP_OK;
+}
+
+int socp_plugin_load(const char *path)
+{
+    if (!path) return fail(nullptr, SOCP_ERR_ARG, "plugin_load: null path");
+    void *h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!h) return fail(nullptr, SOCP_ERR_ARG, std::string("plugin_load: ") + dlerror());
+    typedef int (*reg_fn)(void);
+    reg_fn reg = reinterpret_cast<reg_fn>(dlsym(h, "socp_plugin_register"));
+    if (!reg) { dlclose(h); return fail(nullptr, SOCP_ERR_ARG, "plugin_load: socp_plugin_register not exported"); }
+    return reg();        // the handle stays open: the kernels live in it
 }
 
 int socp_var_jacobian(socp_ctx *c, const double *z, double *fjac)

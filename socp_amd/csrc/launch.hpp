@@ -22,6 +22,20 @@ namespace socp {
     hipError_t eval_##FLAVOUR(int model_id, hipStream_t st, const ModelParams &P, int what, int B,   \
                               const double *t, const double *sw, const double *X, double *out);
 
+// Launch table of an out-of-tree model (include/socp_plugin.h, plugin_impl.hpp): what the C-ABI layer calls
+// instead of the built-in flavour launchers when a context is created with a registered model id.
+constexpr int kPluginAbi = 1;
+struct ModelLaunchers {
+    int abi, dim, control_dim, nparams, default_step_nbr;
+    double default_params[kMaxParams];
+    hipError_t (*traj)(hipStream_t, const ModelParams &, int, const double *, const double *, const double *, const double *, double *);
+    hipError_t (*residual)(hipStream_t, const ModelParams &, const ProblemDev &, int, const double *, double *);
+    hipError_t (*fdjac)(hipStream_t, const ModelParams &, const ProblemDev &, int, int, const int2 *, const double *, const double *, double, double *);
+    hipError_t (*fdrows)(hipStream_t, const ModelParams &, const ProblemDev &, int, const double *, double, double *);
+    hipError_t (*dense)(hipStream_t, const ModelParams &, double, double, double, double, const double *, double *, double *, int, int *);
+    hipError_t (*eval)(hipStream_t, const ModelParams &, int, int, const double *, const double *, const double *, double *);
+};
+
 SOCP_DECLARE_LAUNCHERS(exact)
 // flavour-independent: Jacobian from the rows of fdrows (differences and one division per entry)
 // variational (hybrj) path: double integrator only; reference operation order

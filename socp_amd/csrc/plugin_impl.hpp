@@ -1,0 +1,116 @@
+// plugin_impl.hpp -- build an OUT-OF-TREE device model into a loadable plugin.
+//
+// A model is one struct with the static interface the in-tree models have (models_exact.hpp):
+//
+//   struct MyModel {
+//       static constexpr int D = ...;            // state dimension d; S = 2 d (state + costate)
+//       static constexpr int S = 2 * D;
+//       static constexpr int NU = ...;           // control dimension (<= 3)
+//       static constexpr bool kRefOrder = true;  // true: RK4 in the reference's association order
+//       __device__ static void rhs(const socp::ModelParams &P, double sw0, double sw1, double t,
+//                                  const double (&X)[S], double (&dX)[S]);              // model::Model
+//       __device__ static void control_only(const socp::ModelParams &P, double sw0, double sw1, double t,
+//                                           const double (&X)[S], double (&u)[3]);      // model::Control
+//       __device__ static double hamiltonian(const socp::ModelParams &P, double sw0, double sw1, double t,
+//                                            const double (&X)[S]);                     // model::Hamiltonian
+//       __device__ static double switching_fn(const socp::ModelParams &P, double sw0, double sw1, double t,
+//                                             const double (&X)[S], const double (&Xp)[S]);  // SwitchingTimesFunction
+//   };
+//   SOCP_DEFINE_MODEL_PLUGIN(1001, MyModel, 3 /*nparams*/, 30 /*stepNbr*/, {1.0, 2.0, 3.0})
+//
+// compiled with   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared -I<repo>/socp_amd/csrc
+//                       -I<repo>/include my_model.hip -o libmy_model.so
+// and loaded with socp_plugin_load("libmy_model.so"); afterwards socp_ctx_create(&ctx, 1001, dev) gives a
+// context on which every entry point of socp_hip.h works (trajectories, residual, FD Jacobian, dense output,
+// evaluation, adaptive integrator, lock-step multi-start).
+#pragma once
+#include "integrator.hpp"
+#include "launch.hpp"
+#include "../../include/socp_plugin.h"
+
+namespace socp {
+namespace plugin {
+
+inline unsigned blocks_for(long n) { return (unsigned)((n + 63) / 64); }
+inline int wpe_for(long waves) { const long k = (waves + 1023) / 1024; return k < 1 ? 1 : (k > 3 ? 3 : (int)k); }
+
+// one launch of a hot kernel: adaptive integrator -> one wave per SIMD; otherwise occupancy cap from the grid
+#define SOCP_PLUGIN_LAUNCH(KERNEL, GRID, ST, ...)                                                              \
+    do {                                                                                                       \
+        if (P.integrator == 1) hipLaunchKernelGGL((KERNEL<Mdl, 1, 1>), dim3(GRID), dim3(64), 0, ST, __VA_ARGS__); \
+        else switch (wpe_for(GRID)) {                                                                          \
+        case 1: hipLaunchKernelGGL((KERNEL<Mdl, 1, 0>), dim3(GRID), dim3(64), 0, ST, __VA_ARGS__); break;       \
+        case 2: hipLaunchKernelGGL((KERNEL<Mdl, 2, 0>), dim3(GRID), dim3(64), 0, ST, __VA_ARGS__); break;       \
+        default: hipLaunchKernelGGL((KERNEL<Mdl, 3, 0>), dim3(GRID), dim3(64), 0, ST, __VA_ARGS__); break;      \
+        }                                                                                                      \
+    } while (0)
+
+template <class Mdl>
+hipError_t traj(hipStream_t st, const ModelParams &P, int B, const double *t0, const double *tf, const double *sw,
+                const double *X0, double *Xf)
+{
+    if (B <= 0) return hipSuccess;
+    SOCP_PLUGIN_LAUNCH(traj_lane_kernel, blocks_for(B), st, P, B, t0, tf, sw, X0, Xf);
+    return hipGetLastError();
+}
+template <class Mdl>
+hipError_t residual(hipStream_t st, const ModelParams &P, const ProblemDev &pb, int B, const double *Z, double *F)
+{
+    if (B <= 0) return hipSuccess;
+    SOCP_PLUGIN_LAUNCH(residual_lane_kernel, blocks_for((long)B * pb.M), st, P, pb, B, Z, F);
+    return hipGetLastError();
+}
+template <class Mdl>
+hipError_t fdjac(hipStream_t st, const ModelParams &P, const ProblemDev &pb, int np, int T, const int2 *pairs,
+                 const double *z, const double *fvec, double eps, double *fjac)
+{
+    if (np <= 0 || T <= 0) return hipSuccess;
+    SOCP_PLUGIN_LAUNCH(fdjac_lane_kernel, blocks_for((long)np * T), st, P, pb, np, T, pairs, z, fvec, eps, fjac);
+    return hipGetLastError();
+}
+template <class Mdl>
+hipError_t fdrows(hipStream_t st, const ModelParams &P, const ProblemDev &pb, int np, const double *z, double eps, double *rows)
+{
+    if (np <= 0) return hipSuccess;
+    SOCP_PLUGIN_LAUNCH(fdrows_lane_kernel, blocks_for((long)np * (pb.n + 1) * pb.M), st, P, pb, np, z, eps, rows);
+    return hipGetLastError();
+}
+template <class Mdl>
+hipError_t dense(hipStream_t st, const ModelParams &P, double t0, double tf, double sw0, double sw1, const double *X0,
+                 double *out, double *times, int cap, int *rows)
+{
+    hipLaunchKernelGGL(traj_dense_kernel<Mdl>, dim3(1), dim3(64), 0, st, P, t0, tf, sw0, sw1, X0, out, times, cap, rows);
+    return hipGetLastError();
+}
+template <class Mdl>
+hipError_t eval(hipStream_t st, const ModelParams &P, int what, int B, const double *t, const double *sw, const double *X, double *out)
+{
+    if (B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(eval_lane_kernel<Mdl>, dim3(blocks_for(B)), dim3(64), 0, st, P, what, B, t, sw, X, out);
+    return hipGetLastError();
+}
+
+template <class Mdl>
+ModelLaunchers table(int nparams, int step_nbr, std::initializer_list<double> defaults)
+{
+    static_assert(Mdl::S == 2 * Mdl::D, "state vector is [state ; costate]");
+    static_assert(Mdl::NU >= 1 && Mdl::NU <= 3, "control dimension 1..3");
+    ModelLaunchers t{};
+    t.abi = kPluginAbi; t.dim = Mdl::D; t.control_dim = Mdl::NU; t.nparams = nparams; t.default_step_nbr = step_nbr;
+    int i = 0;
+    for (double v : defaults) if (i < kMaxParams) t.default_params[i++] = v;
+    t.traj = &traj<Mdl>; t.residual = &residual<Mdl>; t.fdjac = &fdjac<Mdl>; t.fdrows = &fdrows<Mdl>;
+    t.dense = &dense<Mdl>; t.eval = &eval<Mdl>;
+    return t;
+}
+
+}  // namespace plugin
+}  // namespace socp
+
+// defines the entry point socp_plugin_load() looks for
+#define SOCP_DEFINE_MODEL_PLUGIN(MODEL_ID, MDL, NPARAMS, STEP_NBR, ...)                                   \
+    extern "C" int socp_plugin_register(void)                                                             \
+    {                                                                                                     \
+        static const socp::ModelLaunchers t = socp::plugin::table<MDL>(NPARAMS, STEP_NBR, __VA_ARGS__);   \
+        return socp_register_model(MODEL_ID, &t, (int)sizeof(t));                                         \
+    }

@@ -1,0 +1,35 @@
+// lqr1d_plugin.hip -- example of an OUT-OF-TREE device model (include/socp_plugin.h):
+// minimum-energy transfer of a 1-D double integrator,  x' = v, v' = u, cost = int u^2/2,
+// Pontryagin: u = -p_v, p_x' = 0, p_v' = -p_x, H = u^2/2 + p_x v + p_v u.
+// State vector [x, v ; p_x, p_v].  One parameter: a control gain g (u = -g p_v, default 1).
+#include "plugin_impl.hpp"
+
+struct Lqr1D {
+    static constexpr int D = 2;
+    static constexpr int S = 4;
+    static constexpr int NU = 1;
+    static constexpr bool kRefOrder = true;
+
+    __device__ static void control_only(const socp::ModelParams &P, double, double, double, const double (&X)[S], double (&u)[3])
+    {
+        u[0] = -P.p[0] * X[3]; u[1] = 0; u[2] = 0;
+    }
+    __device__ static void rhs(const socp::ModelParams &P, double, double, double, const double (&X)[S], double (&dX)[S])
+    {
+        dX[0] = X[1];
+        dX[1] = -P.p[0] * X[3];
+        dX[2] = 0;
+        dX[3] = -X[2];
+    }
+    __device__ static double hamiltonian(const socp::ModelParams &P, double, double, double, const double (&X)[S])
+    {
+        const double u = -P.p[0] * X[3];
+        return u * u / 2 + X[2] * X[1] + X[3] * u;
+    }
+    __device__ static double switching_fn(const socp::ModelParams &P, double a, double b, double t, const double (&X)[S], const double (&Xp)[S])
+    {
+        return hamiltonian(P, a, b, t, X) - hamiltonian(P, a, b, t, Xp);
+    }
+};
+
+SOCP_DEFINE_MODEL_PLUGIN(1001, Lqr1D, 1, 20, {1.0})

@@ -1,0 +1,62 @@
+"""GPU: out-of-tree device model (include/socp_plugin.h).  A 1-D minimum-energy double integrator is built
+as a plugin and driven (a) through the C-ABI and (b) through a user-defined `model` subclass + `shooting`.
+Analytic solution for rest-to-rest x: 0 -> 1 in T = 1: p_x = -12, p_v(0) = -6, u(0) = 6 (RK4 integrates
+this cubic exactly up to rounding)."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PLUGIN = os.path.join(ROOT, "socp_amd", "_build", "plugins", "liblqr1d_plugin.so")
+
+
+def test_plugin_through_c_abi():
+    from socp_amd import capi
+    capi.plugin_load(PLUGIN)
+    ctx = capi.Context(1001, nparams=1)
+    assert (ctx.dim, ctx.s, ctx.nu) == (2, 4, 1)
+    X = np.array([[0.3, -0.2, 2.0, 5.0]])
+    assert np.array_equal(ctx.eval_batch(capi.EVAL_RHS, 0.0, X), [[-0.2, -5.0, 0.0, -2.0]])
+    assert np.array_equal(ctx.eval_batch(capi.EVAL_CONTROL, 0.0, X), [[-5.0]])
+    # single shooting, fixed end state: unknowns are the initial state + costate
+    mode_x = np.zeros((2, 2), dtype=np.int32)
+    Xn = np.zeros((2, 4))
+    Xn[1, 0] = 1.0
+    assert ctx.problem_set([capi.FIXED, capi.FIXED], mode_x, [0.0, 1.0], Xn) == 4
+    out = capi.hybrd(lambda v: ctx.residual(v), np.array([0.0, 0.0, -1.0, -1.0]), xtol=1e-12, epsfcn=1e-15,
+                     fdjac=lambda x, f, e: ctx.fd_jacobian(x, f, epsfcn=e))
+    assert out["info"] == 1
+    assert np.allclose(out["x"], [0.0, 0.0, -12.0, -6.0], rtol=0, atol=1e-9)
+    # the other entry points work for a plugin model too: adaptive integrator, dense output, lock-step multi-start
+    Xf = ctx.integrate_batch(0.0, 1.0, out["x"][None, :])
+    assert np.allclose(Xf[0, :2], [1.0, 0.0], atol=1e-10)
+    ctx.set_integrator(capi.INT_DOPRI5, 1e-10)
+    assert np.allclose(ctx.integrate_batch(0.0, 1.0, out["x"][None, :])[0, :2], [1.0, 0.0], atol=1e-8)
+    ctx.set_integrator(capi.INT_RK4)
+    times, dense = ctx.integrate_dense(0.0, 1.0, out["x"])
+    assert len(times) == 21 and np.allclose(dense[-1], Xf[0])
+    starts = np.tile([0.0, 0.0, -1.0, -1.0], (9, 1)) + np.linspace(0, 1, 9)[:, None] * [0, 0, -3.0, 2.0]
+    ms = ctx.multistart_solve(starts, xtol=1e-12)
+    assert np.all(ms["info"] == 1) and np.allclose(ms["z"][:, 2:], [-12.0, -6.0], atol=1e-8)
+    ctx.close()
+
+
+@pytest.mark.parametrize("M", [1, 4])
+def test_user_model_class_with_plugin(M):
+    exe = os.path.join(ROOT, "socp_amd", "_build", "bin", "plugin_flow")
+    out = subprocess.run([exe, PLUGIN, str(M)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    assert r["info"] == 1 and r["n"] == 4 * M
+    assert abs(r["p_x"] + 12.0) <= 1e-8 and abs(r["p_v"] + 6.0) <= 1e-8 and abs(r["u0"] - 6.0) <= 1e-8
+
+
+def test_unregistered_id_is_rejected():
+    from socp_amd import capi
+    with pytest.raises(capi.SocpError) as e:
+        capi.Context(4242)
+    assert e.value.code == capi.ERR_UNSUPPORTED
