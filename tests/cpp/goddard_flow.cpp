@@ -7,6 +7,7 @@
 //                       85 unknowns in <zfile> (node states + tf), the state testGoddard.cpp is in
 //                       just before its k-th SolveOCP call
 // Run by tests/test_host_flow.py on the GPU box; expected solutions are in tests/golden/.
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -20,13 +21,24 @@
 
 namespace {
 const int kMulti = 6;
+void report_body(const char *stage, int info, const shooting &s);
+
+std::chrono::steady_clock::time_point g_tic = std::chrono::steady_clock::now();
 
 void report(const char *stage, int info, const shooting &s)
+{
+    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - g_tic).count();
+    g_tic = std::chrono::steady_clock::now();
+    std::printf("{\"seconds\": %.6f, ", sec);
+    report_body(stage, info, s);
+}
+
+void report_body(const char *stage, int info, const shooting &s)
 {
     std::vector<real> z;
     s.GetParameters(z);
     std::vector<int> calls = s.GetCallNumber();
-    std::printf("{\"stage\": \"%s\", \"info\": %d, \"nfev\": %d, \"n\": %d, \"trajectories\": %lld, \"z\": [", stage, info,
+    std::printf("\"stage\": \"%s\", \"info\": %d, \"nfev\": %d, \"n\": %d, \"trajectories\": %lld, \"z\": [", stage, info,
                 calls[0], (int)z.size(), s.GetTrajectoryCount());
     for (size_t k = 0; k < z.size(); k++) std::printf("%s%.17g", k ? ", " : "", z[k]);
     std::printf("]}\n");
