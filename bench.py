@@ -175,8 +175,9 @@ def main():
         ctx.fd_diff_dev(P, d_Z.data_ptr(), epsfcn, d_rows.data_ptr(), d_J.data_ptr())
 
     def fence():
+        torch.cuda.synchronize(dev)          # this rank's own launches are done ...
         if world > 1:
-            dist.barrier()
+            dist.barrier()                   # ... and so are everybody else's
         torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
