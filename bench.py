@@ -240,6 +240,11 @@ def main():
                          "flop_per_trajectory": FLOP_PER_TRAJ,
                          "hbm": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                  "frac": gbs / PEAK_HBM_GBS, "bytes_per_trajectory": BYTES_PER_TRAJ}},
+            # Newton-level rate and wave occupancy beside the trajectory rate
+            "jacobians_per_s": P * world * args.steps / elapsed_max,
+            "occupancy": {"waves_per_launch": (traj_per_step_rank + 63) // 64,
+                          "waves_per_simd_cap": min(3 if args.variant == "fast" else 2, max(1, -(-((traj_per_step_rank + 63) // 64) // 1024))),
+                          "simds": 1024},
             "finite_jacobians": [int(r[1]) for r in recs],
         }
         if world == 1 and args.single_problem:
