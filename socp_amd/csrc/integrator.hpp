@@ -336,20 +336,48 @@ __device__ __forceinline__ void segment_residual(const ModelParams &P, const Pro
     }
 }
 
-// K_res: Z[B][n] -> F[B][n]; trajectory index T = row*M + segment.
+// Row-owned tiles.  A workgroup of the residual kernels owns R = min(64 / M, ...) WHOLE residual rows: lane
+// l < R*M integrates segment l % M of local row l / M and drops the residual entries it owns into an LDS
+// tile [R][n]; after the barrier the tile -- one contiguous R*n*8-byte span of the output -- is stored with
+// consecutive lanes on consecutive doubles, i.e. as full cache lines (direct per-lane stores are 8 bytes at
+// a stride of n*8 and cost ~1.7x the algorithmic write traffic, profiles/r01).  rows_per_block = 0 selects
+// the direct form (problems whose row tile would not fit the LDS budget, or M > 64).
+__device__ __forceinline__ void store_tile(const double *tile, double *dst, long count)
+{
+    for (long idx = threadIdx.x; idx < count; idx += 64) dst[idx] = tile[idx];
+}
+
+// K_res: Z[B][n] -> F[B][n]; one lane = (row, segment).
 template <class Mdl, int WPE, int INTEG = 0>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, WPE))) void residual_lane_kernel(ModelParams P, ProblemDev pb, int B,
                                                               const double *__restrict__ Z,
-                                                              double *__restrict__ F)
+                                                              double *__restrict__ F, int rows_per_block)
 {
-    const long T = (long)blockIdx.x * 64 + threadIdx.x;
-    if (T >= (long)B * pb.M) return;
-    const long b = T / pb.M;
-    const int i = (int)(T - b * pb.M);
-    const double *zr = Z + b * pb.n;
-    double *fr = F + b * pb.n;
-    auto z = [=](int k) -> double { return zr[k]; };
-    segment_residual<Mdl, INTEG>(P, pb, z, i, [=](int row, double v) { fr[row] = v; });
+    extern __shared__ __attribute__((aligned(16))) double tile[];
+    const int M = pb.M, n = pb.n;
+    if (rows_per_block == 0) {
+        const long T = (long)blockIdx.x * 64 + threadIdx.x;
+        if (T >= (long)B * M) return;
+        const long b = T / M;
+        const int i = (int)(T - b * M);
+        const double *zr = Z + b * n;
+        double *fr = F + b * n;
+        auto z = [=](int k) -> double { return zr[k]; };
+        segment_residual<Mdl, INTEG>(P, pb, z, i, [=](int row, double v) { fr[row] = v; });
+        return;
+    }
+    const long row0 = (long)blockIdx.x * rows_per_block;
+    const int rows = (B - row0) < rows_per_block ? (int)(B - row0) : rows_per_block;
+    const int lane = threadIdx.x;
+    if (lane < rows * M) {
+        const int lr = lane / M, i = lane - lr * M;
+        const double *zr = Z + (row0 + lr) * n;
+        double *tr = tile + (long)lr * n;
+        auto z = [=](int k) -> double { return zr[k]; };
+        segment_residual<Mdl, INTEG>(P, pb, z, i, [=](int row, double v) { tr[row] = v; });
+    }
+    __syncthreads();
+    store_tile(tile, F + row0 * n, (long)rows * n);
 }
 
 // MINPACK fdjac1 step: h = eps*|z_j|, or eps when that is zero
@@ -386,25 +414,41 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, WPE))) vo
 
 // K_fdr: the (n+1) residual rows of a forward-difference Jacobian -- row 0 at z, row j+1 at
 // z + h_j e_j -- for `np` problems in ONE launch (no dependency between base and perturbed
-// trajectories).  Rows[np][n+1][n]; the perturbation matrix is generated on the fly.
+// trajectories).  Rows[np][n+1][n]; the perturbation matrix is generated on the fly; output through
+// row-owned LDS tiles (see above) so that the residual rows are written as full lines.
 template <class Mdl, int WPE, int INTEG = 0>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, WPE))) void fdrows_lane_kernel(ModelParams P, ProblemDev pb, int np,
                                                             const double *__restrict__ Zb, double eps,
-                                                            double *__restrict__ Rows)
+                                                            double *__restrict__ Rows, int rows_per_block)
 {
-    const long tid = (long)blockIdx.x * 64 + threadIdx.x;
-    const int per = (pb.n + 1) * pb.M;
-    if (tid >= (long)np * per) return;
-    const long prob = tid / per;
-    const int rem = (int)(tid - prob * per);
-    const int row = rem / pb.M;                 // 0 = base, j+1 = column j
-    const int i = rem - row * pb.M;
-    const int j = row - 1;
-    const double *zb = Zb + prob * pb.n;
-    const double zj = j >= 0 ? zb[j] + fd_step(zb[j], eps) : 0.0;
-    auto z = [=](int k) -> double { const double v = zb[k]; return k == j ? zj : v; };
-    double *out = Rows + (prob * (pb.n + 1) + row) * (long)pb.n;
-    segment_residual<Mdl, INTEG>(P, pb, z, i, [=](int r, double v) { out[r] = v; });
+    extern __shared__ __attribute__((aligned(16))) double tile[];
+    const int M = pb.M, n = pb.n;
+    const long total_rows = (long)np * (n + 1);          // virtual residual rows: (problem, FD row)
+    auto run = [&](long vrow, int i, double *out) {
+        const long prob = vrow / (n + 1);
+        const int row = (int)(vrow - prob * (n + 1));    // 0 = base, j+1 = column j
+        const int j = row - 1;
+        const double *zb = Zb + prob * n;
+        const double zj = j >= 0 ? zb[j] + fd_step(zb[j], eps) : 0.0;
+        auto z = [=](int k) -> double { const double v = zb[k]; return k == j ? zj : v; };
+        segment_residual<Mdl, INTEG>(P, pb, z, i, [=](int r, double v) { out[r] = v; });
+    };
+    if (rows_per_block == 0) {
+        const long tid = (long)blockIdx.x * 64 + threadIdx.x;
+        if (tid >= total_rows * M) return;
+        const long vrow = tid / M;
+        run(vrow, (int)(tid - vrow * M), Rows + vrow * n);
+        return;
+    }
+    const long row0 = (long)blockIdx.x * rows_per_block;
+    const int rows = (total_rows - row0) < rows_per_block ? (int)(total_rows - row0) : rows_per_block;
+    const int lane = threadIdx.x;
+    if (lane < rows * M) {
+        const int lr = lane / M;
+        run(row0 + lr, lane - lr * M, tile + (long)lr * n);
+    }
+    __syncthreads();
+    store_tile(tile, Rows + row0 * n, (long)rows * n);
 }
 
 #ifdef SOCP_DEFINE_COMMON

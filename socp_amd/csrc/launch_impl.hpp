@@ -19,6 +19,17 @@ static inline unsigned blocks_for(long n) { return (unsigned)((n + 63) / 64); }
 // SIMD, up to 2048 two per SIMD, beyond that three.
 constexpr int kNumSIMD = 1024;
 
+// rows per workgroup of the row-owned-tile kernels (integrator.hpp): whole rows, M lanes each, tile <= 32 KiB;
+// 0 = direct stores
+static inline int rows_per_block(int M, int n)
+{
+    if (M > 64) return 0;
+    int R = 64 / M;
+    const long bytes = (long)R * n * 8;
+    if (bytes > 32 * 1024) R = (int)(32 * 1024 / ((long)n * 8));
+    return R < 1 ? 0 : R;
+}
+
 static inline int wpe_for(long waves)
 {
     const long k = (waves + kNumSIMD - 1) / kNumSIMD;
@@ -28,30 +39,31 @@ static inline int wpe_for(long waves)
 // SOCP_HAVE_DOPRI5: this translation unit also carries the adaptive-integrator instantiations (one wave per
 // SIMD: seven stage vectors live in registers)
 #ifdef SOCP_HAVE_DOPRI5
-#define SOCP_LAUNCH_ADAPTIVE(KERNEL, MDL, GRID, ST, ...) \
-    if (P.integrator == 1) { hipLaunchKernelGGL((KERNEL<MDL, 1, 1>), dim3(GRID), dim3(64), 0, ST, __VA_ARGS__); break; }
+#define SOCP_LAUNCH_ADAPTIVE(KERNEL, MDL, GRID, LDS, ST, ...) \
+    if (P.integrator == 1) { hipLaunchKernelGGL((KERNEL<MDL, 1, 1>), dim3(GRID), dim3(64), LDS, ST, __VA_ARGS__); break; }
 #else
-#define SOCP_LAUNCH_ADAPTIVE(KERNEL, MDL, GRID, ST, ...)
+#define SOCP_LAUNCH_ADAPTIVE(KERNEL, MDL, GRID, LDS, ST, ...)
 #endif
 
-#define SOCP_LAUNCH_MDL(KERNEL, MDL, WAVES, GRID, ST, ...)                                               \
-    do {                                                                                                \
-        SOCP_LAUNCH_ADAPTIVE(KERNEL, MDL, GRID, ST, __VA_ARGS__)                                        \
-        switch (wpe_for(WAVES)) {                                                                       \
-        case 1: hipLaunchKernelGGL((KERNEL<MDL, 1>), dim3(GRID), dim3(64), 0, ST, __VA_ARGS__); break;  \
-        case 2: hipLaunchKernelGGL((KERNEL<MDL, 2>), dim3(GRID), dim3(64), 0, ST, __VA_ARGS__); break;  \
-        default: hipLaunchKernelGGL((KERNEL<MDL, 3>), dim3(GRID), dim3(64), 0, ST, __VA_ARGS__); break; \
-        }                                                                                               \
+#define SOCP_LAUNCH_MDL(KERNEL, MDL, WAVES, GRID, LDS, ST, ...)                                            \
+    do {                                                                                                  \
+        SOCP_LAUNCH_ADAPTIVE(KERNEL, MDL, GRID, LDS, ST, __VA_ARGS__)                                     \
+        switch (wpe_for(WAVES)) {                                                                         \
+        case 1: hipLaunchKernelGGL((KERNEL<MDL, 1>), dim3(GRID), dim3(64), LDS, ST, __VA_ARGS__); break;  \
+        case 2: hipLaunchKernelGGL((KERNEL<MDL, 2>), dim3(GRID), dim3(64), LDS, ST, __VA_ARGS__); break;  \
+        default: hipLaunchKernelGGL((KERNEL<MDL, 3>), dim3(GRID), dim3(64), LDS, ST, __VA_ARGS__); break; \
+        }                                                                                                 \
     } while (0)
 
 // model_id 1 = Goddard (smooth-law specialisation when mu2 > 0, parameter slot 6), 2 = double integrator
-#define SOCP_DISPATCH_HOT(KERNEL, GRID, ST, ...)                                                        \
+#define SOCP_DISPATCH_HOT_LDS(KERNEL, GRID, LDS, ST, ...)                                               \
     do {                                                                                                \
-        if (model_id == 1 && P.p[6] > 0) SOCP_LAUNCH_MDL(KERNEL, SOCP_GODDARD_SMOOTH, GRID, GRID, ST, __VA_ARGS__); \
-        else if (model_id == 1) SOCP_LAUNCH_MDL(KERNEL, SOCP_GODDARD, GRID, GRID, ST, __VA_ARGS__);     \
-        else if (model_id == 3) SOCP_LAUNCH_MDL(KERNEL, SOCP_COVID, GRID, GRID, ST, __VA_ARGS__);       \
-        else SOCP_LAUNCH_MDL(KERNEL, SOCP_DINT, GRID, GRID, ST, __VA_ARGS__);                           \
+        if (model_id == 1 && P.p[6] > 0) SOCP_LAUNCH_MDL(KERNEL, SOCP_GODDARD_SMOOTH, GRID, GRID, LDS, ST, __VA_ARGS__); \
+        else if (model_id == 1) SOCP_LAUNCH_MDL(KERNEL, SOCP_GODDARD, GRID, GRID, LDS, ST, __VA_ARGS__); \
+        else if (model_id == 3) SOCP_LAUNCH_MDL(KERNEL, SOCP_COVID, GRID, GRID, LDS, ST, __VA_ARGS__);  \
+        else SOCP_LAUNCH_MDL(KERNEL, SOCP_DINT, GRID, GRID, LDS, ST, __VA_ARGS__);                      \
     } while (0)
+#define SOCP_DISPATCH_HOT(KERNEL, GRID, ST, ...) SOCP_DISPATCH_HOT_LDS(KERNEL, GRID, 0, ST, __VA_ARGS__)
 
 #define SOCP_DISPATCH(KERNEL, GRID, ST, ...)                                                            \
     do {                                                                                                \
@@ -78,8 +90,9 @@ hipError_t SOCP_CAT(residual_, SOCP_FLAVOUR)(int model_id, hipStream_t st, const
                                              const ProblemDev &pb, int B, const double *Z, double *F)
 {
     if (B <= 0) return hipSuccess;
-    const long T = (long)B * pb.M;
-    SOCP_DISPATCH_HOT(residual_lane_kernel, blocks_for(T), st, P, pb, B, Z, F);
+    const int R = rows_per_block(pb.M, pb.n);
+    const unsigned grid = R ? (unsigned)((B + R - 1) / R) : blocks_for((long)B * pb.M);
+    SOCP_DISPATCH_HOT_LDS(residual_lane_kernel, grid, (unsigned)((long)R * pb.n * 8), st, P, pb, B, Z, F, R);
     return hipGetLastError();
 }
 
@@ -97,8 +110,10 @@ hipError_t SOCP_CAT(fdrows_, SOCP_FLAVOUR)(int model_id, hipStream_t st, const M
                                            const ProblemDev &pb, int np, const double *z, double eps, double *rows)
 {
     if (np <= 0) return hipSuccess;
-    const long total = (long)np * (pb.n + 1) * pb.M;
-    SOCP_DISPATCH_HOT(fdrows_lane_kernel, blocks_for(total), st, P, pb, np, z, eps, rows);
+    const long vrows = (long)np * (pb.n + 1);
+    const int R = rows_per_block(pb.M, pb.n);
+    const unsigned grid = R ? (unsigned)((vrows + R - 1) / R) : blocks_for(vrows * pb.M);
+    SOCP_DISPATCH_HOT_LDS(fdrows_lane_kernel, grid, (unsigned)((long)R * pb.n * 8), st, P, pb, np, z, eps, rows, R);
     return hipGetLastError();
 }
 

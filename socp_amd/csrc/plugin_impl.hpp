@@ -35,15 +35,24 @@ inline unsigned blocks_for(long n) { return (unsigned)((n + 63) / 64); }
 inline int wpe_for(long waves) { const long k = (waves + 1023) / 1024; return k < 1 ? 1 : (k > 3 ? 3 : (int)k); }
 
 // one launch of a hot kernel: adaptive integrator -> one wave per SIMD; otherwise occupancy cap from the grid
-#define SOCP_PLUGIN_LAUNCH(KERNEL, GRID, ST, ...)                                                              \
-    do {                                                                                                       \
-        if (P.integrator == 1) hipLaunchKernelGGL((KERNEL<Mdl, 1, 1>), dim3(GRID), dim3(64), 0, ST, __VA_ARGS__); \
-        else switch (wpe_for(GRID)) {                                                                          \
-        case 1: hipLaunchKernelGGL((KERNEL<Mdl, 1, 0>), dim3(GRID), dim3(64), 0, ST, __VA_ARGS__); break;       \
-        case 2: hipLaunchKernelGGL((KERNEL<Mdl, 2, 0>), dim3(GRID), dim3(64), 0, ST, __VA_ARGS__); break;       \
-        default: hipLaunchKernelGGL((KERNEL<Mdl, 3, 0>), dim3(GRID), dim3(64), 0, ST, __VA_ARGS__); break;      \
-        }                                                                                                      \
+#define SOCP_PLUGIN_LAUNCH_LDS(KERNEL, GRID, LDS, ST, ...)                                                       \
+    do {                                                                                                         \
+        if (P.integrator == 1) hipLaunchKernelGGL((KERNEL<Mdl, 1, 1>), dim3(GRID), dim3(64), LDS, ST, __VA_ARGS__); \
+        else switch (wpe_for(GRID)) {                                                                            \
+        case 1: hipLaunchKernelGGL((KERNEL<Mdl, 1, 0>), dim3(GRID), dim3(64), LDS, ST, __VA_ARGS__); break;       \
+        case 2: hipLaunchKernelGGL((KERNEL<Mdl, 2, 0>), dim3(GRID), dim3(64), LDS, ST, __VA_ARGS__); break;       \
+        default: hipLaunchKernelGGL((KERNEL<Mdl, 3, 0>), dim3(GRID), dim3(64), LDS, ST, __VA_ARGS__); break;      \
+        }                                                                                                        \
     } while (0)
+#define SOCP_PLUGIN_LAUNCH(KERNEL, GRID, ST, ...) SOCP_PLUGIN_LAUNCH_LDS(KERNEL, GRID, 0, ST, __VA_ARGS__)
+
+inline int rows_per_block(int M, int n)
+{
+    if (M > 64) return 0;
+    int R = 64 / M;
+    if ((long)R * n * 8 > 32 * 1024) R = (int)(32 * 1024 / ((long)n * 8));
+    return R < 1 ? 0 : R;
+}
 
 template <class Mdl>
 hipError_t traj(hipStream_t st, const ModelParams &P, int B, const double *t0, const double *tf, const double *sw,
@@ -57,7 +66,9 @@ template <class Mdl>
 hipError_t residual(hipStream_t st, const ModelParams &P, const ProblemDev &pb, int B, const double *Z, double *F)
 {
     if (B <= 0) return hipSuccess;
-    SOCP_PLUGIN_LAUNCH(residual_lane_kernel, blocks_for((long)B * pb.M), st, P, pb, B, Z, F);
+    const int R = rows_per_block(pb.M, pb.n);
+    const unsigned grid = R ? (unsigned)((B + R - 1) / R) : blocks_for((long)B * pb.M);
+    SOCP_PLUGIN_LAUNCH_LDS(residual_lane_kernel, grid, (unsigned)((long)R * pb.n * 8), st, P, pb, B, Z, F, R);
     return hipGetLastError();
 }
 template <class Mdl>
@@ -72,7 +83,10 @@ template <class Mdl>
 hipError_t fdrows(hipStream_t st, const ModelParams &P, const ProblemDev &pb, int np, const double *z, double eps, double *rows)
 {
     if (np <= 0) return hipSuccess;
-    SOCP_PLUGIN_LAUNCH(fdrows_lane_kernel, blocks_for((long)np * (pb.n + 1) * pb.M), st, P, pb, np, z, eps, rows);
+    const long vrows = (long)np * (pb.n + 1);
+    const int R = rows_per_block(pb.M, pb.n);
+    const unsigned grid = R ? (unsigned)((vrows + R - 1) / R) : blocks_for(vrows * pb.M);
+    SOCP_PLUGIN_LAUNCH_LDS(fdrows_lane_kernel, grid, (unsigned)((long)R * pb.n * 8), st, P, pb, np, z, eps, rows, R);
     return hipGetLastError();
 }
 template <class Mdl>
