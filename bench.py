@@ -220,9 +220,10 @@ def main():
         if os.path.exists(tpath):
             try:
                 with open(tpath) as f:
-                    tj = json.load(f)
-                if tj.get("starts") == P and tj.get("variant") == args.variant and tj.get("rk4_steps") == args.rk4_steps:
-                    traffic = tj.get("hbm_bytes_per_launch")
+                    entries = json.load(f)
+                for tj in (entries if isinstance(entries, list) else [entries]):
+                    if tj.get("starts") == P and tj.get("variant") == args.variant and tj.get("rk4_steps") == args.rk4_steps:
+                        traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {

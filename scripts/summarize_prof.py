@@ -63,7 +63,15 @@ def main():
             tj[k] = int(extra[k])
     if "variant" in extra:
         tj["variant"] = extra["variant"]
-    json.dump(tj, open(os.path.join(root, "traffic_latest.json"), "w"), indent=1)
+    tpath = os.path.join(root, "traffic_latest.json")      # one entry per (variant, starts, rk4_steps); bench.py looks its own up
+    try:
+        entries = json.load(open(tpath))
+        entries = entries if isinstance(entries, list) else [entries]
+    except Exception:
+        entries = []
+    key = lambda e: (e.get("variant"), e.get("starts"), e.get("rk4_steps"))
+    entries = [e for e in entries if key(e) != key(tj)] + [tj]
+    json.dump(entries, open(tpath, "w"), indent=1)
     print(json.dumps(summ, indent=1))
 
 

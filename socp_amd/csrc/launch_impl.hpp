@@ -1,5 +1,6 @@
 // launch_impl.hpp -- body of the launchers; included once per flavour with
 // SOCP_FLAVOUR, SOCP_GODDARD and SOCP_DINT defined by the including .hip file.
+#include <cstdlib>
 #include "integrator.hpp"
 #include "launch.hpp"
 
@@ -23,7 +24,8 @@ constexpr int kNumSIMD = 1024;
 // 0 = direct stores
 static inline int rows_per_block(int M, int n)
 {
-    if (M > 64) return 0;
+    static const bool off = [] { const char *e = getenv("SOCP_ROW_TILES"); return e && e[0] == '0'; }();
+    if (off || M > 64) return 0;                      // SOCP_ROW_TILES=0: direct stores (A/B measurements)
     int R = 64 / M;
     const long bytes = (long)R * n * 8;
     if (bytes > 32 * 1024) R = (int)(32 * 1024 / ((long)n * 8));
