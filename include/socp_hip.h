@@ -34,12 +34,19 @@ extern "C" {
 #define SOCP_MODEL_GODDARD            1   /* dim 7, goddard.cpp:48-295 */
 #define SOCP_MODEL_DOUBLE_INTEGRATOR  2   /* dim 6, doubleIntegrator.cpp:49-300 */
 #define SOCP_MODEL_COVID19            3   /* dim 4, covid19.cpp:53-165 (control dimension 1) */
+#define SOCP_MODEL_INTERCEPTOR        4   /* dim 6, interceptor.cpp:69-998: two charts, two stages, own ComputeTraj and
+                                             final rows (control dimension 2: u, beta) */
 
 /* packed parameter block, refreshed before every Newton solve (parameters are mutated by the
  * continuation loop through a raw real&, shooting.cpp:695-707) */
 #define SOCP_GODDARD_NPARAMS 8   /* C, b, KD, kr, u_max, mu1, mu2, singularControl (goddard.hpp:28-37) */
 #define SOCP_DINT_NPARAMS    3   /* u_max, a_max, muT (doubleIntegrator.hpp:24-28) */
 #define SOCP_COVID_NPARAMS   8   /* R0, Tinf, Tinc, N, Imax, muI, umin, umax (covid19.hpp parameters_struct) */
+/* interceptor.hpp:28-46 in declaration order without the never-read r_2p/t_2p, then data->R_Earth, data->mu0,
+ * data->chartLimit (interceptor.cpp:52-58):  c0, hr, d0, eta, propellant_mass, empty_mass, q, ve, alpha_max, u_max,
+ * a_max, mu_gft, muT, muV, muC, R_Earth, mu0, chartLimit */
+#define SOCP_INTERCEPTOR_NPARAMS 18
+#define SOCP_MAX_NPARAMS         24   /* capacity of a packed parameter block */
 
 /* time / state modes, model.hpp:34-38 */
 #define SOCP_FIXED      0
@@ -105,6 +112,13 @@ int socp_integrate_batch_dev(socp_ctx *ctx, int B, const double *d_t0, const dou
  * steps; *rows = steps + 1 (rows beyond cap are counted, not stored).  sw: NULL or 2 values. */
 int socp_integrate_dense(socp_ctx *ctx, double t0, double tf, const double *sw, const double *X0,
                          double *dense, double *times, int cap, int *rows);
+/* Same, also returning each row's two per-trajectory auxiliary scalars in aux[cap][2] (NULL: not wanted).  They
+ * are the Goddard switching times (constant) or, for the interceptor, (stageMode, currentChart) -- what
+ * interceptor::Trace prints beside the state (interceptor.cpp:131-151).  A model with its own ComputeTraj
+ * (interceptor.cpp:162-218) reports the rows that function traces -- the start of each stage and every step --
+ * followed by ONE extra row: the state ComputeTraj returns (chart 1) with the flags it leaves behind. */
+int socp_integrate_dense_aux(socp_ctx *ctx, double t0, double tf, const double *sw, const double *X0,
+                             double *dense, double *times, double *aux, int cap, int *rows);
 
 /* replaces: model::Model / Control / Hamiltonian called outside the integrator (trace,
  * free-time rows).  t: [B]; X: [B][len]; out: [B][out_len]. */

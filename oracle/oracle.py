@@ -18,9 +18,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(HERE, "_build", "libsocp_oracle.so")
 REF_SO = os.path.join(HERE, "_ref", "libsocp_ref.so")
 
-MODEL_GODDARD, MODEL_DINT, MODEL_COVID = 1, 2, 3
+MODEL_GODDARD, MODEL_DINT, MODEL_COVID, MODEL_INTERCEPTOR = 1, 2, 3, 4
 FIXED, FREE, CONTINUOUS = 0, 1, 2
 GODDARD_PARAM_NAMES = ["C", "b", "KD", "kr", "u_max", "mu1", "mu2", "singularControl"]
+INTERCEPTOR_PARAM_NAMES = ["c0", "hr", "d0", "eta", "propellant_mass", "empty_mass", "q", "ve", "alpha_max", "u_max",
+                           "a_max", "mu_gft", "muT", "muV", "muC", "R_Earth", "mu0", "chartLimit"]
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -39,7 +41,8 @@ def build(ref=True):
 
 class _OrcModel(C.Structure):
     _fields_ = [("model_id", C.c_int), ("dim", C.c_int), ("step_nbr", C.c_int),
-                ("p", C.c_double * 8), ("nsw", C.c_int), ("sw", C.c_double * 64)]
+                ("p", C.c_double * 24), ("nsw", C.c_int), ("sw", C.c_double * 64),
+                ("chart", C.c_int), ("stage", C.c_int)]
 
 
 class _OrcProblem(C.Structure):
@@ -85,7 +88,11 @@ class Oracle:
             self.m.p[i] = float(v)
 
     def set_param(self, name, v):
-        self.m.p[GODDARD_PARAM_NAMES.index(name)] = float(v)
+        names = INTERCEPTOR_PARAM_NAMES if self.m.model_id == MODEL_INTERCEPTOR else GODDARD_PARAM_NAMES
+        self.m.p[names.index(name)] = float(v)
+
+    def params(self):
+        return np.array(self.m.p[:], dtype=np.float64)
 
     def set_switching(self, sw):
         self.m.nsw = len(sw)
@@ -131,10 +138,56 @@ class Oracle:
         return X
 
     def traj(self, t0, X0, tf, is_jac=0):
+        """model::ComputeTraj (for the interceptor: both stages + chart handling; sets chart/stage)."""
         X0 = np.ascontiguousarray(X0, dtype=np.float64)
         Xf = np.empty_like(X0)
-        self.lib.orc_model_int(C.byref(self.m), C.c_double(t0), _d(X0), C.c_double(tf), int(is_jac), _d(Xf))
+        self.lib.orc_compute_traj(C.byref(self.m), C.c_double(t0), _d(X0), C.c_double(tf), int(is_jac), _d(Xf))
         return Xf
+
+    # -- interceptor only
+    def set_flags(self, chart, stage):
+        self.m.chart, self.m.stage = int(chart), int(stage)
+
+    def flags(self):
+        return self.m.chart, self.m.stage
+
+    def chart12(self, X1):
+        X1 = np.ascontiguousarray(X1, dtype=np.float64)
+        X2 = np.empty(12)
+        self.lib.orc_interceptor_chart12(C.byref(self.m), _d(X1), _d(X2))
+        return X2
+
+    def chart21(self, X2):
+        X2 = np.ascontiguousarray(X2, dtype=np.float64)
+        X1 = np.empty(12)
+        self.lib.orc_interceptor_chart21(C.byref(self.m), _d(X2), _d(X1))
+        return X1
+
+    def lu6_solve(self, A, b):
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        x = np.empty(6)
+        self.lib.orc_lu6_solve(_d(A), _d(b), _d(x))
+        return x
+
+    def traj_trace(self, t0, X0, tf):
+        """interceptor ComputeTraj with the trace observer: (Xf, rows[k] = (t, X[12], chart, stage))."""
+        rows = []
+        OBS = C.CFUNCTYPE(None, C.c_void_p, C.c_double, _dp, C.c_int, C.c_int)
+
+        def cb(_ctx, t, X, chart, stage):
+            rows.append((t, np.array([X[i] for i in range(12)]), chart, stage))
+
+        X0 = np.ascontiguousarray(X0, dtype=np.float64)
+        Xf = np.empty(12)
+        self.lib.orc_interceptor_compute_traj_obs(C.byref(self.m), C.c_double(t0), _d(X0), C.c_double(tf), _d(Xf), OBS(cb), None)
+        return Xf, rows
+
+    def init_analytical(self, ti, Xi, tf, Xf):
+        Xi = np.array(Xi, dtype=np.float64)
+        Xf = np.ascontiguousarray(Xf, dtype=np.float64)
+        self.lib.orc_interceptor_init_analytical(C.byref(self.m), C.c_double(ti), _d(Xi), C.c_double(tf), _d(Xf))
+        return Xi
 
     def traj_dopri5(self, t0, X0, tf, tol):
         """Adaptive Dormand-Prince segment, initial step (tf - t0)/stepNbr. Returns (Xf, accepted, rejected)."""

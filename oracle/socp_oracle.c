@@ -20,6 +20,7 @@
  * goddard.hpp:28-37); doubleIntegrator.cpp:26-34 (dim 6, stepNbr 30). */
 void orc_model_init(orc_model *m, int model_id)
 {
+    if (model_id == ORC_MODEL_INTERCEPTOR) { orc_interceptor_init(m); return; }
     memset(m, 0, sizeof(*m));
     m->model_id = model_id;
     if (model_id == ORC_MODEL_GODDARD) {
@@ -41,7 +42,7 @@ void orc_model_init(orc_model *m, int model_id)
     }
 }
 
-int orc_control_dim(const orc_model *m) { return m->model_id == ORC_MODEL_COVID19 ? 1 : 3; }
+int orc_control_dim(const orc_model *m) { return m->model_id == ORC_MODEL_COVID19 ? 1 : (m->model_id == ORC_MODEL_INTERCEPTOR ? 2 : 3); }
 
 int orc_state_len(const orc_model *m, int is_jac)
 {
@@ -298,6 +299,7 @@ void orc_control(const orc_model *m, double t, const double *X, double *u3)
 {
     if (m->model_id == ORC_MODEL_GODDARD) goddard_control(m, t, X, u3);
     else if (m->model_id == ORC_MODEL_COVID19) u3[0] = covid_control(m, X);
+    else if (m->model_id == ORC_MODEL_INTERCEPTOR) orc_interceptor_control(m, t, X, u3);
     else dint_control(m, X, u3);
 }
 
@@ -307,6 +309,7 @@ void orc_rhs(const orc_model *m, double t, const double *X, int is_jac, double *
 {
     if (m->model_id == ORC_MODEL_GODDARD) goddard_model(m, t, X, Xdot);
     else if (m->model_id == ORC_MODEL_COVID19) covid_model(m, X, Xdot);
+    else if (m->model_id == ORC_MODEL_INTERCEPTOR) orc_interceptor_rhs(m, t, X, Xdot);
     else if (is_jac) dint_model_jac(m, X, Xdot);
     else dint_f(m, X, Xdot);
 }
@@ -315,6 +318,7 @@ void orc_hamiltonian(const orc_model *m, double t, const double *X, int is_jac, 
 {
     if (m->model_id == ORC_MODEL_GODDARD) H[0] = goddard_hamiltonian(m, t, X);
     else if (m->model_id == ORC_MODEL_COVID19) H[0] = covid_hamiltonian(m, X);
+    else if (m->model_id == ORC_MODEL_INTERCEPTOR) H[0] = orc_interceptor_hamiltonian(m, t, X);
     else dint_hamiltonian(m, X, is_jac, H);
 }
 
@@ -449,6 +453,17 @@ long orc_model_int(const orc_model *m, double t0, const double *X0, double tf, i
     return orc_integrate(m, Xf, t0, tf, dt, is_jac);
 }
 
+void orc_compute_traj(orc_model *m, double t0, const double *X0, double tf, int is_jac, double *Xf)
+{
+    if (m->model_id == ORC_MODEL_INTERCEPTOR) {
+        double X[12];
+        memcpy(X, X0, sizeof(X));
+        orc_interceptor_compute_traj(m, t0, X, tf, Xf);
+    } else {
+        orc_model_int(m, t0, X0, tf, is_jac, Xf);
+    }
+}
+
 void orc_integrate_batch(const orc_model *m, int B, const double *t0, const double *tf,
                          const double *aux_sw, const double *X0, double *Xf, int is_jac)
 {
@@ -456,7 +471,7 @@ void orc_integrate_batch(const orc_model *m, int B, const double *t0, const doub
     for (int b = 0; b < B; b++) {
         orc_model mm = *m;
         if (aux_sw) { mm.nsw = 2; mm.sw[0] = aux_sw[2*b]; mm.sw[1] = aux_sw[2*b + 1]; }
-        orc_model_int(&mm, t0[b], X0 + (size_t)n*b, tf[b], is_jac, Xf + (size_t)n*b);
+        orc_compute_traj(&mm, t0[b], X0 + (size_t)n*b, tf[b], is_jac, Xf + (size_t)n*b);
     }
 }
 
@@ -635,7 +650,7 @@ void orc_shooting_function(orc_model *m, const orc_problem *p, const double *z, 
     int nbr = s * M;
     for (int i = 0; i < M; i++) {
         double t1 = tl[i], t2 = tl[i + 1];
-        orc_model_int(m, t1, X1, t2, 0, Xtf);
+        orc_compute_traj(m, t1, X1, t2, 0, Xtf);                          /* Move -> model::ComputeTraj */
         int index = s * (i + 1);
         if (i == 0) {
             double f0[ORC_MAX_LEN];
@@ -660,11 +675,15 @@ void orc_shooting_function(orc_model *m, const orc_problem *p, const double *z, 
         }
         if (i == M - 1) {
             double fN[ORC_MAX_LEN];
-            boundary_rows(d, Xtf, p->xnode + (size_t)s * M, p->mode_x + (size_t)d * M, fN);
+            if (m->model_id == ORC_MODEL_INTERCEPTOR)                    /* interceptor.cpp:221-272 overrides */
+                orc_interceptor_final_rows(m, Xtf, p->xnode + (size_t)s * M, p->mode_x + (size_t)d * M, fN);
+            else
+                boundary_rows(d, Xtf, p->xnode + (size_t)s * M, p->mode_x + (size_t)d * M, fN);
             for (int k = 0; k < d; k++) fvec[k + d] = fN[k];
             if (p->mode_t[M] != ORC_FIXED) {
                 double h;
                 orc_hamiltonian(m, t2, Xtf, 0, &h);                       /* model.hpp:147 */
+                if (m->model_id == ORC_MODEL_INTERCEPTOR) h = h + m->p[IP_MUT];   /* interceptor.cpp:270 */
                 fvec[nbr] = h;
                 nbr += 1;
             }

@@ -22,10 +22,10 @@
 extern "C" {
 #endif
 
-enum { ORC_MODEL_GODDARD = 1, ORC_MODEL_DOUBLE_INTEGRATOR = 2, ORC_MODEL_COVID19 = 3 };
+enum { ORC_MODEL_GODDARD = 1, ORC_MODEL_DOUBLE_INTEGRATOR = 2, ORC_MODEL_COVID19 = 3, ORC_MODEL_INTERCEPTOR = 4 };
 enum { ORC_FIXED = 0, ORC_FREE = 1, ORC_CONTINUOUS = 2 };   /* model.hpp:34-38 */
 
-#define ORC_MAX_PARAMS 8
+#define ORC_MAX_PARAMS 24
 #define ORC_MAX_SWITCH 64
 
 /* Goddard parameter slots (goddard.hpp:28-37, goddard.cpp:31-39) */
@@ -35,6 +35,11 @@ enum { DP_UMAX = 0, DP_AMAX, DP_MUT };
 /* covid19 parameter slots (covid19.hpp parameters_struct) */
 enum { CP_R0 = 0, CP_TINF, CP_TINC, CP_N, CP_IMAX, CP_MUI, CP_UMIN, CP_UMAX };
 
+/* interceptor parameter slots (interceptor.hpp:28-46 in declaration order, r_2p/t_2p -- never read --
+ * left out; then data->R_Earth, data->mu0, data->chartLimit, interceptor.cpp:52-58) */
+enum { IP_C0 = 0, IP_HR, IP_D0, IP_ETA, IP_PROP, IP_EMPTY, IP_Q, IP_VE, IP_ALPHA_MAX, IP_UMAX, IP_AMAX,
+       IP_MU_GFT, IP_MUT, IP_MUV, IP_MUC, IP_REARTH, IP_MU0, IP_CHART_LIMIT, IP_COUNT };
+
 typedef struct {
     int model_id;                 /* ORC_MODEL_* */
     int dim;                      /* state dimension d (7 / 6) */
@@ -42,6 +47,8 @@ typedef struct {
     double p[ORC_MAX_PARAMS];     /* packed parameters */
     int nsw;                      /* number of switching times pushed by ComputeTimeLine */
     double sw[ORC_MAX_SWITCH];    /* goddard data->switchingTimes */
+    int chart;                    /* interceptor data->currentChart (1 / 2), left as the last trajectory set it */
+    int stage;                    /* interceptor data->stageMode (1 = powered), likewise */
 } orc_model;
 
 typedef struct {
@@ -77,6 +84,25 @@ long orc_integrate_dopri5(const orc_model *m, double *X, double t0, double tf, d
 /* batch of independent trajectories, one per row; aux_sw may be NULL, else [B][2] */
 void orc_integrate_batch(const orc_model *m, int B, const double *t0, const double *tf,
                          const double *aux_sw, const double *X0, double *Xf, int is_jac);
+
+/* model::ComputeTraj: ModelInt for every model but the interceptor, which overrides it
+ * (two stages + chart switching, interceptor.cpp:162-218) and leaves m->chart / m->stage behind */
+void orc_compute_traj(orc_model *m, double t0, const double *X0, double tf, int is_jac, double *Xf);
+
+/* ---- interceptor (interceptor_oracle.c; PARITY UNPINNED, see that file's header) ---- */
+typedef void (*orc_interceptor_observer)(void *ctx, double t, const double *X, int chart, int stage);
+void orc_interceptor_init(orc_model *m);
+void orc_interceptor_rhs(const orc_model *m, double t, const double *X, double *Xdot);
+void orc_interceptor_control(const orc_model *m, double t, const double *X, double *u_beta);
+double orc_interceptor_hamiltonian(const orc_model *m, double t, const double *X);
+void orc_interceptor_chart12(const orc_model *m, const double *X1, double *X2);
+void orc_interceptor_chart21(const orc_model *m, const double *X2, double *X1);
+void orc_lu6_solve(const double A[6][6], const double *b, double *x);
+void orc_interceptor_compute_traj(orc_model *m, double t0, const double *X0, double tf, double *Xf);
+void orc_interceptor_compute_traj_obs(orc_model *m, double t0, const double *X0, double tf, double *Xf,
+                                      orc_interceptor_observer obs, void *ctx);
+void orc_interceptor_final_rows(const orc_model *m, const double *Xtf, const double *Xf, const int *mode_x, double *fvec);
+void orc_interceptor_init_analytical(const orc_model *m, double ti, double *Xi, double tf, const double *Xf);
 
 /* ---- shooting layer ---- */
 int  orc_num_param(const orc_problem *p);

@@ -12,7 +12,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_build", "libsocp_hip.so")
 
 OK, ERR_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4
-MODEL_GODDARD, MODEL_DOUBLE_INTEGRATOR, MODEL_COVID19 = 1, 2, 3
+MODEL_GODDARD, MODEL_DOUBLE_INTEGRATOR, MODEL_COVID19, MODEL_INTERCEPTOR = 1, 2, 3, 4
+INTERCEPTOR_PARAM_NAMES = ["c0", "hr", "d0", "eta", "propellant_mass", "empty_mass", "q", "ve", "alpha_max", "u_max",
+                           "a_max", "mu_gft", "muT", "muV", "muC", "R_Earth", "mu0", "chartLimit"]
 FIXED, FREE, CONTINUOUS = 0, 1, 2
 VARIANT_AUTO, VARIANT_LANE_EXACT, VARIANT_LANE_FAST, VARIANT_WAVE = 0, 1, 2, 3
 EVAL_RHS, EVAL_CONTROL, EVAL_HAMILTONIAN = 0, 1, 2
@@ -76,6 +78,7 @@ def lib():
         L.socp_integrate_batch.argtypes = [_vp, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_int]
         L.socp_integrate_batch_dev.argtypes = [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int]
         L.socp_integrate_dense.argtypes = [_vp, C.c_double, C.c_double, _dp, _dp, _dp, _dp, C.c_int, _ip]
+        L.socp_integrate_dense_aux.argtypes = [_vp, C.c_double, C.c_double, _dp, _dp, _dp, _dp, _dp, C.c_int, _ip]
         L.socp_eval_batch.argtypes = [_vp, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, _dp, C.c_int]
         L.socp_problem_set.argtypes = [_vp, C.c_int, _ip, _ip, _dp, _dp]
         L.socp_problem_num_param.argtypes = [_vp]
@@ -142,6 +145,8 @@ class Context:
         self.nu = self.L.socp_ctx_control_dim(self.h)
         self.n = None
         self.nparams = nparams
+        if nparams is None and model_id == MODEL_INTERCEPTOR:
+            self.nparams = len(INTERCEPTOR_PARAM_NAMES)
 
     def close(self):
         if self.h:
@@ -171,7 +176,8 @@ class Context:
 
     def set_param(self, name, value):
         p = self.get_params()
-        p[GODDARD_PARAM_NAMES.index(name)] = value
+        names = INTERCEPTOR_PARAM_NAMES if self.model_id == MODEL_INTERCEPTOR else GODDARD_PARAM_NAMES
+        p[names.index(name)] = value
         self.set_params(p)
 
     def set_step_number(self, n):
@@ -231,6 +237,20 @@ class Context:
                                               C.byref(rows)))
         k = min(rows.value, cap)
         return times[:k].copy(), dense[:k].copy()
+
+    def integrate_dense_aux(self, t0, tf, X0, sw=None, cap=None):
+        """As integrate_dense, plus each row's two auxiliary scalars: (times, X[rows][s], aux[rows][2])."""
+        X0 = _f64(X0)
+        cap = cap or 20000
+        dense = np.empty((cap, len(X0)))
+        times = np.empty(cap)
+        aux = np.empty((cap, 2))
+        rows = C.c_int(0)
+        swp = _d(_f64(sw)) if sw is not None else None
+        self._chk(self.L.socp_integrate_dense_aux(self.h, float(t0), float(tf), swp, _d(X0), _d(dense), _d(times),
+                                                  _d(aux), cap, C.byref(rows)))
+        k = min(rows.value, cap)
+        return times[:k].copy(), dense[:k].copy(), aux[:k].copy()
 
     def eval_batch(self, what, t, X, sw=None, is_jac=0):
         X = _f64(X)

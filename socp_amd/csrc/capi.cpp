@@ -162,6 +162,7 @@ int socp_ctx_create(socp_ctx **out, int model_id, int device)
         auto it = plugins().find(model_id);
         if (it != plugins().end()) vt = &it->second;
     }
+    if (model_id == SOCP_MODEL_INTERCEPTOR) vt = interceptor_launchers();   // in-tree, table-driven (kernels_interceptor.hip)
     if (!vt && model_id != SOCP_MODEL_GODDARD && model_id != SOCP_MODEL_DOUBLE_INTEGRATOR && model_id != SOCP_MODEL_COVID19)
         return fail(nullptr, SOCP_ERR_UNSUPPORTED, "socp_ctx_create: unknown model id (no device dynamics; plugins: socp_plugin_load)");
     int ndev = 0;
@@ -182,6 +183,8 @@ int socp_ctx_create(socp_ctx **out, int model_id, int device)
         c->dim = vt->dim; c->nparams = vt->nparams; c->nu = vt->control_dim;
         std::memcpy(c->P.p, vt->default_params, sizeof(double) * kMaxParams);
         c->P.sw0 = c->P.sw1 = 0.0; c->P.step_nbr = vt->default_step_nbr;
+        // interceptor: the auxiliary scalars are (stageMode, currentChart); a fresh object has (0, 1) (interceptor.cpp:62-64)
+        if (model_id == SOCP_MODEL_INTERCEPTOR) c->P.sw1 = 1.0;
     } else if (model_id == SOCP_MODEL_GODDARD) {
         // goddard.cpp:23-40 defaults
         c->dim = 7; c->nparams = SOCP_GODDARD_NPARAMS;
@@ -368,6 +371,12 @@ int socp_integrate_batch(socp_ctx *c, int B, const double *t0, const double *tf,
 int socp_integrate_dense(socp_ctx *c, double t0, double tf, const double *sw, const double *X0,
                          double *dense, double *times, int cap, int *rows)
 {
+    return socp_integrate_dense_aux(c, t0, tf, sw, X0, dense, times, nullptr, cap, rows);
+}
+
+int socp_integrate_dense_aux(socp_ctx *c, double t0, double tf, const double *sw, const double *X0,
+                             double *dense, double *times, double *aux, int cap, int *rows)
+{
     if (!c) return SOCP_ERR_ARG;
     if (!X0 || !dense || !times || !rows || cap < 1) return fail(c, SOCP_ERR_ARG, "integrate_dense: bad argument");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -376,20 +385,23 @@ int socp_integrate_dense(socp_ctx *c, double t0, double tf, const double *sw, co
     HIP_TRY(c, c->s_out.reserve(sizeof(double) * S * cap));
     HIP_TRY(c, c->s_t0.reserve(sizeof(double) * cap));
     HIP_TRY(c, c->s_aux.reserve(sizeof(int) * 4));
+    HIP_TRY(c, c->s_tf.reserve(sizeof(double) * 2 * cap));
+    double *d_aux = aux ? c->s_tf.as<double>() : nullptr;
     HIP_TRY(c, hipMemcpyAsync(c->s_in.p, X0, sizeof(double) * S, hipMemcpyHostToDevice, c->stream));
     const double s0 = sw ? sw[0] : c->P.sw0, s1 = sw ? sw[1] : c->P.sw1;
     c->n_traj += 1; c->n_launch += 1;
     hipError_t e = c->vt
-        ? c->vt->dense(c->stream, c->P, t0, tf, s0, s1, c->s_in.as<double>(), c->s_out.as<double>(), c->s_t0.as<double>(), cap, c->s_aux.as<int>())
+        ? c->vt->dense(c->stream, c->P, t0, tf, s0, s1, c->s_in.as<double>(), c->s_out.as<double>(), c->s_t0.as<double>(), cap, c->s_aux.as<int>(), d_aux)
         : use_fast(c)
-        ? dense_fast(c->model_id, c->stream, c->P, t0, tf, s0, s1, c->s_in.as<double>(), c->s_out.as<double>(), c->s_t0.as<double>(), cap, c->s_aux.as<int>())
-        : dense_exact(c->model_id, c->stream, c->P, t0, tf, s0, s1, c->s_in.as<double>(), c->s_out.as<double>(), c->s_t0.as<double>(), cap, c->s_aux.as<int>());
+        ? dense_fast(c->model_id, c->stream, c->P, t0, tf, s0, s1, c->s_in.as<double>(), c->s_out.as<double>(), c->s_t0.as<double>(), cap, c->s_aux.as<int>(), d_aux)
+        : dense_exact(c->model_id, c->stream, c->P, t0, tf, s0, s1, c->s_in.as<double>(), c->s_out.as<double>(), c->s_t0.as<double>(), cap, c->s_aux.as<int>(), d_aux);
     HIP_TRY(c, e);
     HIP_TRY(c, hipMemcpyAsync(rows, c->s_aux.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     const int kept = *rows < cap ? *rows : cap;
     HIP_TRY(c, hipMemcpy(dense, c->s_out.p, sizeof(double) * S * kept, hipMemcpyDeviceToHost));
     HIP_TRY(c, hipMemcpy(times, c->s_t0.p, sizeof(double) * kept, hipMemcpyDeviceToHost));
+    if (aux) HIP_TRY(c, hipMemcpy(aux, d_aux, sizeof(double) * 2 * kept, hipMemcpyDeviceToHost));
     return SOCP_OK;
 }
 

@@ -4,7 +4,7 @@
 
 namespace socp {
 
-constexpr int kMaxParams = 8;
+constexpr int kMaxParams = 24;          // the interceptor packs 18 (models_interceptor.hpp)
 constexpr int kMaxNodes = 1025;        // M + 1 upper bound for a device-resident problem
 
 // Packed model parameters + default switching times; passed to kernels by value (kernarg).

@@ -6,9 +6,27 @@
 // trajectory: its s-vector, the RK4 stage vectors and all RHS temporaries live in VGPRs, so
 // the inner loop touches neither LDS nor HBM; a 64-lane wave is 64 independent trajectories.
 #pragma once
+#include <type_traits>
+
 #include "dev_common.hpp"
 
 namespace socp {
+
+// Optional model traits (absent = false).  kCustomTraj: the model overrides model::ComputeTraj and brings its
+// own driver  compute_traj<INTEG>(P, a0, a1, t0, tf, X, observer)  that may rewrite its two per-lane auxiliary
+// scalars (models_interceptor.hpp).  kCustomFinal: it overrides Final[H]Function through final_row() /
+// final_h_offset().
+template <class M, class = void> struct has_custom_traj : std::false_type {};
+template <class M> struct has_custom_traj<M, std::void_t<decltype(M::kCustomTraj)>> : std::bool_constant<M::kCustomTraj> {};
+template <class M, class = void> struct has_custom_final : std::false_type {};
+template <class M> struct has_custom_final<M, std::void_t<decltype(M::kCustomFinal)>> : std::bool_constant<M::kCustomFinal> {};
+
+struct NoObserver {
+    template <class... A> __device__ __forceinline__ void operator()(A &&...) const {}
+};
+struct NoStepHook {
+    template <class X> __device__ __forceinline__ bool operator()(double, X &) const { return false; }
+};
 
 template <class Mdl>
 struct Lane {
@@ -67,7 +85,7 @@ struct Lane {
     // dt *= max(0.9 err^-1/3, 0.2), accept with err < 0.5 -> dt *= 0.9 max(5^-5, err)^-1/5, stepping while
     // t + dt <= tf and finishing with dt = tf - t.  Step control is PER LANE: lanes of a wave take different
     // numbers of steps and wait for the slowest (the loop runs under the exec mask).
-    __device__ static __forceinline__ bool dopri5_try(const ModelParams &P, double sw0, double sw1, double &t, double &dt,
+    __device__ static __forceinline__ bool dopri5_try(const ModelParams &P, const double &sw0, const double &sw1, double &t, double &dt,
                                                      const double (&x)[S], const double (&k1)[S], double (&xn)[S], double (&kn)[S])
     {
         constexpr double a2 = 1.0 / 5, a3 = 3.0 / 10, a4 = 4.0 / 5, a5 = 8.0 / 9;
@@ -119,8 +137,11 @@ struct Lane {
         return true;
     }
 
-    __device__ static __forceinline__ void integrate_dopri5(const ModelParams &P, double sw0, double sw1,
-                                                           double t0, double tf, double (&X)[S])
+    // `hook(t, X)` runs before every step and reports whether it rewrote X (the interceptor's chart change): the
+    // FSAL derivative is then recomputed.  sw0/sw1 are references because such a hook may also change them.
+    template <class Hook = NoStepHook>
+    __device__ static __forceinline__ void integrate_dopri5(const ModelParams &P, const double &sw0, const double &sw1,
+                                                           double t0, double tf, double (&X)[S], Hook &&hook = Hook())
     {
         const double eps = 2.220446049250313e-16;
         double t = t0, h = (tf - t0) / P.step_nbr;
@@ -130,6 +151,7 @@ struct Lane {
         int budget = 1 << 22;                                   // every lane reaches an exit: bounded total work
         while (tf - t > eps && budget > 0) {
             while (t + h - tf <= eps && budget > 0) {
+                if (hook(t, X)) have_k1 = false;
                 if (!have_k1) { Mdl::rhs(P, sw0, sw1, t, X, k1); have_k1 = true; }
                 int tries = 0;
                 bool ok;
@@ -150,12 +172,14 @@ struct Lane {
         }
     }
 
+    // model::ComputeTraj.  a0/a1 are the lane's auxiliary scalars; only a kCustomTraj model writes them.
     template <int INTEG>
-    __device__ static __forceinline__ void integrate_with(const ModelParams &P, double sw0, double sw1,
+    __device__ static __forceinline__ void integrate_with(const ModelParams &P, double &a0, double &a1,
                                                          double t0, double tf, double (&X)[S])
     {
-        if constexpr (INTEG == 1) integrate_dopri5(P, sw0, sw1, t0, tf, X);
-        else integrate(P, sw0, sw1, t0, tf, X);
+        if constexpr (has_custom_traj<Mdl>::value) Mdl::template compute_traj<INTEG>(P, a0, a1, t0, tf, X, NoObserver());
+        else if constexpr (INTEG == 1) integrate_dopri5(P, a0, a1, t0, tf, X);
+        else integrate(P, a0, a1, t0, tf, X);
     }
 
     // model.hpp:395-414 / goddard.cpp:298-317 (dt) + odeTools.cpp:128-146 (loop): t is
@@ -211,8 +235,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, WPE))) vo
 #pragma unroll
         for (int k = 0; k < S; k++) X[k] = tile[lane * LD + k];
         const long b = row0 + lane;
-        const double s0 = sw ? sw[2 * b] : P.sw0;
-        const double s1 = sw ? sw[2 * b + 1] : P.sw1;
+        double s0 = sw ? sw[2 * b] : P.sw0;
+        double s1 = sw ? sw[2 * b + 1] : P.sw1;
         Lane<Mdl>::template integrate_with<INTEG>(P, s0, s1, t0[b], tf[b], X);
 #pragma unroll
         for (int k = 0; k < S; k++) tile[lane * LD + k] = X[k];
@@ -225,17 +249,44 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, WPE))) vo
 // K_dense: ONE trajectory with the state after every step kept (trace replay, shooting.cpp:496-544 ->
 // the observer form of integrate, odeTools.cpp:103-123).  Row 0 is (t0, X0); row k the accumulated
 // time t and state after k steps -- exactly what the reference's observer is shown.  Not hot.
+// A kCustomTraj model reports the rows its own ComputeTraj traces, with the two auxiliary scalars of each row in
+// aux[row][2] (may be null).
 template <class Mdl>
 __global__ void traj_dense_kernel(ModelParams P, double t0, double tf, double sw0, double sw1,
                                   const double *__restrict__ X0, double *__restrict__ dense,
-                                  double *__restrict__ times, int cap, int *__restrict__ rows)
+                                  double *__restrict__ times, int cap, int *__restrict__ rows, double *__restrict__ aux)
 {
     constexpr int S = Mdl::S;
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     double X[S];
+    if constexpr (has_custom_traj<Mdl>::value) {
+#pragma unroll
+        for (int k = 0; k < S; k++) X[k] = X0[k];
+        int r = 0;
+        double a0 = sw0, a1 = sw1;
+        Mdl::template compute_traj<0>(P, a0, a1, t0, tf, X, [&](double t, const double (&Xr)[S], double b0, double b1) {
+            if (r < cap) {
+#pragma unroll
+                for (int k = 0; k < S; k++) dense[(long)r * S + k] = Xr[k];
+                times[r] = t;
+                if (aux) { aux[2 * r] = b0; aux[2 * r + 1] = b1; }
+            }
+            r++;
+        });
+        // one more row: the state as ComputeTraj returns it (back in the model's default chart) and the flags it leaves
+        if (r < cap) {
+#pragma unroll
+            for (int k = 0; k < S; k++) dense[(long)r * S + k] = X[k];
+            times[r] = tf;
+            if (aux) { aux[2 * r] = a0; aux[2 * r + 1] = a1; }
+        }
+        *rows = r + 1;
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < S; k++) { X[k] = X0[k]; dense[k] = X[k]; }
     times[0] = t0;
+    if (aux) { aux[0] = sw0; aux[1] = sw1; }
     int r = 1;
     const double dt = (tf - t0) / P.step_nbr;
     double t = t0;
@@ -248,6 +299,7 @@ __global__ void traj_dense_kernel(ModelParams P, double t0, double tf, double sw
 #pragma unroll
             for (int k = 0; k < S; k++) dense[(long)r * S + k] = X[k];
             times[r] = t;
+            if (aux) { aux[2 * r] = sw0; aux[2 * r + 1] = sw1; }
         }
         r++;
     }
@@ -281,8 +333,8 @@ __device__ __forceinline__ void segment_residual(const ModelParams &P, const Pro
     };
     const double t1 = nt(i), t2 = nt(i + 1);
     // model switching times = FREE node times with index < M, in node order (:1604,1615)
-    const double sw0 = pb.sw_node0 >= 0 ? nt(pb.sw_node0) : P.sw0;
-    const double sw1 = pb.sw_node1 >= 0 ? nt(pb.sw_node1) : P.sw1;
+    double sw0 = pb.sw_node0 >= 0 ? nt(pb.sw_node0) : P.sw0;
+    double sw1 = pb.sw_node1 >= 0 ? nt(pb.sw_node1) : P.sw1;
 
     double X[S];
     if (i == 0) {
@@ -327,12 +379,18 @@ __device__ __forceinline__ void segment_residual(const ModelParams &P, const Pro
         // model.hpp:90-122 FinalFunction / :133-185 FinalHFunction, isJac == 0
         const int *mx = pb.mode_x + M * D;
         const double *xd = pb.xnode + M * S;
+        if constexpr (has_custom_final<Mdl>::value) {
 #pragma unroll
-        for (int j = 0; j < D; j++) {
-            const bool fr = mx[j] == 1;
-            emit(D + j, fr ? X[j + D] : X[j] - xd[j]);
+            for (int j = 0; j < D; j++) emit(D + j, Mdl::final_row(P, j, mx[j], X, xd));
+            if (pb.ft_row[M] >= 0) emit(pb.ft_row[M], Mdl::hamiltonian(P, sw0, sw1, t2, X) + Mdl::final_h_offset(P));
+        } else {
+#pragma unroll
+            for (int j = 0; j < D; j++) {
+                const bool fr = mx[j] == 1;
+                emit(D + j, fr ? X[j + D] : X[j] - xd[j]);
+            }
+            if (pb.ft_row[M] >= 0) emit(pb.ft_row[M], Mdl::hamiltonian(P, sw0, sw1, t2, X));
         }
-        if (pb.ft_row[M] >= 0) emit(pb.ft_row[M], Mdl::hamiltonian(P, sw0, sw1, t2, X));
     }
 }
 

@@ -18,13 +18,13 @@ namespace socp {
                                 double *rows);                                                       \
     hipError_t dense_##FLAVOUR(int model_id, hipStream_t st, const ModelParams &P, double t0,         \
                                double tf, double sw0, double sw1, const double *X0, double *dense,   \
-                               double *times, int cap, int *rows);                                   \
+                               double *times, int cap, int *rows, double *aux);                      \
     hipError_t eval_##FLAVOUR(int model_id, hipStream_t st, const ModelParams &P, int what, int B,   \
                               const double *t, const double *sw, const double *X, double *out);
 
 // Launch table of an out-of-tree model (include/socp_plugin.h, plugin_impl.hpp): what the C-ABI layer calls
 // instead of the built-in flavour launchers when a context is created with a registered model id.
-constexpr int kPluginAbi = 1;
+constexpr int kPluginAbi = 2;
 struct ModelLaunchers {
     int abi, dim, control_dim, nparams, default_step_nbr;
     double default_params[kMaxParams];
@@ -32,7 +32,7 @@ struct ModelLaunchers {
     hipError_t (*residual)(hipStream_t, const ModelParams &, const ProblemDev &, int, const double *, double *);
     hipError_t (*fdjac)(hipStream_t, const ModelParams &, const ProblemDev &, int, int, const int2 *, const double *, const double *, double, double *);
     hipError_t (*fdrows)(hipStream_t, const ModelParams &, const ProblemDev &, int, const double *, double, double *);
-    hipError_t (*dense)(hipStream_t, const ModelParams &, double, double, double, double, const double *, double *, double *, int, int *);
+    hipError_t (*dense)(hipStream_t, const ModelParams &, double, double, double, double, const double *, double *, double *, int, int *, double *);
     hipError_t (*eval)(hipStream_t, const ModelParams &, int, int, const double *, const double *, const double *, double *);
 };
 
@@ -48,5 +48,8 @@ hipError_t var_eval(int model_id, hipStream_t st, const ModelParams &P, int what
 hipError_t fd_diff(hipStream_t st, int n, int np, const double *z, double eps, const double *rows, double *fjac);
 
 SOCP_DECLARE_LAUNCHERS(fast)
+
+// in-tree models that live in their own translation unit behind a launch table, like an out-of-tree plugin
+const ModelLaunchers *interceptor_launchers();      // kernels_interceptor.hip
 
 }  // namespace socp

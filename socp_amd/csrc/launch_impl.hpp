@@ -131,14 +131,14 @@ hipError_t fd_diff(hipStream_t st, int n, int np, const double *z, double eps, c
 
 hipError_t SOCP_CAT(dense_, SOCP_FLAVOUR)(int model_id, hipStream_t st, const ModelParams &P, double t0, double tf,
                                           double sw0, double sw1, const double *X0, double *dense, double *times,
-                                          int cap, int *rows)
+                                          int cap, int *rows, double *aux)
 {
     if (model_id == 1)
-        hipLaunchKernelGGL(traj_dense_kernel<SOCP_GODDARD>, dim3(1), dim3(64), 0, st, P, t0, tf, sw0, sw1, X0, dense, times, cap, rows);
+        hipLaunchKernelGGL(traj_dense_kernel<SOCP_GODDARD>, dim3(1), dim3(64), 0, st, P, t0, tf, sw0, sw1, X0, dense, times, cap, rows, aux);
     else if (model_id == 3)
-        hipLaunchKernelGGL(traj_dense_kernel<SOCP_COVID>, dim3(1), dim3(64), 0, st, P, t0, tf, sw0, sw1, X0, dense, times, cap, rows);
+        hipLaunchKernelGGL(traj_dense_kernel<SOCP_COVID>, dim3(1), dim3(64), 0, st, P, t0, tf, sw0, sw1, X0, dense, times, cap, rows, aux);
     else
-        hipLaunchKernelGGL(traj_dense_kernel<SOCP_DINT>, dim3(1), dim3(64), 0, st, P, t0, tf, sw0, sw1, X0, dense, times, cap, rows);
+        hipLaunchKernelGGL(traj_dense_kernel<SOCP_DINT>, dim3(1), dim3(64), 0, st, P, t0, tf, sw0, sw1, X0, dense, times, cap, rows, aux);
     return hipGetLastError();
 }
 

@@ -32,12 +32,18 @@ namespace socp {
 namespace plugin {
 
 inline unsigned blocks_for(long n) { return (unsigned)((n + 63) / 64); }
+// optional model hint kOneWavePerSimd: build and launch only the one-wave-per-SIMD instantiations (heavy
+// right-hand sides whose batches never fill the chip three deep)
+template <class M, class = void> struct one_wave_per_simd : std::false_type {};
+template <class M> struct one_wave_per_simd<M, std::void_t<decltype(M::kOneWavePerSimd)>> : std::bool_constant<M::kOneWavePerSimd> {};
 inline int wpe_for(long waves) { const long k = (waves + 1023) / 1024; return k < 1 ? 1 : (k > 3 ? 3 : (int)k); }
 
 // one launch of a hot kernel: adaptive integrator -> one wave per SIMD; otherwise occupancy cap from the grid
 #define SOCP_PLUGIN_LAUNCH_LDS(KERNEL, GRID, LDS, ST, ...)                                                       \
     do {                                                                                                         \
         if (P.integrator == 1) hipLaunchKernelGGL((KERNEL<Mdl, 1, 1>), dim3(GRID), dim3(64), LDS, ST, __VA_ARGS__); \
+        else if constexpr (one_wave_per_simd<Mdl>::value)                                                        \
+            hipLaunchKernelGGL((KERNEL<Mdl, 1, 0>), dim3(GRID), dim3(64), LDS, ST, __VA_ARGS__);                 \
         else switch (wpe_for(GRID)) {                                                                            \
         case 1: hipLaunchKernelGGL((KERNEL<Mdl, 1, 0>), dim3(GRID), dim3(64), LDS, ST, __VA_ARGS__); break;       \
         case 2: hipLaunchKernelGGL((KERNEL<Mdl, 2, 0>), dim3(GRID), dim3(64), LDS, ST, __VA_ARGS__); break;       \
@@ -91,9 +97,9 @@ hipError_t fdrows(hipStream_t st, const ModelParams &P, const ProblemDev &pb, in
 }
 template <class Mdl>
 hipError_t dense(hipStream_t st, const ModelParams &P, double t0, double tf, double sw0, double sw1, const double *X0,
-                 double *out, double *times, int cap, int *rows)
+                 double *out, double *times, int cap, int *rows, double *aux)
 {
-    hipLaunchKernelGGL(traj_dense_kernel<Mdl>, dim3(1), dim3(64), 0, st, P, t0, tf, sw0, sw1, X0, out, times, cap, rows);
+    hipLaunchKernelGGL(traj_dense_kernel<Mdl>, dim3(1), dim3(64), 0, st, P, t0, tf, sw0, sw1, X0, out, times, cap, rows, aux);
     return hipGetLastError();
 }
 template <class Mdl>

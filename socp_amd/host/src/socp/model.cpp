@@ -29,8 +29,8 @@ socp_ctx *model::DeviceContext() const
     }
     // the continuation loop mutates parameters through a raw real& (shooting.cpp:695-707) and users
     // poke stepNbr / switching times directly: re-pack on every use, never cache
-    double p[16];
-    const int np = DeviceParams(p, 16);
+    double p[SOCP_MAX_NPARAMS];
+    const int np = DeviceParams(p, SOCP_MAX_NPARAMS);
     if (socp_ctx_set_params(deviceCtx_, p, np) != SOCP_OK || socp_ctx_set_step_number(deviceCtx_, DeviceStepNumber()) != SOCP_OK)
         throw std::runtime_error(std::string("model: ") + socp_last_error(deviceCtx_));
     if (socp_ctx_set_integrator(deviceCtx_, AdaptiveIntegrator() ? SOCP_INT_DOPRI5 : SOCP_INT_RK4, odeIntTol) != SOCP_OK)

@@ -1,0 +1,172 @@
+"""GPU: interceptor device model (models_interceptor.hpp) against the CPU restatement
+(oracle/interceptor_oracle.c -- PARITY UNPINNED, see its header: the reference TU needs Eigen).
+
+The model calls sin/cos/tan/atan2/acos/exp, which differ between the device library and libm in the last
+place, so nothing here is bit-exact.  Tolerances: 1e-12 relative on single evaluations, 1e-10 on
+50/100-step trajectories (SURVEY 8d, N = 10/30 class), 1e-9 through a chart change (6x6 solve with
+condition ~1e7 from mixing metres and radians)."""
+import numpy as np
+import pytest
+
+from oracle.oracle import Oracle, Problem, MODEL_INTERCEPTOR, FIXED, FREE, CONTINUOUS
+
+pytestmark = pytest.mark.gpu
+
+R_E = 6378145.0
+
+
+def scenario_state(gamma=np.pi / 4, chi=0.0):
+    """testInterceptor.cpp:170-176 initial state + the analytical costate guess (InitAnalytical)."""
+    o = Oracle(MODEL_INTERCEPTOR)
+    Xi = np.zeros(12)
+    Xi[:6] = [1000, 1000, gamma, chi, 5454661 / R_E, 46086 / R_E]
+    Xf = np.zeros(12)
+    Xf[:6] = [6000, 1000, 0.01 * np.pi, 0.01 * np.pi, (5454661 + 27829.0) / R_E, 46086 / R_E]
+    return o.init_analytical(0.0, Xi, 10.0, Xf), Xf
+
+
+def rel(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))
+
+
+@pytest.fixture(scope="module")
+def ictx():
+    from socp_amd import capi
+    c = capi.Context(capi.MODEL_INTERCEPTOR)
+    yield c
+    c.close()
+
+
+def states_both_charts(o, B, seed=3):
+    rng = np.random.default_rng(seed)
+    X1, _ = scenario_state()
+    rows1, rows2 = [], []
+    for _ in range(B):
+        x = X1 * (1 + 0.2 * rng.uniform(-1, 1, 12))
+        x[2] = rng.uniform(-1.3, 1.3)
+        x[3] = rng.uniform(-3, 3)
+        rows1.append(x)
+        rows2.append(o.chart12(x))
+    return np.array(rows1), np.array(rows2)
+
+
+def test_model_control_hamiltonian_both_charts_both_stages(ictx, built):
+    from socp_amd import capi
+    o = Oracle(MODEL_INTERCEPTOR)
+    X1, X2 = states_both_charts(o, 16)
+    for chart, X in ((1, X1), (2, X2)):
+        for stage, t in ((1, 3.0), (0, 27.0)):
+            o.set_flags(chart, stage)
+            sw = np.tile([float(stage), float(chart)], (len(X), 1))
+            f = ictx.eval_batch(capi.EVAL_RHS, t, X, sw=sw)
+            u = ictx.eval_batch(capi.EVAL_CONTROL, t, X, sw=sw)
+            H = ictx.eval_batch(capi.EVAL_HAMILTONIAN, t, X, sw=sw)[:, 0]
+            for b in range(len(X)):
+                fo = o.rhs(t, X[b])
+                assert np.max(np.abs(f[b] - fo) / np.maximum(1e-6 * np.abs(fo).max(), np.abs(fo))) < 1e-9, (chart, stage, b)
+                assert rel(u[b], o.control(t, X[b])) < 1e-12
+                assert abs(H[b] - o.hamiltonian(t, X[b])[0]) <= 1e-11 * max(1.0, np.abs(fo).max())
+
+
+def test_trajectories_two_stages_and_chart_switch(ictx, built):
+    o = Oracle(MODEL_INTERCEPTOR)
+    X0, _ = scenario_state()
+    cases = [(0.0, 10.0, X0),                      # powered stage only
+             (0.0, 30.0, X0),                      # powered then coasting (t1 = 20 s)
+             (22.0, 31.0, X0)]                     # coasting only
+    Xs, _ = scenario_state(gamma=1.49)             # |cos(gamma)| < chartLimit: starts with a chart change
+    cases.append((0.0, 6.0, Xs))
+    cases.append((0.0, 25.0, Xs))
+    t0 = np.array([c[0] for c in cases])
+    tf = np.array([c[1] for c in cases])
+    X = np.array([c[2] for c in cases])
+    Xf = ictx.integrate_batch(t0, tf, X)
+    switched = 0
+    for b, (a, e, x) in enumerate(cases):
+        ref, rows = o.traj_trace(a, x, e)
+        switched += any(r[2] == 2 for r in rows)
+        assert rel(Xf[b], ref) < (1e-9 if any(r[2] == 2 for r in rows) else 1e-10), (b, Xf[b], ref)
+    assert switched >= 2                           # the chart-change path really ran
+
+
+def test_dense_rows_match_trace_rows(ictx, built):
+    o = Oracle(MODEL_INTERCEPTOR)
+    Xs, _ = scenario_state(gamma=1.49)
+    ref, rows = o.traj_trace(0.0, Xs, 25.0)
+    t, X, aux = ictx.integrate_dense_aux(0.0, 25.0, Xs, cap=256)
+    assert len(t) == len(rows) + 1 == 2 * 50 + 2 + 1
+    for k, (tr, Xr, chart, stage) in enumerate(rows):
+        assert abs(t[k] - tr) <= 1e-12 * max(1, abs(tr))
+        assert (aux[k, 0], aux[k, 1]) == (stage, chart), k
+        assert rel(X[k], Xr) < 1e-9, k
+    assert rel(X[-1], ref) < 1e-9 and tuple(aux[-1]) == (float(o.flags()[1]), float(o.flags()[0]))
+
+
+def single_shooting_problem(o):
+    """testInterceptor.cpp initState(): M = 1, tf free, final velocity free -> n = 13."""
+    X0, Xf = scenario_state()
+    mode_t = [FIXED, FREE]
+    mode_x = np.zeros((2, 6), dtype=np.int32)
+    mode_x[1, 1] = FREE
+    X = np.array([X0, Xf])
+    prob = Problem(6, mode_t, mode_x, np.array([0.0, 10.0]), X)
+    return prob, np.concatenate([X0, [10.0]])
+
+
+def multi_shooting_problem(o, M, tf=24.0):
+    X0, Xf = scenario_state()
+    mode_t = [FIXED] + [CONTINUOUS] * (M - 1) + [FREE]
+    mode_x = np.zeros((M + 1, 6), dtype=np.int32)
+    mode_x[1:M] = CONTINUOUS
+    mode_x[M, 1] = FREE
+    time = np.array([tf * i / M for i in range(M + 1)])
+    X = np.zeros((M + 1, 12))
+    X[0], X[M] = X0, Xf
+    for i in range(1, M):
+        X[i] = o.traj(0.0, X0, time[i])
+    return Problem(6, mode_t, mode_x, time, X), np.concatenate([X[:M].ravel(), [tf]])
+
+
+@pytest.mark.parametrize("M", [1, 4, 21])
+def test_residual_and_fd_rows(ictx, built, M):
+    o = Oracle(MODEL_INTERCEPTOR)
+    o.set_param("mu_gft", 0.6)
+    ictx.set_param("mu_gft", 0.6)
+    prob, z = single_shooting_problem(o) if M == 1 else multi_shooting_problem(o, M)
+    assert ictx.problem_set(prob.mode_t, prob.mode_x, prob.time, prob.xnode) == prob.n
+    if M == 21:
+        assert prob.n == 253                      # BASELINE config 5 class: ~256 unknowns
+    Fo = o.residual(prob, z)
+    F = ictx.residual(z)
+    scale = np.maximum(1.0, np.abs(Fo))
+    assert np.max(np.abs(F - Fo) / scale) < 1e-9
+    # custom final rows really in play: altitude row is scaled by hr, velocity row is p_v + muV
+    Xtf = o.traj(prob.time[M - 1] if M > 1 else 0.0, z[12 * (M - 1):12 * M], z[-1])
+    assert abs(Fo[6] - (Xtf[0] - prob.xnode[M, 0]) / 7500.0) < 1e-12
+    assert abs(Fo[7] - (Xtf[7] + 1.0)) < 1e-12
+    # FD rows = residuals of the perturbed unknown vectors
+    rows = ictx.fd_rows(z[None, :], epsfcn=1e-15)[0]
+    eps = np.sqrt(1e-15)
+    for j in (0, 7, 8, prob.n - 1):
+        zp = z.copy()
+        h = eps * abs(z[j]) or eps
+        zp[j] += h
+        Fj = o.residual(prob, zp)
+        assert np.max(np.abs(rows[j + 1] - Fj) / np.maximum(1.0, np.abs(Fj))) < 1e-9, j
+    assert np.max(np.abs(rows[0] - Fo) / scale) < 1e-9
+    ictx.set_param("mu_gft", 1.0)
+
+
+def test_adaptive_integrator_matches_fine_fixed_step(ictx):
+    """Dormand-Prince with the per-step chart choice (extension; the reference's interceptor is RK4-only):
+    converges to what a very fine fixed-step run gives."""
+    from socp_amd import capi
+    X0, _ = scenario_state()
+    ictx.set_step_number(4000)
+    fine = ictx.integrate_batch(0.0, 30.0, X0[None, :])[0]
+    ictx.set_step_number(50)
+    ictx.set_integrator(capi.INT_DOPRI5, 1e-10)
+    ada = ictx.integrate_batch(0.0, 30.0, X0[None, :])[0]
+    ictx.set_integrator(capi.INT_RK4)
+    assert rel(ada, fine) < 1e-7
