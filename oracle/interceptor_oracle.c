@@ -144,15 +144,15 @@ static void model_1(const orc_model *m, double t, const double *X, double *Xdot)
     Xdot[11] = 0.0;
 }
 
-/* interceptor.cpp:388-437 */
-static double hamiltonian_1(const orc_model *m, double t, const double *X)
+/* interceptor.cpp:388-437; uc = (u, beta) as Control_1 returns them (the `_at` form lets a test hold the control
+ * fixed: the thrust terms use sin/cos(alpha) while the control law is their small-angle optimum, so
+ * dH/du != 0 in the powered stage and only the PARTIAL derivatives of H give the costate equations) */
+static double hamiltonian_1_at(const orc_model *m, double t, const double *X, const double *uc)
 {
     icom c; common(m, t, X, &c);
     double v = X[1], gamma = X[2], chi = X[3], L = X[4];
     double p_h = X[6], p_v = X[7], p_gamma = X[8], p_chi = X[9], p_L = X[10], p_l = X[11];
     double mass = c.mass, c_max = c.c_max, d = c.d, r = c.r, g = c.g, ft = c.ft, eta = c.eta;
-    double uc[2];
-    control_1(m, t, X, uc);
     double u = uc[0], beta = uc[1];
     double alpha = c.alpha_max * u;
     double sg = sin(gamma), cg = cos(gamma), sc = sin(chi), cc = cos(chi), cL = cos(L), tL = tan(L);
@@ -212,14 +212,12 @@ static void model_2(const orc_model *m, double t, const double *X, double *Xdot)
 }
 
 /* interceptor.cpp:555-604 */
-static double hamiltonian_2(const orc_model *m, double t, const double *X)
+static double hamiltonian_2_at(const orc_model *m, double t, const double *X, const double *uc)
 {
     icom c; common(m, t, X, &c);
     double v = X[1], theta = X[2], phi = X[3], L = X[4];
     double p_h = X[6], p_v = X[7], p_theta = X[8], p_phi = X[9], p_L = X[10], p_l = X[11];
     double mass = c.mass, c_max = c.c_max, d = c.d, r = c.r, g = c.g, ft = c.ft, eta = c.eta;
-    double uc[2];
-    control_2(m, t, X, uc);
     double u = uc[0], beta = uc[1];
     double alpha = c.alpha_max * u;
     double st = sin(theta), ct = cos(theta), tt = tan(theta), sp = sin(phi), cp = cos(phi);
@@ -244,9 +242,15 @@ void orc_interceptor_control(const orc_model *m, double t, const double *X, doub
 {
     if (m->chart == 1) control_1(m, t, X, uc); else control_2(m, t, X, uc);
 }
+double orc_interceptor_hamiltonian_at(const orc_model *m, double t, const double *X, const double *u_beta)
+{
+    return m->chart == 1 ? hamiltonian_1_at(m, t, X, u_beta) : hamiltonian_2_at(m, t, X, u_beta);
+}
 double orc_interceptor_hamiltonian(const orc_model *m, double t, const double *X)
 {
-    return m->chart == 1 ? hamiltonian_1(m, t, X) : hamiltonian_2(m, t, X);
+    double uc[2];
+    orc_interceptor_control(m, t, X, uc);
+    return orc_interceptor_hamiltonian_at(m, t, X, uc);
 }
 
 /* ---- chart change ------------------------------------------------------------------------- */

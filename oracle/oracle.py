@@ -151,6 +151,13 @@ class Oracle:
     def flags(self):
         return self.m.chart, self.m.stage
 
+    def hamiltonian_at(self, t, X, u_beta):
+        """interceptor H with the control held at (u, beta) instead of recomputed from X."""
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        ub = np.ascontiguousarray(u_beta, dtype=np.float64)
+        self.lib.orc_interceptor_hamiltonian_at.restype = C.c_double
+        return self.lib.orc_interceptor_hamiltonian_at(C.byref(self.m), C.c_double(t), _d(X), _d(ub))
+
     def chart12(self, X1):
         X1 = np.ascontiguousarray(X1, dtype=np.float64)
         X2 = np.empty(12)

@@ -95,6 +95,7 @@ void orc_interceptor_init(orc_model *m);
 void orc_interceptor_rhs(const orc_model *m, double t, const double *X, double *Xdot);
 void orc_interceptor_control(const orc_model *m, double t, const double *X, double *u_beta);
 double orc_interceptor_hamiltonian(const orc_model *m, double t, const double *X);
+double orc_interceptor_hamiltonian_at(const orc_model *m, double t, const double *X, const double *u_beta);
 void orc_interceptor_chart12(const orc_model *m, const double *X1, double *X2);
 void orc_interceptor_chart21(const orc_model *m, const double *X2, double *X1);
 void orc_lu6_solve(const double A[6][6], const double *b, double *x);

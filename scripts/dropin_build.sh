@@ -15,7 +15,7 @@ OUT="$ROOT/oracle/_ref/dropin"
 [ -f "$ROOT/socp_amd/_build/libsocp_host.so" ] || { echo "build the product first (__graft_entry__.build())"; exit 1; }
 rm -rf "$OUT"; mkdir -p "$OUT/tests" "$OUT/bin"
 ln -s "$ROOT/socp_amd/host/src" "$OUT/src"
-for prog in testGoddard testDoubleIntegrator testDoubleIntegrator_WP testCovid19; do
+for prog in testGoddard testDoubleIntegrator testDoubleIntegrator_WP testCovid19 testInterceptor; do
     ln -s "$REF/tests/$prog.cpp" "$OUT/tests/$prog.cpp"
     g++ -O2 -std=gnu++14 -w -I"$ROOT/include" -I"$ROOT/socp_amd/host/src/socp" -o "$OUT/bin/$prog" "$OUT/tests/$prog.cpp" \
         -L"$ROOT/socp_amd/_build" -lsocp_host -lsocp_hip -Wl,-rpath,"$ROOT/socp_amd/_build" -lpthread

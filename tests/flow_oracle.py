@@ -383,3 +383,58 @@ def covid_flow(solver="scipy", xtol=1e-8, stages=3, step_nbr=1000):
         info = sh.solve_data(0.01)
         out.append(dict(stage="horizon_continuation", info=int(info), nfev=int(sh.nfev), z=sh.z.copy()))
     return out
+
+
+def interceptor_flow(solver="scipy", xtol=1e-8, scenario=1):
+    """tests/testInterceptor.cpp on the oracle (PARITY UNPINNED, oracle/interceptor_oracle.c): analytical guess
+    at mu_gft = 0 -> Newton solve -> continuation of mu_gft to 1 (step 0.1) -> continuation of the boundary data
+    to the scenario (step 0.1).  M = 1, final time and final velocity free: n = 13."""
+    from oracle.oracle import MODEL_INTERCEPTOR
+    RE = 6378145.0
+    d = 6
+    mode_xf = np.zeros(d, dtype=np.int32)
+    mode_xf[1] = FREE
+    out = []
+    # initState(): testInterceptor.cpp:165-218
+    o = Oracle(MODEL_INTERCEPTOR)
+    sh = OracleShooting(o, 1, solver)
+    sh.xtol = xtol
+    sh.set_mode_final(FREE, mode_xf)
+    X0 = np.zeros(12)
+    X0[:6] = [1000, 1000, np.pi / 4, 0.0, 5454661 / RE, 46086 / RE]
+    X1 = np.zeros(12)
+    X1[:6] = [6000, 1000, 0.01 * np.pi, 0.01 * np.pi, (5454661 + 27829.0) / RE, 46086 / RE]
+    o.set_param("mu_gft", 0.0)
+    X0 = o.init_analytical(0.0, X0, 10.0, X1)
+    sh.init_uniform(0.0, X0, 10.0, X1)
+    info = sh.solve()
+    out.append(dict(stage="analytical_guess", info=int(info), nfev=int(sh.nfev), z=sh.z.copy()))
+    if info == 1:
+        info = sh.solve_param(0.1, lambda v: o.set_param("mu_gft", v), 0.0, 1.0)
+        out.append(dict(stage="mu_gft_continuation", info=int(info), nfev=int(sh.nfev), z=sh.z.copy()))
+    if info != 1:
+        return out
+    vt, vX = sh.get_solution()
+    # solve(): testInterceptor.cpp:117-160
+    Xi = np.zeros(12)
+    Xf = np.zeros(12)
+    Xi[:6] = [3000, 1000, 0.0, 0.0, 5454661 / RE, 46086 / RE]
+    Xf[1] = 1000
+    if scenario == 1:
+        Xi[2] = -np.pi / 6
+        Xf[0], Xf[2], Xf[3], Xf[4], Xf[5] = 12000, 0.0, np.pi / 8, 5475000 / RE, 42000 / RE
+    elif scenario == 2:
+        Xi[2] = np.pi / 4
+        Xf[0], Xf[2], Xf[3], Xf[4], Xf[5] = 12000, -np.pi / 4, -np.pi / 2, 5485000 / RE, 36178 / RE
+    else:
+        Xi[2] = 0.0
+        Xf[0], Xf[2], Xf[3], Xf[4], Xf[5] = 3000, 0.0, 0.0, 5485000 / RE, 46086 / RE
+    o2 = Oracle(MODEL_INTERCEPTOR)
+    sh2 = OracleShooting(o2, 1, solver)
+    sh2.xtol = xtol
+    sh2.set_mode_final(FREE, mode_xf)
+    sh2.init_uniform(vt[0], vX[0], vt[1], vX[1])
+    sh2.set_desired([0.0, 20.0], [Xi, Xf])
+    info = sh2.solve_data(0.1)
+    out.append(dict(stage="scenario_continuation", info=int(info), nfev=int(sh2.nfev), z=sh2.z.copy()))
+    return out
