@@ -21,6 +21,8 @@ template <class M> struct has_custom_traj<M, std::void_t<decltype(M::kCustomTraj
 template <class M, class = void> struct has_custom_final : std::false_type {};
 template <class M> struct has_custom_final<M, std::void_t<decltype(M::kCustomFinal)>> : std::bool_constant<M::kCustomFinal> {};
 
+constexpr int kAdaptiveStepBudget = 200000;
+
 struct NoObserver {
     template <class... A> __device__ __forceinline__ void operator()(A &&...) const {}
 };
@@ -148,7 +150,10 @@ struct Lane {
         if (!(h > 0)) return;                                   // zero-length / backward segment: no step
         double k1[S], xn[S], kn[S];
         bool have_k1 = false;
-        int budget = 1 << 22;                                   // every lane reaches an exit: bounded total work
+        // Every lane reaches an exit: at most kAdaptiveStepBudget trial steps per segment (odeint itself has no limit;
+        // a trajectory that runs into a singularity of the dynamics would otherwise hold its whole wave for minutes).
+        // Running out is reported like odeint's step_adjustment_error: the result is NaN.
+        int budget = kAdaptiveStepBudget;
         while (tf - t > eps && budget > 0) {
             while (t + h - tf <= eps && budget > 0) {
                 if (hook(t, X)) have_k1 = false;
@@ -169,6 +174,10 @@ struct Lane {
             }
             h = tf - t;
             have_k1 = false;
+        }
+        if (budget <= 0 && tf - t > eps) {
+#pragma unroll
+            for (int i = 0; i < S; i++) X[i] = __builtin_nan("");
         }
     }
 

@@ -114,8 +114,11 @@ def single_shooting_problem(o):
     return prob, np.concatenate([X0, [10.0]])
 
 
-def multi_shooting_problem(o, M, tf=24.0):
-    X0, Xf = scenario_state()
+def multi_shooting_problem(o, M, tf=24.0, X0=None, Xf=None):
+    """M segments over [0, tf]; node states along the trajectory from X0 (default: the analytical guess -- not a
+    solution, the later nodes are far from anything physical, which is what a first Newton iterate looks like)."""
+    if X0 is None:
+        X0, Xf = scenario_state()
     mode_t = [FIXED] + [CONTINUOUS] * (M - 1) + [FREE]
     mode_x = np.zeros((M + 1, 6), dtype=np.int32)
     mode_x[1:M] = CONTINUOUS
