@@ -21,7 +21,7 @@ template <class M> struct has_custom_traj<M, std::void_t<decltype(M::kCustomTraj
 template <class M, class = void> struct has_custom_final : std::false_type {};
 template <class M> struct has_custom_final<M, std::void_t<decltype(M::kCustomFinal)>> : std::bool_constant<M::kCustomFinal> {};
 
-constexpr int kAdaptiveStepBudget = 200000;
+constexpr int kAdaptiveStepBudget = 50000;
 
 struct NoObserver {
     template <class... A> __device__ __forceinline__ void operator()(A &&...) const {}

@@ -231,3 +231,25 @@ def test_interceptor_trace_file(tmp_path, built):
         o.set_flags(chart, stage)
         want = np.concatenate([[t], X, o.control(t, X), o.hamiltonian(t, X)])
         assert np.all(np.abs(rows[k, :-1] - want) <= 2e-5 * np.abs(want) + 1e-9), k
+
+
+def test_adaptive_budget_bounds_a_singular_trajectory(ictx, built):
+    """Nodes taken along the raw analytical guess run into v -> 0 (a singularity of the dynamics) on the late
+    segments; adaptive stepping there would take millions of steps.  The trial-step budget ends such a lane with
+    NaN (odeint's step_adjustment_error) instead of holding the wave; healthy segments are unaffected."""
+    import time
+    from socp_amd import capi
+    o = Oracle(MODEL_INTERCEPTOR)
+    prob, z = multi_shooting_problem(o, 21)
+    ictx.problem_set(prob.mode_t, prob.mode_x, prob.time, prob.xnode)
+    F_rk4 = ictx.residual(z)
+    ictx.set_integrator(capi.INT_DOPRI5, 1e-8)
+    t = time.perf_counter()
+    F = ictx.residual(z)
+    dt = time.perf_counter() - t
+    ictx.set_integrator(capi.INT_RK4)
+    assert dt < 60.0
+    assert np.isnan(F).any() or np.max(np.abs(F - F_rk4) / np.maximum(1.0, np.abs(F_rk4))) < 1e-2
+    early = slice(12, 12 * 6)                              # continuity rows of the first segments: well-behaved
+    assert np.all(np.isfinite(F[early]))
+    assert np.max(np.abs(F[early] - F_rk4[early]) / np.maximum(1.0, np.abs(F_rk4[early]))) < 1e-4
