@@ -88,6 +88,8 @@ int socp_ctx_set_variant(socp_ctx *ctx, int variant);
 /* enqueue on the caller's hipStream_t (NULL is the device's default stream); use_own != 0 switches
  * back to the context's private non-blocking stream */
 int socp_ctx_set_stream(socp_ctx *ctx, void *hip_stream, int use_own);
+/* the stream launches currently go to (the context's own stream or the one given to socp_ctx_set_stream) */
+int socp_ctx_get_stream(const socp_ctx *ctx, void **hip_stream);
 int socp_ctx_synchronize(socp_ctx *ctx);
 int socp_ctx_dims(const socp_ctx *ctx, int *dim, int *state_len, int *state_len_jac);
 int socp_ctx_control_dim(const socp_ctx *ctx);

@@ -288,6 +288,13 @@ int socp_ctx_set_stream(socp_ctx *c, void *hip_stream, int use_own)
     return SOCP_OK;
 }
 
+int socp_ctx_get_stream(const socp_ctx *c, void **hip_stream)
+{
+    if (!c || !hip_stream) return SOCP_ERR_ARG;
+    *hip_stream = static_cast<void *>(c->stream);
+    return SOCP_OK;
+}
+
 int socp_ctx_synchronize(socp_ctx *c)
 {
     if (!c) return SOCP_ERR_ARG;

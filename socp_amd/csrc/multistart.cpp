@@ -10,6 +10,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -64,6 +66,18 @@ extern "C" int socp_multistart_solve(socp_ctx *ctx, int P, const double *Z0, dou
         return SOCP_ERR_HIP;
     }
 
+    static const bool trace = std::getenv("SOCP_MULTISTART_TRACE") != nullptr;
+    static const bool overlap = [] { const char *e = std::getenv("SOCP_MULTISTART_OVERLAP"); return !(e && e[0] == '0'); }();   // =0: one stream (A/B)
+    // Residual requests and Jacobian requests of one round are independent launches, each one trajectory latency
+    // long: the residual batch goes to a second stream so the two overlap (rounds with both kinds are about half
+    // of a sweep's rounds once the starts fall out of step).
+    void *main_stream = nullptr;
+    hipStream_t aux = nullptr;
+    if (socp_ctx_synchronize(ctx) != SOCP_OK || socp_ctx_get_stream(ctx, &main_stream) != SOCP_OK ||
+        hipStreamCreateWithFlags(&aux, hipStreamNonBlocking) != hipSuccess) {
+        cleanup();
+        return SOCP_ERR_HIP;
+    }
     std::vector<int> flag(P, 0), reqF, reqJ;
     std::vector<double *> outF(P), outJ(P);
     std::vector<char> active(P, 1);
@@ -92,10 +106,14 @@ extern "C" int socp_multistart_solve(socp_ctx *ctx, int P, const double *Z0, dou
         if (reqF.empty() && reqJ.empty()) break;
         rounds++;
         const int kF = (int)reqF.size(), kJ = (int)reqJ.size();
+        if (trace) std::fprintf(stderr, "[socp_multistart] round %lld: %d residual requests, %d Jacobian requests\n", rounds, kF, kJ);
         // the residual launch and the first Jacobian chunk are enqueued before either result is awaited
         if (kF) {
             if (hipMemcpy(dX.p, hX.p, rowB * kF, hipMemcpyHostToDevice) != hipSuccess) { rc = SOCP_ERR_HIP; break; }
-            if ((rc = socp_residual_batch_dev(ctx, kF, dX.d(), dF.d())) != SOCP_OK) break;
+            if (overlap) socp_ctx_set_stream(ctx, aux, 0);
+            rc = socp_residual_batch_dev(ctx, kF, dX.d(), dF.d());
+            if (overlap) socp_ctx_set_stream(ctx, main_stream, 0);
+            if (rc != SOCP_OK) break;
         }
         if (kJ) {
             if (hipMemcpy(dJx.p, hJx.p, rowB * kJ, hipMemcpyHostToDevice) != hipSuccess ||
@@ -106,13 +124,14 @@ extern "C" int socp_multistart_solve(socp_ctx *ctx, int P, const double *Z0, dou
             const int kc = j0 < kJ ? std::min(jchunk, kJ - j0) : 0;
             if (kc && (rc = socp_fd_jacobian_multi_dev(ctx, kc, dJx.d() + (size_t)j0 * n, dJf.d() + (size_t)j0 * n, epsfcn,
                                                         dJ.d(), dedup)) != SOCP_OK) break;
-            if ((rc = socp_ctx_synchronize(ctx)) != SOCP_OK) break;
             if (!f_collected) {
-                if (hipMemcpy(hF.p, dF.p, rowB * kF, hipMemcpyDeviceToHost) != hipSuccess) { rc = SOCP_ERR_HIP; break; }
+                if (hipStreamSynchronize(overlap ? aux : static_cast<hipStream_t>(main_stream)) != hipSuccess ||
+                    hipMemcpy(hF.p, dF.p, rowB * kF, hipMemcpyDeviceToHost) != hipSuccess) { rc = SOCP_ERR_HIP; break; }
                 for (int k = 0; k < kF; k++) std::memcpy(outF[k], hF.d() + (size_t)k * n, rowB);
                 f_collected = true;
             }
             if (kc) {
+                if ((rc = socp_ctx_synchronize(ctx)) != SOCP_OK) break;
                 if (hipMemcpy(hJ.p, dJ.p, jacB * kc, hipMemcpyDeviceToHost) != hipSuccess) { rc = SOCP_ERR_HIP; break; }
                 for (int k = 0; k < kc; k++) std::memcpy(outJ[j0 + k], hJ.d() + (size_t)k * n * n, jacB);
             }
@@ -133,6 +152,8 @@ extern "C" int socp_multistart_solve(socp_ctx *ctx, int P, const double *Z0, dou
         }
     }
     if (rounds_out) *rounds_out = rounds;
+    (void)hipStreamSynchronize(aux);
+    (void)hipStreamDestroy(aux);
     cleanup();
     return rc;
 }
