@@ -118,3 +118,37 @@ def test_config3_64_segments_history(order):
     s, g = stages[0], gold[0]
     assert (s["info"], s["nfev"]) == (g["info"], g["nfev"]) and (order == 0 or s["njev"] == g["njev"])
     assert np.max(np.abs(np.array(s["z"]) - np.array(g["z"]))) <= 1e-13 * np.max(np.abs(g["z"]))
+
+
+@pytest.mark.parametrize("M", [7, 100])
+def test_row_tiles_and_direct_stores_agree_with_cpu(doracle, M, monkeypatch):
+    """The residual kernels write whole rows through an LDS tile when M <= 64 (several rows per workgroup, the
+    last workgroup partly filled) and store directly when M > 64; `SOCP_ROW_TILES=0` forces the direct form.
+    All of them must give the CPU path's bits, for batches that do not divide evenly."""
+    from socp_amd import capi
+    prob, z = _wp_problem(M)
+    rng = np.random.default_rng(M)
+    B = 11
+    Z = z[None, :] + 1e-3 * rng.uniform(-1, 1, (B, prob.n))
+    want = doracle.residual_batch(prob, Z)
+    c = capi.Context(capi.MODEL_DOUBLE_INTEGRATOR)
+    assert c.problem_set(prob.mode_t, prob.mode_x, prob.time, prob.xnode) == prob.n
+    assert np.array_equal(c.residual_batch(Z), want)
+    rows = c.fd_rows(Z[:2])
+    assert np.array_equal(rows[:, 0, :], want[:2])
+    eps = np.sqrt(1e-15)
+    for j in (0, 5, prob.n - 1):
+        zp = Z[1].copy()
+        zp[j] += (eps * abs(zp[j])) or eps
+        assert np.array_equal(rows[1, j + 1], doracle.residual(prob, zp)), j
+    c.close()
+    # the same through the direct-store form, in a fresh process (the switch is read once)
+    code = ("import numpy as np, sys; sys.path.insert(0, %r); from socp_amd import capi; "
+            "d = np.load(sys.argv[1]); c = capi.Context(capi.MODEL_DOUBLE_INTEGRATOR); "
+            "c.problem_set(d['mt'], d['mx'], d['t'], d['x']); np.save(sys.argv[2], c.residual_batch(d['Z']))" % ROOT)
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        np.savez(os.path.join(td, "in.npz"), mt=prob.mode_t, mx=prob.mode_x, t=prob.time, x=prob.xnode, Z=Z)
+        subprocess.run(["python", "-c", code, os.path.join(td, "in.npz"), os.path.join(td, "out.npy")], check=True,
+                       env=dict(os.environ, SOCP_ROW_TILES="0"), timeout=300)
+        assert np.array_equal(np.load(os.path.join(td, "out.npy")), want)
