@@ -14,26 +14,51 @@
 
 namespace socp {
 
-// 1/x to double precision from the hardware estimate + two Newton steps (no div_scale/fixup:
-// arguments here are O(1) masses, never subnormal or huge)
+// 1/x to double precision from the hardware estimate r0 (relative error e ~ 2^-24) in ONE cubic step:
+// 1/x = r0 / (1 - e) with e = 1 - x r0, so r0 (1 + e + e^2) is off by e^3 ~ 1e-22 (no div_scale/fixup:
+// arguments here are O(1) masses, never subnormal or huge).  4 instructions.
 __device__ __forceinline__ double fast_rcp(double x)
 {
-    double r = __builtin_amdgcn_rcp(x);
-    double e = __builtin_fma(-x, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    e = __builtin_fma(-x, r, 1.0);
-    return __builtin_fma(r, e, r);
+    const double r = __builtin_amdgcn_rcp(x);
+    const double e = __builtin_fma(-x, r, 1.0);
+    const double p = __builtin_fma(e, e, e);
+    return __builtin_fma(r, p, r);
 }
 
-// 1/sqrt(x) to double precision: hardware estimate + two coupled Newton steps
+// 1/sqrt(x) to double precision, one cubic step from the hardware estimate y0: with d = 1 - x y0^2,
+// 1/sqrt(x) = y0 (1 - d)^(-1/2) = y0 (1 + d/2 + 3/8 d^2 + 5/16 d^3 ...); y0 + y0 d (1/2 + 3/8 d) is off by
+// 5/16 d^3 ~ 1e-22.  6 instructions.
 __device__ __forceinline__ double fast_rsqrt(double x)
 {
-    double y = __builtin_amdgcn_rsq(x);
-    double h = 0.5 * x;
-    double e = __builtin_fma(-h * y, y, 0.5);
-    y = __builtin_fma(y, e, y);
-    e = __builtin_fma(-h * y, y, 0.5);
-    return __builtin_fma(y, e, y);
+    const double y = __builtin_amdgcn_rsq(x);
+    const double d = __builtin_fma(-(x * y), y, 1.0);
+    const double p = __builtin_fma(0.375, d, 0.5);
+    return __builtin_fma(y * d, p, y);
+}
+
+// exp(x) without the library's overflow / underflow selects: n = round(x log2 e), t = x - n ln2 (two-part
+// ln2), exp(t) = 1 + t + t^2 g(t) with g a degree-9 interpolant of (e^t - 1 - t)/t^2 at the Chebyshev nodes of
+// |t| <= ln2/2 (coefficients solved in 80-digit arithmetic; evaluated error <= 1 ulp), scaled by ldexp --
+// which itself saturates to 0 / inf; NaN propagates through the polynomial.  The air-density term of the
+// Goddard model has |x| = kr |r - 1| of order 10.
+__device__ __forceinline__ double fast_exp(double x)
+{
+    const double n = __builtin_rint(x * 1.4426950408889634);
+    double t = __builtin_fma(-n, 0x1.62e42fefa39efp-1, x);
+    t = __builtin_fma(-n, 0x1.abc9e3b39803fp-56, t);
+    double p = 0x1.af38d53857513p-26;
+    p = __builtin_fma(p, t, 0x1.2891a8c1d838dp-22);
+    p = __builtin_fma(p, t, 0x1.71de0d9c145d0p-19);
+    p = __builtin_fma(p, t, 0x1.a019b8ef67c6cp-16);
+    p = __builtin_fma(p, t, 0x1.a01a01a7c8d47p-13);
+    p = __builtin_fma(p, t, 0x1.6c16c17893833p-10);
+    p = __builtin_fma(p, t, 0x1.11111111109adp-7);
+    p = __builtin_fma(p, t, 0x1.5555555553d4fp-5);
+    p = __builtin_fma(p, t, 0x1.5555555555556p-3);
+    p = __builtin_fma(p, t, 0x1.0000000000001p-1);
+    p = __builtin_fma(p, t, 1.0);
+    p = __builtin_fma(p, t, 1.0);
+    return ldexp(p, (int)n);
 }
 
 template <bool SMOOTH>
@@ -58,7 +83,7 @@ struct GoddardFastT {
         const double im = fast_rcp(mass);
         const double pvdotv = p_vx*vx + p_vy*vy + p_vz*vz;
         const double pvdotr = p_vx*x + p_vy*y + p_vz*z;
-        const double E = exp(-kr*(r - 1));
+        const double E = fast_exp(-kr*(r - 1));
         const double ir2 = ir * ir;              // g = 1/r^2
         const double ir3 = ir2 * ir;             // g/r
 
@@ -66,9 +91,12 @@ struct GoddardFastT {
         const double Cm = C * im;
         const double Switch = P.p[GP_MU1] - b*p_mass - Cm*norm_pv;
         double alpha = 0;
-        if (SMOOTH || P.p[GP_MU2] > 0) {
+        if constexpr (SMOOTH) {
+            alpha = __builtin_fmax(-Switch * (0.5 / P.p[GP_MU2]), 0.0);      // Switch < 0 ? -Switch/(2 mu2) : 0
+        } else if (P.p[GP_MU2] > 0) {
             if (Switch < 0) alpha = -Switch * (0.5 / P.p[GP_MU2]);
-        } else if constexpr (!SMOOTH) {
+        }
+        if constexpr (!SMOOTH) if (!(P.p[GP_MU2] > 0)) {
             if (t <= sw0) {
                 alpha = 1.0;
             } else if (t > sw0 && t <= sw1) {
@@ -82,34 +110,40 @@ struct GoddardFastT {
             }
         }
         const double u_max = P.p[GP_UMAX];
-        const double a_abs = fabs(alpha);
         // u = -p_v/|p_v| * alpha, rescaled to |u| = u_max when |alpha| > u_max (:167-176)
         // (alpha * u_max/|alpha| = sign(alpha) * u_max: no division needed)
-        const double norm_u = a_abs > u_max ? u_max : a_abs;
-        const double a_eff = copysign(norm_u, alpha);
-        const double ua = -a_eff * iq;
-        const double u0 = p_vx * ua, u1 = p_vy * ua, u2 = p_vz * ua;
+        double norm_u, a_eff;
+        if constexpr (SMOOTH) {
+            norm_u = __builtin_fmin(alpha, u_max);           // the smooth law gives alpha >= 0
+            a_eff = norm_u;
+        } else {
+            const double a_abs = fabs(alpha);
+            norm_u = a_abs > u_max ? u_max : a_abs;
+            a_eff = copysign(norm_u, alpha);
+        }
+        const double ua = -a_eff * iq;                       // u = ua * p_v
         const double pvdotu = -a_eff * norm_pv;
 
-        // state equations (:81-87)
+        // state equations (:81-87), thrust term C/m u_i written as (C/m ua) p_v,i
         const double Dm = KD * E * im;           // KD exp(-kr(r-1)) / m
         const double Dv = Dm * v;
+        const double Tm = Cm * ua;
         dX[0] = vx;
         dX[1] = vy;
         dX[2] = vz;
-        dX[3] = Cm*u0 - Dv*vx - ir3*x;
-        dX[4] = Cm*u1 - Dv*vy - ir3*y;
-        dX[5] = Cm*u2 - Dv*vz - ir3*z;
+        dX[3] = Tm*p_vx - Dv*vx - ir3*x;
+        dX[4] = Tm*p_vy - Dv*vy - ir3*y;
+        dX[5] = Tm*p_vz - Dv*vz - ir3*z;
         dX[6] = -b*norm_u;
         // costate equations (:91-97)
         const double W = -(kr * Dv * pvdotv * ir) - 3.0 * ir3 * ir2 * pvdotr;
         dX[7] = W*x + ir3*p_vx;
         dX[8] = W*y + ir3*p_vy;
         dX[9] = W*z + ir3*p_vz;
-        const double G = pvdotv * iv;
-        dX[10] = Dm*(G*vx + p_vx*v) - p_x;
-        dX[11] = Dm*(G*vy + p_vy*v) - p_y;
-        dX[12] = Dm*(G*vz + p_vz*v) - p_z;
+        const double DG = Dm * (pvdotv * iv);
+        dX[10] = DG*vx + (Dv*p_vx - p_x);
+        dX[11] = DG*vy + (Dv*p_vy - p_y);
+        dX[12] = DG*vz + (Dv*p_vz - p_z);
         dX[13] = im * (Cm*pvdotu - Dv*pvdotv);
     }
 
