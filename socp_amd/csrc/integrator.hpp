@@ -422,27 +422,32 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, WPE))) vo
 {
     extern __shared__ __attribute__((aligned(16))) double tile[];
     const int M = pb.M, n = pb.n;
+    // one code path for both output forms: `out` is the lane's row either in the LDS tile or in F itself
+    long b;
+    int i;
+    double *out;
+    bool live;
+    const long row0 = (long)blockIdx.x * rows_per_block;
+    const int rows = rows_per_block ? ((B - row0) < rows_per_block ? (int)(B - row0) : rows_per_block) : 0;
     if (rows_per_block == 0) {
         const long T = (long)blockIdx.x * 64 + threadIdx.x;
-        if (T >= (long)B * M) return;
-        const long b = T / M;
-        const int i = (int)(T - b * M);
+        live = T < (long)B * M;
+        b = T / M;
+        i = (int)(T - b * M);
+        out = F + b * n;
+    } else {
+        const int lane = threadIdx.x, lr = lane / M;
+        live = lane < rows * M;
+        b = row0 + lr;
+        i = lane - lr * M;
+        out = tile + (long)lr * n;
+    }
+    if (live) {
         const double *zr = Z + b * n;
-        double *fr = F + b * n;
         auto z = [=](int k) -> double { return zr[k]; };
-        segment_residual<Mdl, INTEG>(P, pb, z, i, [=](int row, double v) { fr[row] = v; });
-        return;
+        segment_residual<Mdl, INTEG>(P, pb, z, i, [=](int row, double v) { out[row] = v; });
     }
-    const long row0 = (long)blockIdx.x * rows_per_block;
-    const int rows = (B - row0) < rows_per_block ? (int)(B - row0) : rows_per_block;
-    const int lane = threadIdx.x;
-    if (lane < rows * M) {
-        const int lr = lane / M, i = lane - lr * M;
-        const double *zr = Z + (row0 + lr) * n;
-        double *tr = tile + (long)lr * n;
-        auto z = [=](int k) -> double { return zr[k]; };
-        segment_residual<Mdl, INTEG>(P, pb, z, i, [=](int row, double v) { tr[row] = v; });
-    }
+    if (rows_per_block == 0) return;                 // uniform over the workgroup
     __syncthreads();
     store_tile(tile, F + row0 * n, (long)rows * n);
 }
@@ -491,7 +496,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, WPE))) vo
     extern __shared__ __attribute__((aligned(16))) double tile[];
     const int M = pb.M, n = pb.n;
     const long total_rows = (long)np * (n + 1);          // virtual residual rows: (problem, FD row)
-    auto run = [&](long vrow, int i, double *out) {
+    // one code path for both output forms: `out` is the lane's row either in the LDS tile or in Rows itself
+    long vrow;
+    int i;
+    double *out;
+    bool live;
+    const long row0 = (long)blockIdx.x * rows_per_block;
+    const int rows = rows_per_block ? ((total_rows - row0) < rows_per_block ? (int)(total_rows - row0) : rows_per_block) : 0;
+    if (rows_per_block == 0) {
+        const long tid = (long)blockIdx.x * 64 + threadIdx.x;
+        live = tid < total_rows * M;
+        vrow = tid / M;
+        i = (int)(tid - vrow * M);
+        out = Rows + vrow * n;
+    } else {
+        const int lane = threadIdx.x, lr = lane / M;
+        live = lane < rows * M;
+        vrow = row0 + lr;
+        i = lane - lr * M;
+        out = tile + (long)lr * n;
+    }
+    if (live) {
         const long prob = vrow / (n + 1);
         const int row = (int)(vrow - prob * (n + 1));    // 0 = base, j+1 = column j
         const int j = row - 1;
@@ -499,21 +524,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, WPE))) vo
         const double zj = j >= 0 ? zb[j] + fd_step(zb[j], eps) : 0.0;
         auto z = [=](int k) -> double { const double v = zb[k]; return k == j ? zj : v; };
         segment_residual<Mdl, INTEG>(P, pb, z, i, [=](int r, double v) { out[r] = v; });
-    };
-    if (rows_per_block == 0) {
-        const long tid = (long)blockIdx.x * 64 + threadIdx.x;
-        if (tid >= total_rows * M) return;
-        const long vrow = tid / M;
-        run(vrow, (int)(tid - vrow * M), Rows + vrow * n);
-        return;
     }
-    const long row0 = (long)blockIdx.x * rows_per_block;
-    const int rows = (total_rows - row0) < rows_per_block ? (int)(total_rows - row0) : rows_per_block;
-    const int lane = threadIdx.x;
-    if (lane < rows * M) {
-        const int lr = lane / M;
-        run(row0 + lr, lane - lr * M, tile + (long)lr * n);
-    }
+    if (rows_per_block == 0) return;                 // uniform over the workgroup
     __syncthreads();
     store_tile(tile, Rows + row0 * n, (long)rows * n);
 }
