@@ -21,3 +21,6 @@ for prog in testGoddard testDoubleIntegrator testDoubleIntegrator_WP testCovid19
         -L"$ROOT/socp_amd/_build" -lsocp_host -lsocp_hip -Wl,-rpath,"$ROOT/socp_amd/_build" -lpthread
     echo "built $OUT/bin/$prog"
 done
+# the scratch tree only existed to resolve the includes: remove the links so that nothing under oracle/_ref
+# points at (or could be resolved into) reference sources when the directory travels to the GPU box
+rm -rf "$OUT/tests" "$OUT/src"
