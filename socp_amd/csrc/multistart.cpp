@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -78,28 +79,45 @@ extern "C" int socp_multistart_solve(socp_ctx *ctx, int P, const double *Z0, dou
         cleanup();
         return SOCP_ERR_HIP;
     }
-    std::vector<int> flag(P, 0), reqF, reqJ;
+    std::vector<int> flag(P, 0), reqF, reqJ, req(P, SOCP_REQ_DONE);
+    std::vector<const double *> xin(P, nullptr);
+    std::vector<double *> xout(P, nullptr);
+    // host threads for step (1): all cores up to 16, one thread for small sweeps (thread start-up is ~50 us each)
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int nthreads = ((long)P * n * n < 200000) ? 1 : (int)std::max(1u, std::min(16u, hw ? hw : 1u));
+    auto parallel_for = [&](int count, auto &&body) {
+        if (nthreads <= 1) { for (int k = 0; k < count; k++) body(k); return; }
+        std::vector<std::thread> pool;
+        pool.reserve(nthreads);
+        for (int t = 0; t < nthreads; t++)
+            pool.emplace_back([&, t]() { for (int k = t; k < count; k += nthreads) body(k); });
+        for (std::thread &th : pool) th.join();
+    };
     std::vector<double *> outF(P), outJ(P);
     std::vector<char> active(P, 1);
     long long rounds = 0;
     int rc = SOCP_OK;
     for (;;) {
         reqF.clear(); reqJ.clear();
+        // (1) advance every active state machine -- QR, dogleg, Broyden update: O(n^2)..O(n^3) host work per start,
+        //     independent between starts, so it is spread over the host cores
+        parallel_for(P, [&](int p) {
+            if (!active[p]) return;
+            req[p] = socp_hybr_advance(solver[p], flag[p], &xin[p], &xout[p]);
+            flag[p] = 0;
+        });
+        // (2) gather the requests into the staging buffers in start order (keeps the batches deterministic)
         for (int p = 0; p < P; p++) {
             if (!active[p]) continue;
-            const double *xe = nullptr;
-            double *out = nullptr;
-            const int req = socp_hybr_advance(solver[p], flag[p], &xe, &out);
-            flag[p] = 0;
-            if (req == SOCP_REQ_DONE) { active[p] = 0; continue; }
-            if (req == SOCP_REQ_FVEC) {
-                std::memcpy(hX.d() + (size_t)reqF.size() * n, xe, rowB);
-                outF[reqF.size()] = out;
+            if (req[p] == SOCP_REQ_DONE) { active[p] = 0; continue; }
+            if (req[p] == SOCP_REQ_FVEC) {
+                std::memcpy(hX.d() + (size_t)reqF.size() * n, xin[p], rowB);
+                outF[reqF.size()] = xout[p];
                 reqF.push_back(p);
             } else {
-                std::memcpy(hJx.d() + (size_t)reqJ.size() * n, xe, rowB);
+                std::memcpy(hJx.d() + (size_t)reqJ.size() * n, xin[p], rowB);
                 std::memcpy(hJf.d() + (size_t)reqJ.size() * n, socp_hybr_fvec(solver[p]), rowB);
-                outJ[reqJ.size()] = out;
+                outJ[reqJ.size()] = xout[p];
                 reqJ.push_back(p);
             }
         }

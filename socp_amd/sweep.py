@@ -78,6 +78,36 @@ def goddard_single_shooting_problem(ctx, tf=TF):
     return ctx.problem_set([capi.FIXED, capi.FIXED], mode_x, np.array([0.0, tf]), X)
 
 
+def goddard_multiple_shooting_problem(ctx, M, tf=TF):
+    """The testGoddard layout (testGoddard.cpp:24-82) with M segments: initial state fixed, interior nodes
+    CONTINUOUS, final altitude pinned at 1.01, final velocity and mass free, final time FREE: n = 14 M + 1."""
+    from . import capi
+    mode_t = [capi.FIXED] + [capi.CONTINUOUS] * (M - 1) + [capi.FREE]
+    mode_x = np.zeros((M + 1, 7), dtype=np.int32)
+    mode_x[1:M] = capi.CONTINUOUS
+    mode_x[M, 3:7] = capi.FREE
+    X = np.zeros((M + 1, 14))
+    X[0, :7] = X0_STATE
+    X[M, 0] = 1.01
+    return ctx.problem_set(mode_t, mode_x, np.linspace(0.0, tf, M + 1), X)
+
+
+def goddard_multiple_shooting_starts(ctx, Z14, M, tf=TF):
+    """Unknown vectors [node states | tf] of the M-segment problem: node 0 = the start's perturbed initial state,
+    nodes 1..M-1 = the converged trajectory re-gridded to M uniform segments (the set-up of the survey's
+    convergence-basin probe), integrated on the device."""
+    P = Z14.shape[0]
+    Z = np.empty((P, 14 * M + 1))
+    Z[:, :14] = Z14
+    Z[:, -1] = tf
+    if M > 1:
+        star = np.concatenate([X0_STATE, PSTAR])[None, :]
+        tk = np.linspace(0.0, tf, M + 1)[1:M]
+        nodes = ctx.integrate_batch(np.zeros(M - 1), tk, np.repeat(star, M - 1, axis=0))
+        Z[:, 14:14 * M] = nodes.reshape(1, 14 * (M - 1))
+    return Z
+
+
 def run_sweep(Z0, solve_local, dist=None, device=None):
     """Shard the rows of Z0 over the ranks, solve, gather.  `solve_local(Zblock)` returns a dict with
     z [k][n], info [k], nfev [k], fnorm [k].  Returns (table [P][n+3] in start order, local dict)."""
@@ -104,7 +134,11 @@ def run_sweep(Z0, solve_local, dist=None, device=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--starts", type=int, default=4096)
-    ap.add_argument("--eps", type=float, default=1e-3)
+    ap.add_argument("--eps", type=float, default=None,
+                    help="relative costate perturbation; default 1e-3 for single shooting, 0.05 for --segments >= 2 "
+                         "(single shooting diverges beyond ~0.3 %%, SURVEY 7 hard part 3)")
+    ap.add_argument("--segments", type=int, default=1, help="1: single shooting, fixed tf (n = 14); M >= 2: the "
+                    "testGoddard layout with M segments and free tf (n = 14 M + 1)")
     ap.add_argument("--rk4-steps", type=int, default=10000)
     ap.add_argument("--xtol", type=float, default=1e-8)
     ap.add_argument("--variant", choices=["exact", "fast"], default="fast")
@@ -127,8 +161,16 @@ def main():
     ctx.set_params(GODDARD_PARAMS)
     ctx.set_step_number(args.rk4_steps)
     ctx.set_variant(capi.VARIANT_LANE_FAST if args.variant == "fast" else capi.VARIANT_LANE_EXACT)
-    goddard_single_shooting_problem(ctx)
-    Z0 = goddard_starts(args.starts, args.eps)
+    eps = args.eps if args.eps is not None else (1e-3 if args.segments == 1 else 0.05)
+    Z0 = goddard_starts(args.starts, eps)
+    if args.segments == 1:
+        goddard_single_shooting_problem(ctx)
+    else:
+        goddard_multiple_shooting_problem(ctx, args.segments)
+        lo, hi = shard(args.starts, rank, world)
+        Zfull = np.zeros((args.starts, 14 * args.segments + 1))
+        Zfull[lo:hi] = goddard_multiple_shooting_starts(ctx, Z0[lo:hi], args.segments)     # each rank builds its own rows
+        Z0 = Zfull
     n_unknown = Z0.shape[1]
 
     if world > 1:
@@ -148,7 +190,8 @@ def main():
         conv = table[info == 1, :n_unknown]
         spread = float(np.max(np.abs(conv - np.median(conv, axis=0))) / np.max(np.abs(conv))) if len(conv) else None
         print(json.dumps({"solution_spread_rel": spread, "max_fnorm_converged": float(np.max(table[info == 1, -3])) if len(conv) else None,
-                          "sweep": "goddard_single_shooting_n14", "starts": args.starts, "eps": args.eps, "n_gpus": world,
+                          "sweep": "goddard_single_shooting_n14" if args.segments == 1 else "goddard_multiple_shooting_M%d_n%d" % (args.segments, n_unknown),
+                          "starts": args.starts, "eps": eps, "n_gpus": world,
                           "rk4_steps": args.rk4_steps, "variant": args.variant, "xtol": args.xtol, "wall_s": wall,
                           "converged": int(np.sum(info == 1)), "info_histogram": {str(k): int(np.sum(info == k)) for k in np.unique(info)},
                           "trajectories": int(traj.item()), "trajectories_per_s": traj.item() / wall,
