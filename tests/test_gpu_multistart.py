@@ -42,3 +42,29 @@ def test_sweep_single_process_on_gpu():
     table, local = sweep.run_sweep(Z0, lambda Zb: ctx.multistart_solve(Zb, xtol=1e-8))
     assert table.shape == (64, 17) and np.all(table[:, -2] == 1)
     ctx.close()
+
+
+@pytest.mark.parametrize("variant", ["exact", "fast"])
+def test_multiple_shooting_sweep_lands_on_the_cpu_solution(variant):
+    """The testGoddard layout (M = 6, free tf, n = 85) swept from 5 %-perturbed costates: every start converges,
+    and to the converged solution of the CPU path (golden: stage 2 of the reference's test program over the
+    oracle, xtol 1e-12) within north_star's 1e-8 -- with enough starts (>= 200000 / n^2) to go through the
+    threaded host side."""
+    import json
+    import os
+    from socp_amd import capi, sweep
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gold = json.load(open(os.path.join(root, "tests", "golden", "goddard_flow.json")))["goddard_single_stage"]
+    zg = np.array([g for g in gold if g["stage"] == 2 and g["xtol"] == 1e-12][0]["z"])
+    ctx = capi.Context(capi.MODEL_GODDARD)
+    ctx.set_params(sweep.GODDARD_PARAMS)
+    ctx.set_step_number(10)                                  # the test program's step count
+    ctx.set_variant(capi.VARIANT_LANE_FAST if variant == "fast" else capi.VARIANT_LANE_EXACT)
+    assert sweep.goddard_multiple_shooting_problem(ctx, 6, tf=zg[-1]) == 85
+    P = 40
+    Z0 = sweep.goddard_multiple_shooting_starts(ctx, sweep.goddard_starts(P, 0.05), 6, tf=zg[-1])
+    out = ctx.multistart_solve(Z0, xtol=1e-12)
+    assert np.all(out["info"] == 1)
+    err = np.max(np.abs(out["z"] - zg[None, :]), axis=1) / np.max(np.abs(zg))
+    assert np.max(err) <= 1e-8, err.max()
+    ctx.close()
