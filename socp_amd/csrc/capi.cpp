@@ -45,7 +45,8 @@ struct DevBuf {
 
 struct socp_ctx {
     int model_id = 0;
-    const ModelLaunchers *vt = nullptr;   // out-of-tree model: its launch table (socp_plugin.h)
+    const ModelLaunchers *vt = nullptr;   // table-driven model (out-of-tree plugin, or in-tree interceptor): its launch table
+    const ModelLaunchers *vt_fast = nullptr;   // the same model's throughput flavour, when it has one
     int device = 0;
     int dim = 0, S = 0, nu = 3;
     int nparams = 0;
@@ -104,6 +105,9 @@ bool use_fast(const socp_ctx *c)
     return c->variant == SOCP_VARIANT_LANE_FAST && c->P.integrator == SOCP_INT_RK4;
 }
 
+// launch table of a table-driven model for the current variant / integrator
+const ModelLaunchers *table_of(const socp_ctx *c) { return (use_fast(c) && c->vt_fast) ? c->vt_fast : c->vt; }
+
 int check_variant(socp_ctx *c)
 {
     if (c->variant == SOCP_VARIANT_WAVE)
@@ -115,7 +119,7 @@ hipError_t run_traj(socp_ctx *c, int B, const double *t0, const double *tf, cons
                     const double *X0, double *Xf)
 {
     c->n_traj += B; c->n_launch += 1;
-    if (c->vt) return c->vt->traj(c->stream, c->P, B, t0, tf, sw, X0, Xf);
+    if (c->vt) return table_of(c)->traj(c->stream, c->P, B, t0, tf, sw, X0, Xf);
     return use_fast(c) ? traj_fast(c->model_id, c->stream, c->P, B, t0, tf, sw, X0, Xf)
                        : traj_exact(c->model_id, c->stream, c->P, B, t0, tf, sw, X0, Xf);
 }
@@ -123,7 +127,7 @@ hipError_t run_traj(socp_ctx *c, int B, const double *t0, const double *tf, cons
 hipError_t run_residual(socp_ctx *c, int B, const double *Z, double *F)
 {
     c->n_traj += (long long)B * c->M; c->n_launch += 1;
-    if (c->vt) return c->vt->residual(c->stream, c->P, c->pb, B, Z, F);
+    if (c->vt) return table_of(c)->residual(c->stream, c->P, c->pb, B, Z, F);
     return use_fast(c) ? residual_fast(c->model_id, c->stream, c->P, c->pb, B, Z, F)
                        : residual_exact(c->model_id, c->stream, c->P, c->pb, B, Z, F);
 }
@@ -132,7 +136,7 @@ hipError_t run_fdjac(socp_ctx *c, int np, int T, const int2 *pairs, const double
                      double eps, double *fjac)
 {
     c->n_traj += (long long)np * T; c->n_launch += 1;
-    if (c->vt) return c->vt->fdjac(c->stream, c->P, c->pb, np, T, pairs, z, fvec, eps, fjac);
+    if (c->vt) return table_of(c)->fdjac(c->stream, c->P, c->pb, np, T, pairs, z, fvec, eps, fjac);
     return use_fast(c) ? fdjac_fast(c->model_id, c->stream, c->P, c->pb, np, T, pairs, z, fvec, eps, fjac)
                        : fdjac_exact(c->model_id, c->stream, c->P, c->pb, np, T, pairs, z, fvec, eps, fjac);
 }
@@ -140,7 +144,7 @@ hipError_t run_fdjac(socp_ctx *c, int np, int T, const int2 *pairs, const double
 hipError_t run_fdrows(socp_ctx *c, int np, const double *z, double eps, double *rows)
 {
     c->n_traj += (long long)np * (c->n + 1) * c->M; c->n_launch += 1;
-    if (c->vt) return c->vt->fdrows(c->stream, c->P, c->pb, np, z, eps, rows);
+    if (c->vt) return table_of(c)->fdrows(c->stream, c->P, c->pb, np, z, eps, rows);
     return use_fast(c) ? fdrows_fast(c->model_id, c->stream, c->P, c->pb, np, z, eps, rows)
                        : fdrows_exact(c->model_id, c->stream, c->P, c->pb, np, z, eps, rows);
 }
@@ -178,6 +182,7 @@ int socp_ctx_create(socp_ctx **out, int model_id, int device)
     socp_ctx *c = new socp_ctx;
     c->model_id = model_id;
     c->vt = vt;
+    if (model_id == SOCP_MODEL_INTERCEPTOR) c->vt_fast = interceptor_launchers_fast();
     c->device = device;
     if (vt) {
         c->dim = vt->dim; c->nparams = vt->nparams; c->nu = vt->control_dim;
@@ -398,7 +403,7 @@ int socp_integrate_dense_aux(socp_ctx *c, double t0, double tf, const double *sw
     const double s0 = sw ? sw[0] : c->P.sw0, s1 = sw ? sw[1] : c->P.sw1;
     c->n_traj += 1; c->n_launch += 1;
     hipError_t e = c->vt
-        ? c->vt->dense(c->stream, c->P, t0, tf, s0, s1, c->s_in.as<double>(), c->s_out.as<double>(), c->s_t0.as<double>(), cap, c->s_aux.as<int>(), d_aux)
+        ? table_of(c)->dense(c->stream, c->P, t0, tf, s0, s1, c->s_in.as<double>(), c->s_out.as<double>(), c->s_t0.as<double>(), cap, c->s_aux.as<int>(), d_aux)
         : use_fast(c)
         ? dense_fast(c->model_id, c->stream, c->P, t0, tf, s0, s1, c->s_in.as<double>(), c->s_out.as<double>(), c->s_t0.as<double>(), cap, c->s_aux.as<int>(), d_aux)
         : dense_exact(c->model_id, c->stream, c->P, t0, tf, s0, s1, c->s_in.as<double>(), c->s_out.as<double>(), c->s_t0.as<double>(), cap, c->s_aux.as<int>(), d_aux);
@@ -447,7 +452,7 @@ int socp_eval_batch(socp_ctx *c, int what, int B, const double *t, const double 
     hipError_t e = var
         ? var_eval(c->model_id, c->stream, c->P, what == SOCP_EVAL_RHS ? 0 : 1, B, c->s_in.as<double>(), len, c->s_out.as<double>())
         : c->vt
-        ? c->vt->eval(c->stream, c->P, what, B, c->s_t0.as<double>(), dsw, c->s_in.as<double>(), c->s_out.as<double>())
+        ? table_of(c)->eval(c->stream, c->P, what, B, c->s_t0.as<double>(), dsw, c->s_in.as<double>(), c->s_out.as<double>())
         : use_fast(c)
         ? eval_fast(c->model_id, c->stream, c->P, what, B, c->s_t0.as<double>(), dsw, c->s_in.as<double>(), c->s_out.as<double>())
         : eval_exact(c->model_id, c->stream, c->P, what, B, c->s_t0.as<double>(), dsw, c->s_in.as<double>(), c->s_out.as<double>());

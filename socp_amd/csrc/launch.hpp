@@ -50,6 +50,7 @@ hipError_t fd_diff(hipStream_t st, int n, int np, const double *z, double eps, c
 SOCP_DECLARE_LAUNCHERS(fast)
 
 // in-tree models that live in their own translation unit behind a launch table, like an out-of-tree plugin
-const ModelLaunchers *interceptor_launchers();      // kernels_interceptor.hip
+const ModelLaunchers *interceptor_launchers();      // kernels_interceptor.hip      (reference operation order)
+const ModelLaunchers *interceptor_launchers_fast(); // kernels_interceptor_fast.hip (restructured, contraction on)
 
 }  // namespace socp

@@ -19,7 +19,58 @@
 
 namespace socp {
 
-struct InterceptorModel {
+// ---- helpers of the throughput flavour (FAST = true; compiled with FMA contraction) -----------------------
+namespace ifast {
+// 1/x and 1/sqrt(x) in one cubic step from the hardware estimate (error e^3 ~ 1e-22; arguments are O(1..1e7)
+// physical quantities, never subnormal)
+__device__ __forceinline__ double rcp(double x)
+{
+    const double r = __builtin_amdgcn_rcp(x);
+    const double e = __builtin_fma(-x, r, 1.0);
+    return __builtin_fma(r, __builtin_fma(e, e, e), r);
+}
+__device__ __forceinline__ double rsqrt(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    const double d = __builtin_fma(-(x * y), y, 1.0);
+    return __builtin_fma(y * d, __builtin_fma(0.375, d, 0.5), y);
+}
+// sin and cos together: k = round(2x/pi), r = x - k pi/2 with a two-part pi/2 (Cody-Waite; exact enough for
+// |x| up to ~1e4, the flight-path / heading / latitude angles are O(1)), degree-15 / degree-16 Taylor
+// polynomials on |r| <= pi/4 (remainders 5e-17, 2e-18), quadrant by select.  ~1 ulp; 33 instructions instead
+// of the library's ~120 with its large-argument path.
+__device__ __forceinline__ void sincos(double x, double &s, double &c)
+{
+    const double k = __builtin_rint(x * 0.6366197723675814);
+    double r = __builtin_fma(-k, 0x1.921fb54442d18p+0, x);
+    r = __builtin_fma(-k, 0x1.1a62633145c07p-54, r);
+    const double r2 = r * r;
+    double p = -1.0 / 1307674368000.0;
+    p = __builtin_fma(p, r2, 1.0 / 6227020800.0);
+    p = __builtin_fma(p, r2, -1.0 / 39916800.0);
+    p = __builtin_fma(p, r2, 1.0 / 362880.0);
+    p = __builtin_fma(p, r2, -1.0 / 5040.0);
+    p = __builtin_fma(p, r2, 1.0 / 120.0);
+    p = __builtin_fma(p, r2, -1.0 / 6.0);
+    const double sr = __builtin_fma(r * r2, p, r);
+    double q = 1.0 / 20922789888000.0;
+    q = __builtin_fma(q, r2, -1.0 / 87178291200.0);
+    q = __builtin_fma(q, r2, 1.0 / 479001600.0);
+    q = __builtin_fma(q, r2, -1.0 / 3628800.0);
+    q = __builtin_fma(q, r2, 1.0 / 40320.0);
+    q = __builtin_fma(q, r2, -1.0 / 720.0);
+    q = __builtin_fma(q, r2, 1.0 / 24.0);
+    const double cr = __builtin_fma(r2 * r2, q, __builtin_fma(-0.5, r2, 1.0));
+    const int n = (int)k;
+    const bool swap = n & 1;
+    const double s0 = swap ? cr : sr, c0 = swap ? sr : cr;
+    s = (n & 2) ? -s0 : s0;
+    c = ((n + 1) & 2) ? -c0 : c0;
+}
+}  // namespace ifast
+
+template <bool FAST>
+struct InterceptorT {
     static constexpr int D = 6;
     static constexpr int S = 12;
     static constexpr int NU = 2;
@@ -27,6 +78,9 @@ struct InterceptorModel {
     static constexpr bool kCustomTraj = true;
     static constexpr bool kCustomFinal = true;
     static constexpr bool kOneWavePerSimd = true;      // launch-table hint: instantiate the WPE = 1 kernels only
+    // FAST: the right-hand side is restructured (reciprocals instead of the ~25 divisions, cos/sin(beta) from the
+    // atan2 arguments instead of atan2 + sincos, tan = sin/cos, short sincos, contraction); same mathematics,
+    // rounding-level differences.  Control(), Hamiltonian(), the chart change and the drivers are shared.
 
     // parameter slots = include/socp_hip.h SOCP_INTERCEPTOR_* (interceptor.hpp:28-46 order, then R_Earth, mu0, chartLimit)
     enum { C0 = 0, HR, D0, ETA, PROP, EMPTY, Q, VE, ALPHA_MAX, UMAX, AMAX, MU_GFT, MUT, MUV, MUC, REARTH, MU0, CHART_LIMIT };
@@ -76,7 +130,7 @@ struct InterceptorModel {
     }
 
     // Model_1 (:275-335) / Model_2 (:440-503)
-    __device__ static __forceinline__ void rhs(const ModelParams &P, double stage, double chart, double t,
+    __device__ static __forceinline__ void rhs_ref(const ModelParams &P, double stage, double chart, double t,
                                               const double (&X)[S], double (&Xdot)[S])
     {
         const Com c = common(P, stage, t, X[0]);
@@ -144,6 +198,113 @@ struct InterceptorModel {
                       - p_theta * (v * st * (-sp + cp * tL) / r)
                       - p_phi * v * ct * (cp + tt * tt * (cp + tL * sp)) / r;
             Xdot[10] = -p_l * v * st * tL / cL / r - v * (1 + tL * tL) * (p_theta * st * sp - p_phi * ct * cp * tt * tt) / r;
+            Xdot[11] = 0.0;
+        }
+    }
+
+    __device__ static __forceinline__ void rhs(const ModelParams &P, double stage, double chart, double t,
+                                              const double (&X)[S], double (&Xdot)[S])
+    {
+        if constexpr (FAST) rhs_fast(P, stage, chart, t, X, Xdot);
+        else rhs_ref(P, stage, chart, t, X, Xdot);
+    }
+
+    // The same right-hand side, restructured for throughput.  Notation: i* = reciprocal of *, vr = v/r,
+    // K = d + eta c_max u^2 (drag + induced drag), An = ft sin(alpha)/(m v) (thrust-normal turn rate),
+    // Q = v c_max u + An (total turn rate magnitude).
+    __device__ static __forceinline__ void rhs_fast(const ModelParams &P, double stage, double chart, double t,
+                                                   const double (&X)[S], double (&Xdot)[S])
+    {
+        const bool chart1 = chart == 1.0;
+        const double h = X[0], v = X[1], L = X[4];
+        const double p_h = X[6], p_v = X[7], p_a1 = X[8], p_a2 = X[9], p_L = X[10], p_l = X[11];
+        const double eta = P.p[ETA], alpha_max = P.p[ALPHA_MAX];
+        // ComputeMass + the common temporaries (:292-308, :981-997)
+        const double qm1 = P.p[Q] * P.p[MU_GFT];
+        const double mass = P.p[EMPTY] + P.p[PROP] - qm1 * (stage == 1.0 ? t : P.p[PROP] * ifast::rcp(P.p[Q]));
+        const double im = ifast::rcp(mass), ihr = ifast::rcp(P.p[HR]);
+        const double dens = exp(-h * ihr) * (P.p[PROP] + P.p[EMPTY]) * im;
+        const double c_max = P.p[C0] * dens, d = P.p[D0] * dens;
+        const double r = h + P.p[REARTH];
+        const double ir = ifast::rcp(r), iv = ifast::rcp(v);
+        const double g = P.p[MU0] * ir * ir * P.p[MU_GFT];
+        const double ft = P.p[VE] * (stage * qm1);
+        double s1, c1, s2, c2, sL, cL;
+        ifast::sincos(X[2], s1, c1);
+        ifast::sincos(X[3], s2, c2);
+        ifast::sincos(L, sL, cL);
+        const double ic1 = ifast::rcp(c1), icL = ifast::rcp(cL);
+        const double tL = sL * icL;
+        // control (:338-385 / :506-552): cos/sin(beta) straight from the atan2 arguments
+        const double by = chart1 ? p_a2 : -p_a2, bx = p_a1 * c1;
+        const double b2 = bx * bx + by * by;
+        double cb = 1.0, sb = 0.0;                          // atan2(0, 0) = 0
+        if (b2 > 0) { const double ib = ifast::rsqrt(b2); cb = bx * ib; sb = by * ib; }
+        const double W = v * c_max + ft * alpha_max * im * iv;
+        const double num = p_a1 * cb * W + by * sb * ic1 * W;      // chart 2: - p_phi (...) = by (...)
+        const double den = p_v * (2 * eta * c_max * v * v + ft * alpha_max * alpha_max * im) - P.p[MUC];
+        double u = num / den;
+        if (fabs(u) > P.p[UMAX]) u = copysign(P.p[UMAX], u);
+        double sa, ca;
+        ifast::sincos(alpha_max * u, sa, ca);
+
+        const double K = d + eta * c_max * u * u;
+        const double vr = v * ir;
+        const double An = ft * sa * im * iv;
+        const double Q = v * c_max * u + An;
+        const double Kv2 = K * v * v;
+        if (chart1) {
+            const double sg = s1, cg = c1, sc = s2, cc = c2, p_gamma = p_a1, p_chi = p_a2, icg = ic1;
+            const double vrcg = vr * cg;
+            const double lat = p_L * cc + p_l * sc * icL;             // (p_L cos chi + p_l sin chi / cos L)
+            Xdot[0] = v * sg;
+            Xdot[1] = -Kv2 - g * sg + ft * ca * im;
+            Xdot[2] = Q * cb - g * iv * cg + vrcg;
+            Xdot[3] = Q * sb * icg + vrcg * tL * sc;
+            Xdot[4] = vrcg * cc;
+            Xdot[5] = vrcg * sc * icL;
+            Xdot[6] = -p_v * ihr * Kv2 - 2 * g * ir * (p_gamma * iv * cg + p_v * sg)
+                      + ir * (vrcg * (lat + p_gamma + p_chi * tL * sc))
+                      + ihr * v * c_max * u * (p_gamma * cb + p_chi * sb * icg);
+            Xdot[7] = -(ir * cg * lat + p_h * sg
+                        + p_gamma * (c_max * u * cb + g * iv * iv * cg - An * iv * cb + cg * ir)
+                        + p_chi * ((c_max * u - An * iv) * sb * icg + cg * tL * sc * ir)
+                        - 2 * p_v * K * v);
+            Xdot[8] = vr * sg * (lat + p_gamma + p_chi * tL * sc) - v * p_h * cg
+                      - g * (p_gamma * iv * sg - p_v * cg)
+                      - p_chi * Q * sb * sg * icg * icg;
+            Xdot[9] = vrcg * (p_L * sc - p_l * cc * icL - p_chi * tL * cc);
+            Xdot[10] = -vrcg * sc * (p_l * sL * icL * icL + p_chi * (1 + tL * tL));
+            Xdot[11] = 0.0;
+        } else {
+            const double st = s1, ct = c1, sp = s2, cp = c2, p_theta = p_a1, p_phi = p_a2, ict = ic1;
+            const double tt = st * ict, tt2 = tt * tt;
+            const double A = cp + sp * tL;                            // cos phi + sin phi tan L
+            const double B = sp + tt2 * (sp - tL * cp);               // sin phi + tan^2 theta (sin phi - tan L cos phi)
+            const double givt = g * iv;
+            Xdot[0] = -v * ct * cp;
+            Xdot[1] = -Kv2 + g * ct * cp + ft * ca * im;
+            Xdot[2] = Q * cb + vr * st * A - givt * st * cp;
+            Xdot[3] = -Q * sb * ict + vr * ct * B - givt * sp * ict;
+            Xdot[4] = vr * ct * sp;
+            Xdot[5] = vr * st * icL;
+            Xdot[6] = -p_v * ihr * Kv2 - 2 * g * ir * (iv * (p_theta * st * cp + p_phi * sp * ict) - p_v * ct * cp)
+                      + ir * vr * (p_L * ct * sp + p_theta * st * A + p_l * st * icL + p_phi * ct * B)
+                      + ihr * v * c_max * u * (p_theta * cb - p_phi * sb * ict);
+            Xdot[7] = -(ir * (p_L * ct * sp + p_l * st * icL) - p_h * ct * cp
+                        + p_theta * (c_max * u * cb + givt * iv * st * cp - An * iv * cb + st * A * ir)
+                        + p_phi * ((-c_max * u + An * iv) * sb * ict + givt * iv * sp * ict + ct * B * ir)
+                        - 2 * p_v * K * v);
+            Xdot[8] = -v * (-p_L * st * sp * ir + p_l * ct * ir * icL + p_h * st * cp)
+                      + givt * (p_theta * ct * cp + p_phi * sp * tt * ict) + g * p_v * st * cp
+                      - p_theta * vr * ct * A + p_phi * vr * st * B
+                      - p_phi * vr * ct * (2 * tt * (1 + tt2) * (sp - tL * cp))
+                      + p_phi * Q * sb * tt * ict;
+            Xdot[9] = -v * (p_h * ct * sp + p_L * ct * cp * ir)
+                      - givt * (p_theta * st * sp - p_phi * cp * ict) + g * p_v * ct * sp
+                      - p_theta * vr * st * (-sp + cp * tL)
+                      - p_phi * vr * ct * (cp + tt2 * (cp + tL * sp));
+            Xdot[10] = -p_l * vr * st * tL * icL - vr * (1 + tL * tL) * (p_theta * st * sp - p_phi * ct * cp * tt2);
             Xdot[11] = 0.0;
         }
     }
@@ -409,7 +570,7 @@ struct InterceptorModel {
             if (ph == 1) stage = 0.0;
             obs(ta, X, stage, chart);
             if constexpr (INTEG == 1) {
-                Lane<InterceptorModel>::integrate_dopri5(P, stage, chart, ta, tb, X,
+                Lane<InterceptorT>::integrate_dopri5(P, stage, chart, ta, tb, X,
                                                          [&](double, double (&Xc)[S]) { return set_chart(P, chart, Xc); });
                 obs(tb, X, stage, chart);
             } else {
@@ -440,5 +601,8 @@ struct InterceptorModel {
     // the free-final-time row is H + muT (:270)
     __device__ static __forceinline__ double final_h_offset(const ModelParams &P) { return P.p[MUT]; }
 };
+
+using InterceptorModel = InterceptorT<false>;      // reference operation order (kernels_interceptor.hip)
+using InterceptorFast = InterceptorT<true>;        // throughput flavour (kernels_interceptor_fast.hip)
 
 }  // namespace socp

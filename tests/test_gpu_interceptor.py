@@ -253,3 +253,48 @@ def test_adaptive_budget_bounds_a_singular_trajectory(ictx, built):
     early = slice(12, 12 * 6)                              # continuity rows of the first segments: well-behaved
     assert np.all(np.isfinite(F[early]))
     assert np.max(np.abs(F[early] - F_rk4[early]) / np.maximum(1.0, np.abs(F_rk4[early]))) < 1e-4
+
+
+# ---- throughput flavour (InterceptorT<true>: reciprocals, short sincos, no atan2; contraction on) --------------
+def test_fast_flavour_matches_cpu_path(built):
+    from socp_amd import capi
+    o = Oracle(MODEL_INTERCEPTOR)
+    c = capi.Context(capi.MODEL_INTERCEPTOR)
+    c.set_variant(capi.VARIANT_LANE_FAST)
+    X1, X2 = states_both_charts(o, 16)
+    for chart, X in ((1, X1), (2, X2)):
+        for stage, t in ((1, 3.0), (0, 27.0)):
+            o.set_flags(chart, stage)
+            sw = np.tile([float(stage), float(chart)], (len(X), 1))
+            f = c.eval_batch(capi.EVAL_RHS, t, X, sw=sw)
+            for b in range(len(X)):
+                fo = o.rhs(t, X[b])
+                assert np.max(np.abs(f[b] - fo) / np.maximum(1e-6 * np.abs(fo).max(), np.abs(fo))) < 1e-9, (chart, stage, b)
+    X0, _ = scenario_state()
+    Xs, _ = scenario_state(gamma=1.49)
+    cases = [(0.0, 10.0, X0), (0.0, 30.0, X0), (22.0, 31.0, X0), (0.0, 6.0, Xs), (0.0, 25.0, Xs)]
+    Xf = c.integrate_batch(np.array([k[0] for k in cases]), np.array([k[1] for k in cases]), np.array([k[2] for k in cases]))
+    for b, (a, e, x) in enumerate(cases):
+        assert rel(Xf[b], o.traj(a, x, e)) < 1e-9, b
+    o.set_param("mu_gft", 0.6)
+    c.set_param("mu_gft", 0.6)
+    prob, z = multi_shooting_problem(o, 21)
+    c.problem_set(prob.mode_t, prob.mode_x, prob.time, prob.xnode)
+    Fo = o.residual(prob, z)
+    assert np.max(np.abs(c.residual(z) - Fo) / np.maximum(1.0, np.abs(Fo))) < 1e-9
+    F = c.residual(z)
+    assert np.array_equal(c.fd_jacobian(z, F, dedup=True), c.fd_jacobian(z, F, dedup=False))
+    c.close()
+
+
+@pytest.mark.parametrize("scenario", [1, 3])
+def test_fast_flavour_converged_solution(scenario):
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "interceptor_flow.json")))
+    out = subprocess.run([EXE, "1e-12", str(scenario)], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, SOCP_VARIANT="fast"))
+    stages = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    want = gold["scenario%d_xtol1e-12" % scenario]
+    assert out.returncode == 0 and len(stages) == len(want), out.stderr
+    for s, g in zip(stages, want):
+        z, zg = np.array(s["z"]), np.array(g["z"])
+        assert s["info"] == 1 and np.max(np.abs(z - zg)) <= 1e-8 * np.max(np.abs(zg)), s["stage"]
