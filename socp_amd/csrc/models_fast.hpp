@@ -169,6 +169,35 @@ using GoddardFastSmooth = GoddardFastT<true>;
 // The double integrator has one division per control component and one rare square root: nothing
 // to restructure beyond what contraction gives.
 using DIntFast = DIntExact;
-using CovidFast = CovidExact;     // IEEE +,-,*,/ only: nothing to restructure
+// SEIR model, throughput flavour: the reference's ten divisions per right-hand side are all by the model constants
+// Tinf, Tinc, N -- here three reciprocals that do not depend on the state (the compiler hoists them out of the
+// time loop) and one shared infection flux Rt S I / (Tinf N); contraction on.  Rounding-level differences only.
+struct CovidFast : CovidExact {
+    static constexpr bool kRefOrder = false;
+
+    __device__ static __forceinline__ void rhs(const ModelParams &P, double, double, double,
+                                              const double (&X)[S], double (&dX)[S])
+    {
+        const double Sx = X[0], E = X[1], I = X[2], R = X[3], pS = X[4], pE = X[5], pI = X[6], pR = X[7];
+        const double iTinf = fast_rcp(P.p[CP_TINF]), iTinc = fast_rcp(P.p[CP_TINC]), iN = fast_rcp(P.p[CP_N]);
+        const double k = iTinf * iN;
+        double u = (pE - pS) * Sx * I * k * P.p[CP_R0];
+        u = __builtin_fmin(__builtin_fmax(u, P.p[CP_UMIN]), P.p[CP_UMAX]);
+        const double Rt = P.p[CP_R0] * (1 - u);
+        const double dI = I - P.p[CP_IMAX];
+        const double Ipen = dI >= 0 ? -P.p[CP_MUI] * dI : 0.0;
+        const double flux = Rt * k * Sx * I;
+        const double EoT = E * iTinc, IoT = I * iTinf;
+        const double dp = (pS - pE) * R * k;
+        dX[0] = -flux;
+        dX[1] = flux - EoT;
+        dX[2] = EoT - IoT;
+        dX[3] = IoT;
+        dX[4] = dp * I;
+        dX[5] = (pE - pI) * iTinc;
+        dX[6] = dp * Sx + (pI - pR) * iTinf + Ipen;
+        dX[7] = 0;
+    }
+};
 
 }  // namespace socp

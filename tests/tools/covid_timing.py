@@ -49,6 +49,15 @@ for dd in (False, True):
     out["gpu_fd_jacobian_%s" % ("dedup" if dd else "full")] = {"ms": 1e3 * (time.perf_counter() - t) / 5,
                                                                "trajectories": int((ctx.counters()[0] - c0) // 5)}
 out["bit_identical_to_cpu"] = bool(np.array_equal(J, Jo))
+ctx.set_variant(capi.VARIANT_LANE_FAST)
+Ff = ctx.residual(z)
+ctx.fd_jacobian(z, Ff, dedup=True)
+t = time.perf_counter()
+for _ in range(5):
+    ctx.fd_jacobian(z, Ff, dedup=True)
+out["gpu_fd_jacobian_dedup_fast_flavour_ms"] = 1e3 * (time.perf_counter() - t) / 5
+out["fast_flavour_residual_max_abs_diff"] = float(np.max(np.abs(Ff - F)))
+ctx.set_variant(capi.VARIANT_AUTO)
 exe = os.path.join(ROOT, "socp_amd", "_build", "bin", "covid_flow")
 t = time.perf_counter()
 r = subprocess.run([exe, "1e-8", "3"], capture_output=True, text=True)
