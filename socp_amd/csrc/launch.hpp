@@ -1,8 +1,40 @@
 // launch.hpp -- host-callable launchers, one set per arithmetic flavour (translation unit).
 #pragma once
+#include <cstdlib>
+
 #include "dev_common.hpp"
 
 namespace socp {
+
+// ---- launch geometry shared by the in-tree flavours (launch_impl.hpp) and table-driven models (plugin_impl.hpp) ----
+constexpr int kNumSIMD = 1024;                       // MI355X: 256 CUs x 4 SIMDs
+
+inline unsigned blocks_for(long n) { return (unsigned)((n + 63) / 64); }
+
+// Fill-the-chip placement.  Workgroups here are single waves that keep their trajectory in registers for
+// milliseconds.  The dispatcher packs them as deep as registers allow (3 per SIMD at <= 168 VGPRs) and a CU
+// does not balance single-wave workgroups over its 4 SIMDs, so a grid of W < 3072 waves would time-slice
+// three waves on some SIMDs while others idle (measured: 960 waves took 2x, 1920 waves 3x the single-wave
+// time).  Every hot kernel is therefore instantiated with an occupancy cap WPE in {1,2,3}
+// (amdgpu_waves_per_eu) and the launcher picks WPE = ceil(W / 1024 SIMDs): up to 1024 waves run one per
+// SIMD, up to 2048 two per SIMD, beyond that three.
+inline int wpe_for(long waves)
+{
+    const long k = (waves + kNumSIMD - 1) / kNumSIMD;
+    return k < 1 ? 1 : (k > 3 ? 3 : (int)k);
+}
+
+// rows per workgroup of the row-owned-tile kernels (integrator.hpp): whole rows, M lanes each, tile <= 32 KiB;
+// 0 = direct stores
+inline int rows_per_block(int M, int n)
+{
+    static const bool off = [] { const char *e = std::getenv("SOCP_ROW_TILES"); return e && e[0] == '0'; }();
+    if (off || M > 64) return 0;                      // SOCP_ROW_TILES=0: direct stores (A/B measurements)
+    int R = 64 / M;
+    const long bytes = (long)R * n * 8;
+    if (bytes > 32 * 1024) R = (int)(32 * 1024 / ((long)n * 8));
+    return R < 1 ? 0 : R;
+}
 
 #define SOCP_DECLARE_LAUNCHERS(FLAVOUR)                                                              \
     hipError_t traj_##FLAVOUR(int model_id, hipStream_t st, const ModelParams &P, int B,             \

@@ -9,35 +9,6 @@ namespace socp {
 #define SOCP_CAT_(a, b) a##b
 #define SOCP_CAT(a, b) SOCP_CAT_(a, b)
 
-static inline unsigned blocks_for(long n) { return (unsigned)((n + 63) / 64); }
-
-// Fill-the-chip placement.  Workgroups here are single waves that keep their trajectory in registers for
-// milliseconds.  The dispatcher packs them as deep as registers allow (3 per SIMD at <= 168 VGPRs) and a CU
-// does not balance single-wave workgroups over its 4 SIMDs, so a grid of W < 3072 waves would time-slice
-// three waves on some SIMDs while others idle (measured: 960 waves took 2x, 1920 waves 3x the single-wave
-// time).  Every hot kernel is therefore instantiated with an occupancy cap WPE in {1,2,3}
-// (amdgpu_waves_per_eu) and the launcher picks WPE = ceil(W / 1024 SIMDs): up to 1024 waves run one per
-// SIMD, up to 2048 two per SIMD, beyond that three.
-constexpr int kNumSIMD = 1024;
-
-// rows per workgroup of the row-owned-tile kernels (integrator.hpp): whole rows, M lanes each, tile <= 32 KiB;
-// 0 = direct stores
-static inline int rows_per_block(int M, int n)
-{
-    static const bool off = [] { const char *e = getenv("SOCP_ROW_TILES"); return e && e[0] == '0'; }();
-    if (off || M > 64) return 0;                      // SOCP_ROW_TILES=0: direct stores (A/B measurements)
-    int R = 64 / M;
-    const long bytes = (long)R * n * 8;
-    if (bytes > 32 * 1024) R = (int)(32 * 1024 / ((long)n * 8));
-    return R < 1 ? 0 : R;
-}
-
-static inline int wpe_for(long waves)
-{
-    const long k = (waves + kNumSIMD - 1) / kNumSIMD;
-    return k < 1 ? 1 : (k > 3 ? 3 : (int)k);
-}
-
 // SOCP_HAVE_DOPRI5: this translation unit also carries the adaptive-integrator instantiations (one wave per
 // SIMD: seven stage vectors live in registers)
 #ifdef SOCP_HAVE_DOPRI5

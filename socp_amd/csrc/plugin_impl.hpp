@@ -31,12 +31,10 @@
 namespace socp {
 namespace plugin {
 
-inline unsigned blocks_for(long n) { return (unsigned)((n + 63) / 64); }
 // optional model hint kOneWavePerSimd: build and launch only the one-wave-per-SIMD instantiations (heavy
 // right-hand sides whose batches never fill the chip three deep)
 template <class M, class = void> struct one_wave_per_simd : std::false_type {};
 template <class M> struct one_wave_per_simd<M, std::void_t<decltype(M::kOneWavePerSimd)>> : std::bool_constant<M::kOneWavePerSimd> {};
-inline int wpe_for(long waves) { const long k = (waves + 1023) / 1024; return k < 1 ? 1 : (k > 3 ? 3 : (int)k); }
 
 // one launch of a hot kernel: adaptive integrator -> one wave per SIMD; otherwise occupancy cap from the grid
 #define SOCP_PLUGIN_LAUNCH_LDS(KERNEL, GRID, LDS, ST, ...)                                                       \
@@ -51,14 +49,6 @@ inline int wpe_for(long waves) { const long k = (waves + 1023) / 1024; return k 
         }                                                                                                        \
     } while (0)
 #define SOCP_PLUGIN_LAUNCH(KERNEL, GRID, ST, ...) SOCP_PLUGIN_LAUNCH_LDS(KERNEL, GRID, 0, ST, __VA_ARGS__)
-
-inline int rows_per_block(int M, int n)
-{
-    if (M > 64) return 0;
-    int R = 64 / M;
-    if ((long)R * n * 8 > 32 * 1024) R = (int)(32 * 1024 / ((long)n * 8));
-    return R < 1 ? 0 : R;
-}
 
 template <class Mdl>
 hipError_t traj(hipStream_t st, const ModelParams &P, int B, const double *t0, const double *tf, const double *sw,
