@@ -219,3 +219,23 @@ def test_dopri5_restatement_converges_like_a_54_pair(built):
             assert err < prev / 20          # two decades of tolerance buy > 1.3 decades of accuracy
         prev = err
     assert np.array_equal(o.traj_dopri5(0.1, X0, 0.1, 1e-8)[0], X0)      # zero-length segment: untouched
+
+
+def test_dopri5_single_step_equals_scipy_tableau_step(built):
+    """The Dormand-Prince tableau of the restatement, pinned against an independent implementation: with a
+    tolerance nobody can miss, the first trial step of size dt is accepted as is, so a segment of exactly one
+    initial step is ONE application of the tableau -- which must equal SciPy's rk_step with its RK45 A/B/C
+    (only the order of the stage sums differs: agreement to rounding)."""
+    from scipy.integrate._ivp.rk import RK45, rk_step
+    from oracle.oracle import Oracle, MODEL_GODDARD
+    o = Oracle(MODEL_GODDARD, step_nbr=1)                  # initial step = whole segment
+    o.set_param("mu2", 1.0)
+    X0 = np.concatenate([[0.999949994, 1e-4, 0.01, 1e-10, 1e-10, 1e-10, 1.0],
+                         [-8.121947733, 7.775439382e-3, 0.7775438809, -0.4779369965, 5.715013318e-4, 5.715009222e-2, 9.958404873e-2]])
+    h = 0.01
+    X, steps, rej = o.traj_dopri5(0.0, X0, h, 1e30)
+    assert (steps, rej) == (1, 0)
+    fun = lambda t, y: o.rhs(t, y)
+    K = np.empty((RK45.n_stages + 1, 14))
+    y_new, _ = rk_step(fun, 0.0, X0, fun(0.0, X0), h, RK45.A, RK45.B, RK45.C, K)
+    assert np.max(np.abs(X - y_new) / np.maximum(1e-3, np.abs(y_new))) < 5e-15
