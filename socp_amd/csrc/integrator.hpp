@@ -342,8 +342,12 @@ __device__ __forceinline__ void segment_residual(const ModelParams &P, const Pro
     };
     const double t1 = nt(i), t2 = nt(i + 1);
     // model switching times = FREE node times with index < M, in node order (:1604,1615)
-    double sw0 = pb.sw_node0 >= 0 ? nt(pb.sw_node0) : P.sw0;
-    double sw1 = pb.sw_node1 >= 0 ? nt(pb.sw_node1) : P.sw1;
+    // (a model with its own ComputeTraj keeps its two auxiliary scalars for itself: they are not switching times)
+    double sw0 = P.sw0, sw1 = P.sw1;
+    if constexpr (!has_custom_traj<Mdl>::value) {
+        if (pb.sw_node0 >= 0) sw0 = nt(pb.sw_node0);
+        if (pb.sw_node1 >= 0) sw1 = nt(pb.sw_node1);
+    }
 
     double X[S];
     if (i == 0) {
