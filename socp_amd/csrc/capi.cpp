@@ -106,7 +106,11 @@ bool use_fast(const socp_ctx *c)
 }
 
 // launch table of a table-driven model for the current variant / integrator
-const ModelLaunchers *table_of(const socp_ctx *c) { return (use_fast(c) && c->vt_fast) ? c->vt_fast : c->vt; }
+// (a table carries its own adaptive-integrator instantiations, so the throughput table serves both integrators)
+const ModelLaunchers *table_of(const socp_ctx *c)
+{
+    return (c->variant == SOCP_VARIANT_LANE_FAST && c->vt_fast) ? c->vt_fast : c->vt;
+}
 
 int check_variant(socp_ctx *c)
 {

@@ -1,7 +1,7 @@
 // kernels_interceptor_fast.hip -- throughput flavour of the interceptor model (InterceptorT<true>,
 // models_interceptor.hpp): compiled WITH FMA contraction.  Same launch-table mechanism as
-// kernels_interceptor.hip; capi.cpp uses this table when the context's variant is SOCP_VARIANT_LANE_FAST and the
-// integrator is fixed-step RK4 (the adaptive integrator lives in the reference-order translation unit only).
+// kernels_interceptor.hip; capi.cpp uses this table when the context's variant is SOCP_VARIANT_LANE_FAST, for
+// both integrators (the table carries its own adaptive instantiations).
 #include "models_interceptor.hpp"
 #include "plugin_impl.hpp"
 

@@ -284,6 +284,12 @@ def test_fast_flavour_matches_cpu_path(built):
     assert np.max(np.abs(c.residual(z) - Fo) / np.maximum(1.0, np.abs(Fo))) < 1e-9
     F = c.residual(z)
     assert np.array_equal(c.fd_jacobian(z, F, dedup=True), c.fd_jacobian(z, F, dedup=False))
+    # adaptive integrator in the throughput flavour agrees with the adaptive integrator in reference order
+    c.set_integrator(capi.INT_DOPRI5, 1e-10)
+    Xa = c.integrate_batch(0.0, 30.0, X0[None, :])[0]
+    c.set_variant(capi.VARIANT_AUTO)
+    Xb = c.integrate_batch(0.0, 30.0, X0[None, :])[0]
+    assert rel(Xa, Xb) < 1e-8
     c.close()
 
 

@@ -43,8 +43,9 @@ out = {"n": n, "segments": 21}
 t = time.perf_counter()
 Jo = o.fdjac(prob, z, o.residual(prob, z))
 out["cpu_restatement_1core"] = {"fd_jacobian_ms": 1e3 * (time.perf_counter() - t), "trajectories": (n + 1) * 21}
-for name, kind, tol in (("rk4", capi.INT_RK4, 0.0), ("rk4_fast_flavour", capi.INT_RK4, 0.0), ("dopri5_tol1e-8", capi.INT_DOPRI5, 1e-8)):
-    ctx.set_variant(capi.VARIANT_LANE_FAST if name == "rk4_fast_flavour" else capi.VARIANT_AUTO)
+for name, kind, tol in (("rk4", capi.INT_RK4, 0.0), ("rk4_fast_flavour", capi.INT_RK4, 0.0), ("dopri5_tol1e-8", capi.INT_DOPRI5, 1e-8),
+                        ("dopri5_tol1e-8_fast_flavour", capi.INT_DOPRI5, 1e-8)):
+    ctx.set_variant(capi.VARIANT_LANE_FAST if name.endswith("fast_flavour") else capi.VARIANT_AUTO)
     if kind == capi.INT_DOPRI5:
         ctx.set_integrator(kind, tol)
     else:
