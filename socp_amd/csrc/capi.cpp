@@ -101,8 +101,7 @@ int hip_fail(socp_ctx *c, hipError_t e, const char *what)
 bool use_fast(const socp_ctx *c)
 {
     // AUTO keeps the reference operation order: it is the variant every parity claim is made on.
-    // The adaptive integrator exists in the reference-order translation unit only.
-    return c->variant == SOCP_VARIANT_LANE_FAST && c->P.integrator == SOCP_INT_RK4;
+    return c->variant == SOCP_VARIANT_LANE_FAST;
 }
 
 // launch table of a table-driven model for the current variant / integrator

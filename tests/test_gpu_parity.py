@@ -361,3 +361,17 @@ def test_dopri5_residual_and_newton(gctx, goracle):
     assert ref["info"] == 1
     assert np.max(np.abs(out["x"] - ref["x"])) <= 1e-5 * np.max(np.abs(ref["x"]))
     gctx.set_step_number(10)
+
+
+def test_dopri5_fast_flavour_agrees_with_reference_order(gctx, gfast):
+    """The adaptive integrator on the restructured right-hand side: same trajectories to the tolerance level."""
+    from socp_amd import capi
+    X0 = goddard_costate_batch(64, 1e-3)
+    out = []
+    for c in (gctx, gfast):
+        c.set_param("mu2", 1.0)
+        c.set_step_number(10)
+        c.set_integrator(capi.INT_DOPRI5, 1e-10)
+        out.append(c.integrate_batch(0.0, GODDARD_TF, X0))
+        c.set_integrator(capi.INT_RK4)
+    assert np.max(np.abs(out[0] - out[1]) / np.maximum(1.0, np.abs(out[0]))) < 1e-8
