@@ -12,6 +12,40 @@
 
 namespace socp {
 
+// ---- IEEE quotients that share a denominator ---------------------------------------------------------------
+// The compiler expands every double division n / d into the hardware's correctly rounded sequence
+//     d' = div_scale(d), n' = div_scale(n);  r0 = rcp(d');  r1 = r0 + r0 (1 - d' r0);  r2 = r1 + r1 (1 - d' r1);
+//     q0 = n' r2;  e = n' - d' q0;  q1 = q0 + e r2;  result = div_fixup(q1)
+// (11 instructions plus hazard nops).  The scaling and the fix-up only act when an operand is zero, infinite,
+// NaN, subnormal, or when the exponents are extreme; otherwise they pass the operands through and the first five
+// steps depend on d alone.  `Den` does those five steps once and `n / Den` the last three, with the SAME
+// instructions in the same order -- so for a denominator within 2^-400 .. 2^400 and numerators within
+// 2^-568 .. 2^368 every quotient has exactly the bits of the compiler's n / d.  The models below ask den_ok()
+// for each shared denominator and fall back to plain division (DenT = double) otherwise; the reference's
+// right-hand sides divide ~56 times by four distinct quantities (r, v, m, |p_v|).
+struct Den {
+    double d, r;
+    __device__ __forceinline__ explicit Den(double den) : d(den)
+    {
+        const double r0 = __builtin_amdgcn_rcp(den);
+        const double f0 = __builtin_fma(-den, r0, 1.0);
+        const double r1 = __builtin_fma(r0, f0, r0);
+        const double f1 = __builtin_fma(-den, r1, 1.0);
+        r = __builtin_fma(r1, f1, r1);
+    }
+};
+__device__ __forceinline__ double operator/(double n, const Den &D)
+{
+    const double q0 = n * D.r;
+    const double e = __builtin_fma(-D.d, q0, n);
+    return __builtin_fma(e, D.r, q0);
+}
+__device__ __forceinline__ bool den_ok(double d)
+{
+    const double a = fabs(d);
+    return a > 0x1p-400 && a < 0x1p400;              // false for NaN
+}
+
 enum { GP_C = 0, GP_B, GP_KD, GP_KR, GP_UMAX, GP_MU1, GP_MU2, GP_SING };
 enum { DP_UMAX = 0, DP_AMAX, DP_MUT };
 enum { CP_R0 = 0, CP_TINF, CP_TINC, CP_N, CP_IMAX, CP_MUI, CP_UMIN, CP_UMAX };
@@ -44,21 +78,26 @@ struct GoddardExactT {
     }
 
     // costate derivatives of position and velocity (goddard.cpp:91-96, reused at :214-219)
+    // DenT = double: plain IEEE division; DenT = Den: the same quotients from shared reciprocals (see Den)
+    template <class DenT = double>
     __device__ static __forceinline__ void costate_dots(const ModelParams &P, const Common &c,
                                                        const double (&X)[S], double (&pd)[6])
     {
-        const double x = X[0], y = X[1], z = X[2], vx = X[3], vy = X[4], vz = X[5], mass = X[6];
+        const double x = X[0], y = X[1], z = X[2], vx = X[3], vy = X[4], vz = X[5];
         const double p_x = X[7], p_y = X[8], p_z = X[9], p_vx = X[10], p_vy = X[11], p_vz = X[12];
         const double KD = P.p[GP_KD], kr = P.p[GP_KR];
-        const double r = c.r, v = c.v, g = c.g, pvdotv = c.pvdotv, E = c.E;
+        const double g = c.g, pvdotv = c.pvdotv, E = c.E;
+        const DenT r(c.r), mass(X[6]);
+        const double v = c.v;
         const double A = -kr*KD / mass*v*E;          // common left prefix of :91-93
         const double Q = KD / mass*E;                // common left prefix of :94-96
         pd[0] = A*x / r*pvdotv + g*(p_vx*(1 - 3 * x*x / r / r) / r - p_vy * 3 * x*y / r / r / r - p_vz * 3 * x*z / r / r / r);
         pd[1] = A*y / r*pvdotv + g*(-p_vx * 3 * y*x / r / r / r + p_vy*(1 - 3 * y*y / r / r) / r - p_vz * 3 * y*z / r / r / r);
         pd[2] = A*z / r*pvdotv + g*(-p_vx * 3 * z*x / r / r / r - p_vy * 3 * z*y / r / r / r + p_vz*(1 - 3 * z*z / r / r) / r);
-        pd[3] = -p_x + Q*(pvdotv*vx / v + p_vx*v);
-        pd[4] = -p_y + Q*(pvdotv*vy / v + p_vy*v);
-        pd[5] = -p_z + Q*(pvdotv*vz / v + p_vz*v);
+        const DenT dv(c.v);
+        pd[3] = -p_x + Q*(pvdotv*vx / dv + p_vx*v);
+        pd[4] = -p_y + Q*(pvdotv*vy / dv + p_vy*v);
+        pd[5] = -p_z + Q*(pvdotv*vz / dv + p_vz*v);
     }
 
     // goddard.cpp:188-253
@@ -94,10 +133,12 @@ struct GoddardExactT {
     }
 
     // goddard.cpp:104-185
+    template <class DenT = double>
     __device__ static __forceinline__ void control(const ModelParams &P, const Common &c, double sw0, double sw1,
                                                   double t, const double (&X)[S], double (&u)[3])
     {
-        const double mass = X[6], p_vx = X[10], p_vy = X[11], p_vz = X[12], p_mass = X[13];
+        const double p_vx = X[10], p_vy = X[11], p_vz = X[12], p_mass = X[13];
+        const DenT mass(X[6]), npv(c.norm_pv);
         const double Switch = P.p[GP_MU1] - P.p[GP_B]*p_mass - P.p[GP_C] / mass*c.norm_pv;
         double alpha_u = 0;
         if (SMOOTH || P.p[GP_MU2] > 0) {
@@ -109,9 +150,9 @@ struct GoddardExactT {
                 alpha_u = (P.p[GP_SING] < 0) ? singular_control(P, c, X) : P.p[GP_SING];
             }
         }
-        u[0] = -p_vx*alpha_u / c.norm_pv;
-        u[1] = -p_vy*alpha_u / c.norm_pv;
-        u[2] = -p_vz*alpha_u / c.norm_pv;
+        u[0] = -p_vx*alpha_u / npv;
+        u[1] = -p_vy*alpha_u / npv;
+        u[2] = -p_vz*alpha_u / npv;
         const double norm_u = fabs(alpha_u);
         const double u_max = P.p[GP_UMAX];
         if (norm_u > u_max) {
@@ -126,22 +167,31 @@ struct GoddardExactT {
                                               const double (&X)[S], double (&dX)[S])
     {
         const Common c = common(P, X);
+        if (den_ok(c.r) && den_ok(c.v) && den_ok(X[6]) && den_ok(c.norm_pv)) rhs_with<Den>(P, c, sw0, sw1, t, X, dX);
+        else rhs_with<double>(P, c, sw0, sw1, t, X, dX);
+    }
+
+    template <class DenT>
+    __device__ static __forceinline__ void rhs_with(const ModelParams &P, const Common &c, double sw0, double sw1, double t,
+                                                   const double (&X)[S], double (&dX)[S])
+    {
         double u[3];
-        control(P, c, sw0, sw1, t, X, u);
-        const double x = X[0], y = X[1], z = X[2], vx = X[3], vy = X[4], vz = X[5], mass = X[6];
+        control<DenT>(P, c, sw0, sw1, t, X, u);
+        const double x = X[0], y = X[1], z = X[2], vx = X[3], vy = X[4], vz = X[5];
+        const DenT mass(X[6]), cr(c.r);
         const double p_vx = X[10], p_vy = X[11], p_vz = X[12];
         const double b = P.p[GP_B], C = P.p[GP_C], KD = P.p[GP_KD];
         const double norm_u = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
         const double pvdotu = p_vx*u[0] + p_vy*u[1] + p_vz*u[2];
         const double W = -KD*c.v;                    // common left prefix of :84-86
         double pd[6];
-        costate_dots(P, c, X, pd);
+        costate_dots<DenT>(P, c, X, pd);
         dX[0] = vx;
         dX[1] = vy;
         dX[2] = vz;
-        dX[3] = W*vx*c.E / mass - c.g*x / c.r + C*u[0] / mass;
-        dX[4] = W*vy*c.E / mass - c.g*y / c.r + C*u[1] / mass;
-        dX[5] = W*vz*c.E / mass - c.g*z / c.r + C*u[2] / mass;
+        dX[3] = W*vx*c.E / mass - c.g*x / cr + C*u[0] / mass;
+        dX[4] = W*vy*c.E / mass - c.g*y / cr + C*u[1] / mass;
+        dX[5] = W*vz*c.E / mass - c.g*z / cr + C*u[2] / mass;
         dX[6] = -b*norm_u;
         dX[7] = pd[0];
         dX[8] = pd[1];
@@ -266,13 +316,23 @@ struct CovidExact {
         u[0] = control_scalar(P, X); u[1] = 0; u[2] = 0;
     }
 
-    // covid19.cpp:53-95
+    // covid19.cpp:53-95.  All ten divisions are by the model constants Tinf, Tinc, N: shared denominators (see Den).
     __device__ static __forceinline__ void rhs(const ModelParams &P, double, double, double,
                                               const double (&X)[S], double (&dX)[S])
     {
+        if (den_ok(P.p[CP_TINF]) && den_ok(P.p[CP_TINC]) && den_ok(P.p[CP_N])) rhs_with<Den>(P, X, dX);
+        else rhs_with<double>(P, X, dX);
+    }
+
+    template <class DenT>
+    __device__ static __forceinline__ void rhs_with(const ModelParams &P, const double (&X)[S], double (&dX)[S])
+    {
         const double Sx = X[0], E = X[1], I = X[2], R = X[3], pS = X[4], pE = X[5], pI = X[6], pR = X[7];
-        const double R0 = P.p[CP_R0], Tinf = P.p[CP_TINF], Tinc = P.p[CP_TINC], N = P.p[CP_N];
-        const double u = control_scalar(P, X);
+        const double R0 = P.p[CP_R0];
+        const DenT Tinf(P.p[CP_TINF]), Tinc(P.p[CP_TINC]), N(P.p[CP_N]);
+        double u = (X[5] - X[4])*X[0]*X[2] / Tinf / N * R0;             // control_scalar (:97-126) with the shared denominators
+        if (u <= P.p[CP_UMIN]) u = P.p[CP_UMIN];
+        if (u >= P.p[CP_UMAX]) u = P.p[CP_UMAX];
         const double Rt = R0 * (1 - u);
         double Ipen = 0;
         if (I >= P.p[CP_IMAX]) Ipen = -P.p[CP_MUI]*(I - P.p[CP_IMAX]);
