@@ -9,6 +9,7 @@
 // ocml's exp.  Citations: file:line into bherisse/socp.
 #pragma once
 #include "dev_common.hpp"
+#include "exp_glibc.hpp"
 
 namespace socp {
 
@@ -73,7 +74,7 @@ struct GoddardExactT {
         c.pvdotv = X[10]*X[3] + X[11]*X[4] + X[12]*X[5];
         c.g = 1 / c.r / c.r;
         c.norm_pv = sqrt(X[10]*X[10] + X[11]*X[11] + X[12]*X[12]);
-        c.E = exp(-P.p[GP_KR]*(c.r - 1));
+        c.E = exp_glibc(-P.p[GP_KR]*(c.r - 1));
         return c;
     }
 

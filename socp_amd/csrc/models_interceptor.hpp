@@ -15,6 +15,7 @@
 // (6x6 PartialPivLU solve and matrix-vector product) are a textbook partial-pivot LU and row sums here,
 // written with static indices only so the 6x6 stays in registers.
 #pragma once
+#include "exp_glibc.hpp"
 #include "integrator.hpp"
 
 namespace socp {
@@ -95,7 +96,7 @@ struct InterceptorT {
         const double t1 = P.p[PROP] / P.p[Q];
         const double qm = stage * P.p[Q] * P.p[MU_GFT];
         c.mass = P.p[EMPTY] + P.p[PROP] - qm_mass * (stage == 1.0 ? t : t1);
-        const double e = exp(-h / P.p[HR]);
+        const double e = exp_glibc(-h / P.p[HR]);
         c.c_max = P.p[C0] * e * (P.p[PROP] + P.p[EMPTY]) / c.mass;
         c.d = P.p[D0] * e * (P.p[PROP] + P.p[EMPTY]) / c.mass;
         c.r = h + P.p[REARTH];
