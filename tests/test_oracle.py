@@ -101,9 +101,10 @@ def test_residual_against_reference_probe(built):
     assert abs(float(np.dot(F, F)) - 8018306.4439022318) <= 1e-8
 
 
-@pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built (no /root/reference here)")
 def test_live_reference_agreement(built):
     """Random states, all control laws, against the reference objects themselves: bit equality."""
+    if not have_ref():          # decided at run time: a source-only checkout builds oracle/_ref during collection
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
     rng = np.random.default_rng(7)
     for mu2 in (1.0, 0.0):
         o, r = Oracle(MODEL_GODDARD), Ref(MODEL_GODDARD)
