@@ -72,7 +72,8 @@ struct GoddardExactT {
         c.r = sqrt(X[0]*X[0] + X[1]*X[1] + X[2]*X[2]);
         c.v = sqrt(X[3]*X[3] + X[4]*X[4] + X[5]*X[5]);
         c.pvdotv = X[10]*X[3] + X[11]*X[4] + X[12]*X[5];
-        c.g = 1 / c.r / c.r;
+        if (den_ok(c.r)) { const Den R(c.r); c.g = 1 / R / R; }      // same bits as 1 / r / r (see Den)
+        else c.g = 1 / c.r / c.r;
         c.norm_pv = sqrt(X[10]*X[10] + X[11]*X[11] + X[12]*X[12]);
         c.E = exp_glibc(-P.p[GP_KR]*(c.r - 1));
         return c;
