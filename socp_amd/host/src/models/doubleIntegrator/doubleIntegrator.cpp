@@ -10,7 +10,7 @@ struct doubleIntegrator::data_struct {
 };
 
 doubleIntegrator::doubleIntegrator(int modelOrder, std::string the_fileTrace)
-    : model(6, modelOrder, 30, the_fileTrace), my_odeStruct(nullptr), data(new data_struct)
+    : model(6, modelOrder, 30, the_fileTrace), data(new data_struct), my_odeStruct(nullptr)
 {
     data->parameters.u_max = 1;       // doubleIntegrator.cpp:30-32
     data->parameters.a_max = 1;

@@ -14,58 +14,50 @@
 
 class interceptor : public model
 {
+    struct data_struct;
+    data_struct *data;
+
+    // evaluated by the device twin in the chart / stage the object is currently in
+    mstate Model(real const &t, mstate const &X, int isJac) const override;
+    mcontrol Control(real const &t, mstate const &X) const override;
+    mstate Hamiltonian(real const &t, mstate const &X, int isJac) const override;
+    int GetMode(real const &t, mstate const &X) const override;
+    real ComputeMass(real const &t, mstate const &X) const;
+
 public:
-    // interceptor.hpp:28-46
+    // same members, order and types as interceptor.hpp:28-46 (assigned through GetParameterData())
     struct parameters_struct {
-        real c0;                 // max curvature at ground level (1/m)
-        real hr;                 // reference altitude (m)
-        real d0;                 // drag at ground level (1/m)
-        real eta;                // coefficient of efficiency
-        real propellant_mass;    // (kg)
-        real empty_mass;         // (kg)
-        real q;                  // mass flow rate (kg/s)
-        real ve;                 // gas speed (m/s)
-        real alpha_max;          // max angle of attack (rad)
-        real u_max;              // bound of the normalised control
-        real a_max;              // max acceleration (unused by the dynamics)
-        real r_2p;               // declared by the reference, never read
-        real t_2p;               // declared by the reference, never read
-        real mu_gft;             // 0..1 homotopy on gravity and thrust
-        real muT;                // weight of time in the cost
-        real muV;                // weight of final velocity in the cost
-        real muC;                // weight of the quadratic control cost
+        real c0, hr, d0;                      // max curvature and drag at ground level (1/m), reference altitude (m)
+        real eta;                             // coefficient of efficiency
+        real propellant_mass, empty_mass;     // (kg)
+        real q, ve;                           // mass flow rate (kg/s), gas speed (m/s)
+        real alpha_max, u_max;                // max angle of attack (rad), bound of the normalised control
+        real a_max;                           // max acceleration (not used by the dynamics)
+        real r_2p, t_2p;                      // declared by the reference, never read
+        real mu_gft;                          // 0..1 homotopy on gravity and thrust
+        real muT, muV, muC;                   // cost weights: time, final velocity, quadratic control
     };
 
     interceptor(std::string the_fileTrace = std::string(""));
-    virtual ~interceptor();
+    ~interceptor() override;
 
     parameters_struct &GetParameterData();
 
     // two stages (powered until propellant_mass/q, then coasting), chart re-chosen before every step, state
     // returned in chart 1 (interceptor.cpp:162-218)
-    virtual mstate ComputeTraj(real const &t0, mstate const &X0, real const &tf, int isTrace, int isJac);
+    mstate ComputeTraj(real const &t0, mstate const &X0, real const &tf, int isTrace, int isJac) override;
 
-    virtual void FinalFunction(real const &tf, mstate const &X_tf, mstate const &Xf, std::vector<int> const &mode_X, std::vector<real> &fvec, int isJac) const;
-    virtual void FinalHFunction(real const &tf, mstate const &X_tf, mstate const &Xf, std::vector<int> const &mode_X, std::vector<real> &fvec, int isJac) const;
+    void FinalFunction(real const &tf, mstate const &X_tf, mstate const &Xf, std::vector<int> const &mode_X, std::vector<real> &fvec, int isJac) const override;
+    void FinalHFunction(real const &tf, mstate const &X_tf, mstate const &Xf, std::vector<int> const &mode_X, std::vector<real> &fvec, int isJac) const override;
 
     // closed-form costate guess (IFAC WC 2017 paper cited by the reference); fills Xi[6..12)
     void InitAnalytical(real const &ti, mstate &Xi, real const &tf, mstate &Xf) const;
 
     // device hook
-    virtual int DeviceModelId() const;
-    virtual int DeviceParams(double *out, int cap) const;
-    virtual int DeviceStepNumber() const;
-    virtual std::vector<real> DeviceSwitchingTimes() const;     // (stageMode, currentChart): the device twin's two flags
-
-private:
-    struct data_struct;
-    data_struct *data;
-
-    virtual mstate Model(real const &t, mstate const &X, int isJac) const;
-    virtual mcontrol Control(real const &t, mstate const &X) const;
-    virtual mstate Hamiltonian(real const &t, mstate const &X, int isJac) const;
-    virtual int GetMode(real const &t, mstate const &X) const;
-    real ComputeMass(real const &t, mstate const &X) const;
+    int DeviceModelId() const override;
+    int DeviceParams(double *out, int cap) const override;
+    int DeviceStepNumber() const override;
+    std::vector<real> DeviceSwitchingTimes() const override;     // (stageMode, currentChart): the device twin's two flags
 };
 
 #endif
