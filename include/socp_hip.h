@@ -54,10 +54,13 @@ extern "C" {
 #define SOCP_CONTINUOUS 2
 
 /* kernel variants behind one call */
-#define SOCP_VARIANT_AUTO       0   /* chosen from batch size */
-#define SOCP_VARIANT_LANE_EXACT 1   /* one trajectory per lane, reference operation order, no FMA contraction */
-#define SOCP_VARIANT_LANE_FAST  2   /* one trajectory per lane, reciprocal/FMA-restructured arithmetic */
-#define SOCP_VARIANT_WAVE       3   /* one trajectory per wavefront, state staged in LDS (latency variant) */
+#define SOCP_VARIANT_AUTO       0   /* default: the reference-order kernels (= LANE_EXACT), the flavour every parity claim is
+                                       made on; the environment variable SOCP_VARIANT=fast|exact changes the default */
+#define SOCP_VARIANT_LANE_EXACT 1   /* one trajectory per lane, reference operation order, no FMA contraction: bit-identical
+                                       to the CPU path for goddard / doubleIntegrator / covid19 */
+#define SOCP_VARIANT_LANE_FAST  2   /* one trajectory per lane, reciprocal/FMA-restructured arithmetic (<= 1e-8 after 1e4 steps) */
+#define SOCP_VARIANT_WAVE       3   /* one trajectory per wavefront, state staged in LDS: exists for the variational
+                                       (is_jac = 1) integration only, which always runs that way; rejected elsewhere */
 
 /* what socp_eval_batch computes */
 #define SOCP_EVAL_RHS         0   /* odeTools.hpp:82  Model(t, X, isJac)      -> len(X) values  */
