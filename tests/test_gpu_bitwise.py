@@ -122,3 +122,25 @@ def test_unmodified_reference_program_reports_success(tmp_path):
     out = subprocess.run([exe], cwd=work, input="\n", capture_output=True, text=True, timeout=600)
     oks = [l.split("OK =")[1].strip() for l in out.stdout.splitlines() if "OK =" in l]
     assert oks == ["1", "1", "1", "1"], out.stdout
+
+
+def test_degenerate_states_take_the_plain_division_path_and_still_match(built):
+    """Shared-denominator division (models_exact.hpp: Den) is used only for denominators within 2^-400..2^400;
+    zero speed, zero p_v and states scaled by 10^+-150 go through plain IEEE division -- and must equal the CPU
+    path as well (NaN where the CPU has NaN)."""
+    from socp_amd import capi
+    params = [3.5, 7.0, 310.0, 500.0, 1.0, 1.0, 1.0, -1.0]
+    o = Oracle(MODEL_GODDARD, params=params)
+    c = capi.Context(capi.MODEL_GODDARD)
+    c.set_params(params)
+    X, t = random_states(400, seed=5)
+    X[:100, 3:6] = 0.0
+    X[100:200, 10:13] = 0.0
+    X[200:300] *= 1e150
+    X[300:400] *= 1e-150
+    f = c.eval_batch(capi.EVAL_RHS, t, X)
+    with np.errstate(all="ignore"):
+        ref = np.array([o.rhs(t[b], X[b]) for b in range(len(X))])
+    assert np.array_equal(f, ref, equal_nan=True)
+    assert np.isnan(ref).any() and np.isinf(ref).any() and np.isfinite(ref).any()   # the set really contains all kinds
+    c.close()
