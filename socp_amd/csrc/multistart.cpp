@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -49,16 +50,33 @@ extern "C" int socp_multistart_solve(socp_ctx *ctx, int P, const double *Z0, dou
     if (n <= 0) return SOCP_ERR_ARG;
     if (P == 0) return SOCP_OK;
 
+    const std::chrono::steady_clock::time_point t_begin = std::chrono::steady_clock::now();
+    // host threads for the per-start work (state-machine advances, workspace set-up, Jacobian scatter): all cores
+    // up to 16, one thread for small sweeps (thread start-up is ~50 us each)
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int nthreads = ((long)P * n * n < 200000) ? 1 : (int)std::max(1u, std::min(16u, hw ? hw : 1u));
+    auto parallel_for = [&](int count, auto &&body) {
+        if (nthreads <= 1) { for (int k = 0; k < count; k++) body(k); return; }
+        std::vector<std::thread> pool;
+        pool.reserve(nthreads);
+        for (int t = 0; t < nthreads; t++)
+            pool.emplace_back([&, t]() { for (int k = t; k < count; k += nthreads) body(k); });
+        for (std::thread &th : pool) th.join();
+    };
+
+    // one solver workspace per start (~n^2 doubles each: 400 MB of first-touch pages at P = 4096, n = 85)
     std::vector<socp_hybr *> solver(P, nullptr);
-    for (int p = 0; p < P; p++) {
+    parallel_for(P, [&](int p) {
         solver[p] = socp_hybr_create(n, xtol, maxfev, epsfcn, 1, factor, 0);
-        socp_hybr_start(solver[p], Z0 + (size_t)p * n, nullptr);
-    }
-    auto cleanup = [&]() { for (socp_hybr *s : solver) socp_hybr_destroy(s); };
+        if (solver[p]) socp_hybr_start(solver[p], Z0 + (size_t)p * n, nullptr);
+    });
+    auto cleanup = [&]() { parallel_for(P, [&](int p) { socp_hybr_destroy(solver[p]); solver[p] = nullptr; }); };
+    for (int p = 0; p < P; p++)
+        if (!solver[p]) { cleanup(); return SOCP_ERR_ARG; }
 
     const size_t rowB = sizeof(double) * n, jacB = rowB * n;
-    // Jacobian blocks are P*n*n doubles: stage them in chunks of at most ~256 MiB (pinned + device)
-    const int jchunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)P, ((size_t)256 << 20) / jacB));
+    // Jacobian blocks are P*n*n doubles: stage them in chunks of at most ~64 MiB (pinned + device)
+    const int jchunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)P, ((size_t)64 << 20) / jacB));
     PinnedBuf hX, hF, hJx, hJf, hJ;
     DevBuf dX, dF, dJx, dJf, dJ;
     if (!hX.reserve(rowB * P) || !hF.reserve(rowB * P) || !hJx.reserve(rowB * P) || !hJf.reserve(rowB * P) || !hJ.reserve(jacB * jchunk) ||
@@ -82,22 +100,16 @@ extern "C" int socp_multistart_solve(socp_ctx *ctx, int P, const double *Z0, dou
     std::vector<int> flag(P, 0), reqF, reqJ, req(P, SOCP_REQ_DONE);
     std::vector<const double *> xin(P, nullptr);
     std::vector<double *> xout(P, nullptr);
-    // host threads for step (1): all cores up to 16, one thread for small sweeps (thread start-up is ~50 us each)
-    const unsigned hw = std::thread::hardware_concurrency();
-    const int nthreads = ((long)P * n * n < 200000) ? 1 : (int)std::max(1u, std::min(16u, hw ? hw : 1u));
-    auto parallel_for = [&](int count, auto &&body) {
-        if (nthreads <= 1) { for (int k = 0; k < count; k++) body(k); return; }
-        std::vector<std::thread> pool;
-        pool.reserve(nthreads);
-        for (int t = 0; t < nthreads; t++)
-            pool.emplace_back([&, t]() { for (int k = t; k < count; k += nthreads) body(k); });
-        for (std::thread &th : pool) th.join();
-    };
     std::vector<double *> outF(P), outJ(P);
     std::vector<char> active(P, 1);
     long long rounds = 0;
     int rc = SOCP_OK;
+    using clk = std::chrono::steady_clock;
+    auto ms_since = [](clk::time_point t) { return std::chrono::duration<double, std::milli>(clk::now() - t).count(); };
+    double t_adv = 0, t_gpu = 0, t_copy = 0;
+    const double t_setup = ms_since(t_begin);
     for (;;) {
+        const clk::time_point ta = clk::now();
         reqF.clear(); reqJ.clear();
         // (1) advance every active state machine -- QR, dogleg, Broyden update: O(n^2)..O(n^3) host work per start,
         //     independent between starts, so it is spread over the host cores
@@ -121,8 +133,10 @@ extern "C" int socp_multistart_solve(socp_ctx *ctx, int P, const double *Z0, dou
                 reqJ.push_back(p);
             }
         }
+        t_adv += ms_since(ta);
         if (reqF.empty() && reqJ.empty()) break;
         rounds++;
+        const clk::time_point tg = clk::now();
         const int kF = (int)reqF.size(), kJ = (int)reqJ.size();
         if (trace) std::fprintf(stderr, "[socp_multistart] round %lld: %d residual requests, %d Jacobian requests\n", rounds, kF, kJ);
         // the residual launch and the first Jacobian chunk are enqueued before either result is awaited
@@ -150,8 +164,12 @@ extern "C" int socp_multistart_solve(socp_ctx *ctx, int P, const double *Z0, dou
             }
             if (kc) {
                 if ((rc = socp_ctx_synchronize(ctx)) != SOCP_OK) break;
+                t_gpu += ms_since(tg);
+                const clk::time_point tc = clk::now();
                 if (hipMemcpy(hJ.p, dJ.p, jacB * kc, hipMemcpyDeviceToHost) != hipSuccess) { rc = SOCP_ERR_HIP; break; }
-                for (int k = 0; k < kc; k++) std::memcpy(outJ[j0 + k], hJ.d() + (size_t)k * n * n, jacB);
+                // hundreds of MB per round at n ~ 100: spread the copies into the solvers' own buffers over the host threads
+                parallel_for(kc, [&](int k) { std::memcpy(outJ[j0 + k], hJ.d() + (size_t)k * n * n, jacB); });
+                t_copy += ms_since(tc);
             }
         }
         if (rc != SOCP_OK) break;
@@ -169,6 +187,7 @@ extern "C" int socp_multistart_solve(socp_ctx *ctx, int P, const double *Z0, dou
             }
         }
     }
+    if (trace) std::fprintf(stderr, "[socp_multistart] set-up %.1f ms, host advance %.1f ms, launches + wait (Jacobian rounds) %.1f ms, Jacobian read-back + scatter %.1f ms, total %.1f ms\n", t_setup, t_adv, t_gpu, t_copy, ms_since(t_begin));
     if (rounds_out) *rounds_out = rounds;
     (void)hipStreamSynchronize(aux);
     (void)hipStreamDestroy(aux);
