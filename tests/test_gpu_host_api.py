@@ -26,3 +26,22 @@ def test_conventions():
     assert got == ["unknown_parameter_name", "out_of_range", "solve_returns_1", "get_parameters_new_array",
                    "timeout_returns_minus_1", "no_device_twin_throws", "host_rk_helpers_throw"], out.stdout + out.stderr
     assert "does not exist" in out.stdout
+
+
+def test_independent_pairs_solve_concurrently():
+    """SURVEY 8b threading contract: one (model, shooting) pair per thread may solve concurrently; every thread's
+    result equals, bit for bit, what the same start gives in a serial run."""
+    import json
+    exe = os.path.join(os.path.dirname(EXE), "concurrent_solves")
+
+    def run(serial):
+        out = subprocess.run([exe, "6", str(serial)], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr
+        rows = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+        return {r["thread"]: r for r in rows}
+
+    par, ser = run(0), run(1)
+    assert sorted(par) == sorted(ser) == list(range(6))
+    for k in range(6):
+        assert par[k]["info"] == ser[k]["info"] == 1
+        assert par[k]["nfev"] == ser[k]["nfev"] and par[k]["z"] == ser[k]["z"]
