@@ -242,7 +242,10 @@ def main():
                          "hbm": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                  "frac": gbs / PEAK_HBM_GBS, "bytes_per_trajectory": BYTES_PER_TRAJ}},
             # Newton-level rate and wave occupancy beside the trajectory rate
+            # Newton-level rates: with M = 1 a residual evaluation is one trajectory, and a forward-difference
+            # Jacobian is the n + 1 = 15 evaluations of one start (single shooting has nothing to dedup)
             "jacobians_per_s": P * world * args.steps / elapsed_max,
+            "residual_evaluations_per_s": value,
             "occupancy": {"waves_per_launch": (traj_per_step_rank + 63) // 64,
                           "waves_per_simd_cap": min(3 if args.variant == "fast" else 2, max(1, -(-((traj_per_step_rank + 63) // 64) // 1024))),
                           "simds": 1024},
