@@ -51,6 +51,11 @@ void socp_hybr_destroy(socp_hybr *s);
 int socp_hybr_start(socp_hybr *s, const double *x0, const double *diag);
 /* user_flag: value the caller's evaluation returned for the PREVIOUS request (< 0 aborts). */
 int socp_hybr_advance(socp_hybr *s, int user_flag, const double **x_eval, double **out);
+/* host threads for this solver's O(n^3) factor work (qrfac / qform); default 1.  The factorisation is bit-identical
+ * for any count (columns are dealt out to threads, each updated by the serial sequence of operations).  The
+ * blocking entry points (hybrd, hybrj, socp_hybrd_batched) pick up to 16 threads by themselves when n >= 192;
+ * the environment variable SOCP_LINALG_THREADS overrides that choice. */
+int socp_hybr_set_threads(socp_hybr *s, int threads);
 int socp_hybr_info(const socp_hybr *s);
 int socp_hybr_nfev(const socp_hybr *s);
 int socp_hybr_njev(const socp_hybr *s);

@@ -16,7 +16,9 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -66,51 +68,124 @@ double enorm(int n, const double *x)
 // Householder QR of the n x n matrix a (column-major, ld lda), no column pivoting: on return the
 // strict upper triangle holds R's off-diagonal, rdiag its diagonal, the lower trapezoid the
 // Householder vectors; acnorm = input column norms.
-void qrfac_nopivot(int n, double *a, int lda, double *rdiag, double *acnorm)
+//
+// MINPACK's qrfac is a right-looking column algorithm: reflector j is finished on column j, then applied to
+// every later column k, each column on its own (one dot product, one axpy).  For large n (the 832-unknown
+// doubleIntegrator problem factors 832 x 832 twice per solve, ~0.8 Gflop each) the work is split by COLUMN: the
+// reflectors of a panel of 32 columns are finished serially (that needs only the panel itself), then host threads
+// bring the remaining columns up to date, each thread applying the panel's reflectors to its own columns in the
+// order 0, 1, ... exactly as the serial code does.  Every number is computed by the same operations in the same
+// order, so the factorisation is bit-identical for any thread count.  Threads are started per panel and joined
+// (no spinning: the solver may run under a CPU quota).
+namespace {
+inline void finish_reflector(int n, int j, double *aj, double *rdiag)
 {
-    for (int j = 0; j < n; j++) {
-        acnorm[j] = enorm(n, a + (size_t)j * lda);
-        rdiag[j] = acnorm[j];
+    double ajnorm = enorm(n - j, aj + j);
+    if (ajnorm != 0) {
+        if (aj[j] < 0) ajnorm = -ajnorm;
+        for (int i = j; i < n; i++) aj[i] /= ajnorm;
+        aj[j] += 1;
     }
-    for (int j = 0; j < n; j++) {
-        double *aj = a + (size_t)j * lda;
-        double ajnorm = enorm(n - j, aj + j);
-        if (ajnorm != 0) {
-            if (aj[j] < 0) ajnorm = -ajnorm;
-            for (int i = j; i < n; i++) aj[i] /= ajnorm;
-            aj[j] += 1;
-            for (int k = j + 1; k < n; k++) {
-                double *ak = a + (size_t)k * lda;
-                double sum = 0;
-                for (int i = j; i < n; i++) sum += aj[i] * ak[i];
-                const double temp = sum / aj[j];
-                for (int i = j; i < n; i++) ak[i] -= temp * aj[i];
-            }
+    rdiag[j] = -ajnorm;            // == 0 marks an identity reflector
+}
+inline void apply_reflector(int n, int j, const double *aj, double *ak)
+{
+    double sum = 0;
+    for (int i = j; i < n; i++) sum += aj[i] * ak[i];
+    const double temp = sum / aj[j];
+    for (int i = j; i < n; i++) ak[i] -= temp * aj[i];
+}
+}  // namespace
+
+void qrfac_nopivot(int n, double *a, int lda, double *rdiag, double *acnorm, int threads)
+{
+    for (int j = 0; j < n; j++) acnorm[j] = enorm(n, a + (size_t)j * lda);
+    if (threads <= 1 || n < 2 * threads) {
+        for (int j = 0; j < n; j++) {
+            double *aj = a + (size_t)j * lda;
+            finish_reflector(n, j, aj, rdiag);
+            if (rdiag[j] != 0)
+                for (int k = j + 1; k < n; k++) apply_reflector(n, j, aj, a + (size_t)k * lda);
         }
-        rdiag[j] = -ajnorm;
+        return;
+    }
+    const int T = threads, NB = 32;
+    for (int j0 = 0; j0 < n; j0 += NB) {
+        const int j1 = std::min(j0 + NB, n);
+        for (int j = j0; j < j1; j++) {                    // the panel: columns j0 .. j1-1 among themselves
+            double *aj = a + (size_t)j * lda;
+            finish_reflector(n, j, aj, rdiag);
+            if (rdiag[j] != 0)
+                for (int k = j + 1; k < j1; k++) apply_reflector(n, j, aj, a + (size_t)k * lda);
+        }
+        if (j1 >= n) break;
+        auto work = [&](int tid) {                          // the rest: each column through reflectors j0 .. j1-1 in order
+            for (int k = j1 + tid; k < n; k += T) {
+                double *ak = a + (size_t)k * lda;
+                for (int j = j0; j < j1; j++)
+                    if (rdiag[j] != 0) apply_reflector(n, j, a + (size_t)j * lda, ak);
+            }
+        };
+        const int use = std::min(T, n - j1);
+        std::vector<std::thread> pool;
+        for (int t = 1; t < use; t++) pool.emplace_back(work, t);
+        work(0);
+        for (std::thread &th : pool) th.join();
     }
 }
 
-// accumulate the orthogonal factor Q (n x n) from the Householder vectors left by qrfac
-void qform(int n, double *q, int ldq, double *wa)
+// accumulate the orthogonal factor Q (n x n) from the Householder vectors left by qrfac.  Column j of Q is
+// e_j pushed through the reflectors j, j-1, ..., 0 -- independent of every other column once the vectors are
+// copied out of the way, so the columns are dealt out to threads with the serial operation order per column.
+void qform(int n, double *q, int ldq, double *wa, int threads)
 {
-    for (int j = 1; j < n; j++)
-        for (int i = 0; i < j; i++) q[i + (size_t)j * ldq] = 0;
-    for (int l = 0; l < n; l++) {
-        const int k = n - 1 - l;
-        double *qk = q + (size_t)k * ldq;
-        for (int i = k; i < n; i++) { wa[i] = qk[i]; qk[i] = 0; }
-        qk[k] = 1;
-        if (wa[k] != 0) {
-            for (int j = k; j < n; j++) {
-                double *qj = q + (size_t)j * ldq;
-                double sum = 0;
-                for (int i = k; i < n; i++) sum += qj[i] * wa[i];
-                const double temp = sum / wa[k];
-                for (int i = k; i < n; i++) qj[i] -= temp * wa[i];
+    if (threads <= 1 || n < 2 * threads) {
+        for (int j = 1; j < n; j++)
+            for (int i = 0; i < j; i++) q[i + (size_t)j * ldq] = 0;
+        for (int l = 0; l < n; l++) {
+            const int k = n - 1 - l;
+            double *qk = q + (size_t)k * ldq;
+            for (int i = k; i < n; i++) { wa[i] = qk[i]; qk[i] = 0; }
+            qk[k] = 1;
+            if (wa[k] != 0) {
+                for (int j = k; j < n; j++) {
+                    double *qj = q + (size_t)j * ldq;
+                    double sum = 0;
+                    for (int i = k; i < n; i++) sum += qj[i] * wa[i];
+                    const double temp = sum / wa[k];
+                    for (int i = k; i < n; i++) qj[i] -= temp * wa[i];
+                }
             }
         }
+        return;
     }
+    // Householder vectors, packed: v_k = V[off[k] .. off[k] + n - k)
+    std::vector<size_t> off(n);
+    size_t total = 0;
+    for (int k = 0; k < n; k++) { off[k] = total; total += (size_t)(n - k); }
+    std::vector<double> V(total);
+    for (int k = 0; k < n; k++) std::memcpy(V.data() + off[k], q + (size_t)k * ldq + k, sizeof(double) * (n - k));
+    const int T = threads;
+    auto work = [&](int tid) {
+        for (int j = tid; j < n; j += T) {
+            double *qj = q + (size_t)j * ldq;
+            for (int i = 0; i < n; i++) qj[i] = 0;
+            qj[j] = 1;
+            for (int k = j; k >= 0; k--) {
+                const double *v = V.data() + off[k] - k;       // v[i] for i = k .. n-1
+                if (v[k] == 0) continue;
+                double sum = 0;
+                for (int i = k; i < n; i++) sum += qj[i] * v[i];
+                const double temp = sum / v[k];
+                for (int i = k; i < n; i++) qj[i] -= temp * v[i];
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < T; t++) pool.emplace_back(work, t);
+    work(0);
+    for (std::thread &th : pool) th.join();
+    (void)wa;
 }
 
 // dogleg step: minimiser of |R x - qtb| within the ellipsoid |diag x| <= delta, restricted to
@@ -281,6 +356,7 @@ struct Core {
     int n = 0, maxfev = 0, mode = 1, msum = 0, ldfjac = 0, lr = 0;
     double xtol = 0, epsfcn = 0, factor = 0;
     bool analytic = false, bad_input = false;
+    int lin_threads = 1;            // host threads for qrfac / qform (bit-identical for any count; see qrfac_nopivot)
     // caller-visible arrays
     double *x = nullptr, *fvec = nullptr, *diag = nullptr, *fjac = nullptr, *r = nullptr, *qtf = nullptr;
     double *wa1 = nullptr, *wa2 = nullptr, *wa3 = nullptr, *wa4 = nullptr;
@@ -324,7 +400,7 @@ struct Core {
     void after_jacobian()
     {
         if (analytic) njev += 1; else nfev += msum;
-        qrfac_nopivot(n, fjac, ldfjac, wa1, wa2);      // wa1 = diag(R), wa2 = column norms
+        qrfac_nopivot(n, fjac, ldfjac, wa1, wa2, lin_threads);      // wa1 = diag(R), wa2 = column norms
         if (iter == 1) {
             if (mode != 2)
                 for (int j = 0; j < n; j++) diag[j] = wa2[j] == 0 ? 1.0 : wa2[j];
@@ -352,7 +428,7 @@ struct Core {
             r[l] = wa1[j];
             if (wa1[j] == 0) sing = true;
         }
-        qform(n, fjac, ldfjac, wa1);
+        qform(n, fjac, ldfjac, wa1, lin_threads);
         if (mode != 2)
             for (int j = 0; j < n; j++) diag[j] = std::max(diag[j], wa2[j]);
     }
@@ -501,6 +577,16 @@ void bind(Core &s, int n, double *x, double *fvec, double xtol, int maxfev, doub
     s.phase = PH_INIT;
 }
 
+// host threads for the O(n^3) factor work of ONE solve (the blocking entry points): none below n = 192, where a
+// factorisation is < 10 Mflop; SOCP_LINALG_THREADS overrides (1 = serial).  Results do not depend on the count.
+int auto_lin_threads(int n)
+{
+    if (const char *e = std::getenv("SOCP_LINALG_THREADS")) { const int t = std::atoi(e); return t < 1 ? 1 : (t > 64 ? 64 : t); }
+    if (n < 192) return 1;
+    const unsigned hw = std::thread::hardware_concurrency();
+    return (int)std::max(1u, std::min(16u, hw ? hw : 1u));
+}
+
 }  // namespace
 
 extern "C" {
@@ -514,6 +600,7 @@ int socp_hybrd_batched(cminpack_func_nn fcn, socp_fdjac_fn fdjac, void *p, int n
     Core s;
     bind(s, n, x, fvec, xtol, maxfev, epsfcn, diag, mode, factor, fjac, ldfjac, r, lr, qtf, wa1, wa2, wa3, wa4);
     s.analytic = false;
+    s.lin_threads = auto_lin_threads(n);
     if (ml < 0 || mu < 0) s.bad_input = true;
     s.msum = std::min(ml + mu + 1, n);
     const double *xe = nullptr;
@@ -552,6 +639,7 @@ int hybrj(cminpack_funcder_nn fcn, void *p, int n, double *x, double *fvec, doub
     Core s;
     bind(s, n, x, fvec, xtol, maxfev, 0.0, diag, mode, factor, fjac, ldfjac, r, lr, qtf, wa1, wa2, wa3, wa4);
     s.analytic = true;
+    s.lin_threads = auto_lin_threads(n);
     const double *xe = nullptr;
     double *out = nullptr;
     int flag = 0;
@@ -604,6 +692,15 @@ int socp_hybr_start(socp_hybr *s, const double *x0, const double *diag)
 int socp_hybr_advance(socp_hybr *s, int user_flag, const double **x_eval, double **out)
 {
     return s->core.advance(user_flag, x_eval, out);
+}
+
+// host threads for this solver's factor work (default 1: the lock-step multi-start engine already runs one state
+// machine per thread); any count gives the same bits
+int socp_hybr_set_threads(socp_hybr *s, int threads)
+{
+    if (!s || threads < 1) return -1;
+    s->core.lin_threads = threads;
+    return 0;
 }
 
 int socp_hybr_info(const socp_hybr *s) { return s->core.info; }

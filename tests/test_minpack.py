@@ -149,3 +149,34 @@ def test_improper_input_is_info_zero():
 def test_maxfev_is_info_two():
     out = capi.hybrd(trig, np.ones(8) / 8, maxfev=20)
     assert out["info"] == 2
+
+
+def test_threaded_factor_work_is_bit_identical():
+    """qrfac / qform split their columns over host threads for large n; every column is updated by the serial
+    sequence of operations, so iterates do not depend on the thread count (n = 260 > the 192 threshold)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, json
+sys.path.insert(0, %r)
+import numpy as np
+from socp_amd import capi
+n = 260
+rng = np.random.default_rng(3)
+A = rng.normal(size=(n, n)) / np.sqrt(n) + 2 * np.eye(n)
+b = rng.normal(size=n)
+f = lambda x: A @ x + 0.3 * np.sin(x) - b
+r = capi.hybrd(f, np.zeros(n), xtol=1e-12, epsfcn=1e-15)
+print(json.dumps({"info": r["info"], "nfev": r["nfev"], "x": [float(v).hex() for v in r["x"]]}))
+''' % root
+    res = {}
+    for t in ("1", "3", "8"):
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                             env=dict(os.environ, SOCP_LINALG_THREADS=t))
+        assert out.returncode == 0, out.stderr[-2000:]
+        res[t] = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["1"]["info"] == 1
+    assert res["1"] == res["3"] == res["8"]
