@@ -323,30 +323,40 @@ inline void decode_rotation(double t, double &cs, double &sn)
 }
 
 // a (m x n, column-major) <- a * Q1 with Q1 replayed from the encodings left in v and w by r1updt
-void r1mpyq(int m, int n, double *a, int lda, const double *v, const double *w)
+void r1mpyq(int m, int n, double *a, int lda, const double *v, const double *w, int threads = 1)
 {
-    double *an = a + (size_t)(n - 1) * lda;
-    for (int nmj = 1; nmj <= n - 1; nmj++) {
-        const int j = n - 1 - nmj;
-        double cs, sn;
-        decode_rotation(v[j], cs, sn);
-        double *aj = a + (size_t)j * lda;
-        for (int i = 0; i < m; i++) {
-            const double temp = cs * aj[i] - sn * an[i];
-            an[i] = sn * aj[i] + cs * an[i];
-            aj[i] = temp;
+    // every row of a goes through the same 2(n-1) rotations and no rotation mixes rows: large matrices are split
+    // by ROW RANGE over host threads (same operations per element, bit-identical for any count)
+    auto rows = [&](int i0, int i1) {
+        double *an = a + (size_t)(n - 1) * lda;
+        for (int nmj = 1; nmj <= n - 1; nmj++) {
+            const int j = n - 1 - nmj;
+            double cs, sn;
+            decode_rotation(v[j], cs, sn);
+            double *aj = a + (size_t)j * lda;
+            for (int i = i0; i < i1; i++) {
+                const double temp = cs * aj[i] - sn * an[i];
+                an[i] = sn * aj[i] + cs * an[i];
+                aj[i] = temp;
+            }
         }
-    }
-    for (int j = 0; j < n - 1; j++) {
-        double cs, sn;
-        decode_rotation(w[j], cs, sn);
-        double *aj = a + (size_t)j * lda;
-        for (int i = 0; i < m; i++) {
-            const double temp = cs * aj[i] + sn * an[i];
-            an[i] = -sn * aj[i] + cs * an[i];
-            aj[i] = temp;
+        for (int j = 0; j < n - 1; j++) {
+            double cs, sn;
+            decode_rotation(w[j], cs, sn);
+            double *aj = a + (size_t)j * lda;
+            for (int i = i0; i < i1; i++) {
+                const double temp = cs * aj[i] + sn * an[i];
+                an[i] = -sn * aj[i] + cs * an[i];
+                aj[i] = temp;
+            }
         }
-    }
+    };
+    if (threads <= 1 || m < 256) { rows(0, m); return; }
+    const int T = std::min(threads, m / 64);
+    std::vector<std::thread> pool;
+    for (int t = 1; t < T; t++) pool.emplace_back(rows, (int)((long)m * t / T), (int)((long)m * (t + 1) / T));
+    rows(0, (int)((long)m / T));
+    for (std::thread &th : pool) th.join();
 }
 
 enum Phase { PH_INIT, PH_F0, PH_JAC, PH_TRIAL, PH_DONE };
@@ -489,7 +499,7 @@ struct Core {
             if (ratio >= p0001) qtf[j] = sum;
         }
         r1updt(n, r, wa1, wa2, wa3, sing);
-        r1mpyq(n, n, fjac, ldfjac, wa2, wa3);
+        r1mpyq(n, n, fjac, ldfjac, wa2, wa3, lin_threads);
         r1mpyq(1, n, qtf, 1, wa2, wa3);
         jeval = false;
         return request_trial(xe, out);
