@@ -144,3 +144,23 @@ def test_degenerate_states_take_the_plain_division_path_and_still_match(built):
     assert np.array_equal(f, ref, equal_nan=True)
     assert np.isnan(ref).any() and np.isinf(ref).any() and np.isfinite(ref).any()   # the set really contains all kinds
     c.close()
+
+
+def test_extreme_air_density_arguments_bitwise(built):
+    """exp(-kr (r - 1)) over the whole range glibc treats by its main algorithm and by its x <= -512 branch
+    (radii 0.05 .. 2.35 => arguments +475 .. -675): the right-hand side still equals the CPU path bit for bit."""
+    from socp_amd import capi
+    params = [3.5, 7.0, 310.0, 500.0, 1.0, 1.0, 1.0, -1.0]
+    o = Oracle(MODEL_GODDARD, params=params)
+    c = capi.Context(capi.MODEL_GODDARD)
+    c.set_params(params)
+    X, t = random_states(4000, seed=11)
+    rng = np.random.default_rng(12)
+    radius = rng.uniform(0.05, 2.35, len(X))
+    X[:, 0:3] *= (radius / np.linalg.norm(X[:, 0:3], axis=1))[:, None]
+    f = c.eval_batch(capi.EVAL_RHS, t, X)
+    with np.errstate(all="ignore"):
+        ref = np.array([o.rhs(t[b], X[b]) for b in range(len(X))])
+    assert np.array_equal(f, ref, equal_nan=True)
+    assert np.sum(radius > 2.03) > 300                  # the x <= -512 branch is well represented
+    c.close()
