@@ -47,6 +47,25 @@ __device__ __forceinline__ bool den_ok(double d)
     return a > 0x1p-400 && a < 0x1p400;              // false for NaN
 }
 
+// The same idea for sqrt: the compiler's correctly rounded double sqrt is  scale-if-tiny, v_rsq, eight fused steps,
+// unscale, and a class test that passes 0 / inf / NaN through (22 instructions).  For an argument within
+// 2^-800 .. 2^800 the scaling and the class test are pass-through; sqrt_in_range() is the remaining ten
+// instructions, in the compiler's order.
+__device__ __forceinline__ bool sqrt_arg_ok(double x) { return x > 0x1p-800 && x < 0x1p800; }
+__device__ __forceinline__ double sqrt_in_range(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = y * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    double d = __builtin_fma(-g, g, x);
+    h = __builtin_fma(h, r, h);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    return __builtin_fma(d, h, g);
+}
+
 enum { GP_C = 0, GP_B, GP_KD, GP_KR, GP_UMAX, GP_MU1, GP_MU2, GP_SING };
 enum { DP_UMAX = 0, DP_AMAX, DP_MUT };
 enum { CP_R0 = 0, CP_TINF, CP_TINC, CP_N, CP_IMAX, CP_MUI, CP_UMIN, CP_UMAX };
@@ -64,17 +83,30 @@ struct GoddardExactT {
     // quantities both Model() and Control() derive from the state (goddard.cpp:66-76,121-130)
     struct Common {
         double r, v, pvdotv, g, norm_pv, E;
+        bool shared;               // r, v, |p_v| and m are all in range: shared-denominator quotients, short sqrt
     };
 
     __device__ static __forceinline__ Common common(const ModelParams &P, const double (&X)[S])
     {
         Common c;
-        c.r = sqrt(X[0]*X[0] + X[1]*X[1] + X[2]*X[2]);
-        c.v = sqrt(X[3]*X[3] + X[4]*X[4] + X[5]*X[5]);
+        const double r2 = X[0]*X[0] + X[1]*X[1] + X[2]*X[2];
+        const double v2 = X[3]*X[3] + X[4]*X[4] + X[5]*X[5];
+        const double q2 = X[10]*X[10] + X[11]*X[11] + X[12]*X[12];
         c.pvdotv = X[10]*X[3] + X[11]*X[4] + X[12]*X[5];
-        if (den_ok(c.r)) { const Den R(c.r); c.g = 1 / R / R; }      // same bits as 1 / r / r (see Den)
-        else c.g = 1 / c.r / c.r;
-        c.norm_pv = sqrt(X[10]*X[10] + X[11]*X[11] + X[12]*X[12]);
+        // (squares within 2^-800 .. 2^800 <=> norms within 2^-400 .. 2^400, the den_ok range)
+        c.shared = sqrt_arg_ok(r2) && sqrt_arg_ok(v2) && sqrt_arg_ok(q2) && den_ok(X[6]);
+        if (c.shared) {
+            c.r = sqrt_in_range(r2);
+            c.v = sqrt_in_range(v2);
+            c.norm_pv = sqrt_in_range(q2);
+            const Den R(c.r);
+            c.g = 1 / R / R;                                  // same bits as 1 / r / r (see Den)
+        } else {
+            c.r = sqrt(r2);
+            c.v = sqrt(v2);
+            c.norm_pv = sqrt(q2);
+            c.g = 1 / c.r / c.r;
+        }
         c.E = exp_glibc(-P.p[GP_KR]*(c.r - 1));
         return c;
     }
@@ -169,7 +201,7 @@ struct GoddardExactT {
                                               const double (&X)[S], double (&dX)[S])
     {
         const Common c = common(P, X);
-        if (den_ok(c.r) && den_ok(c.v) && den_ok(X[6]) && den_ok(c.norm_pv)) rhs_with<Den>(P, c, sw0, sw1, t, X, dX);
+        if (c.shared) rhs_with<Den>(P, c, sw0, sw1, t, X, dX);
         else rhs_with<double>(P, c, sw0, sw1, t, X, dX);
     }
 
