@@ -23,7 +23,8 @@ def counters(d, kernel):
         for r in csv.DictReader(open(f)):
             if kernel in r["Kernel_Name"] and float(r["Grid_Size"]) > 4096:
                 out[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in out.items()}
+    # median over the launches: a dispatch now and then reports a doubled counter (seen on SQ_WAVES)
+    return {k: sorted(v)[len(v) // 2] for k, v in out.items()}
 
 
 def main():
@@ -44,7 +45,7 @@ def main():
         c.update(counters(d, kernel))
     fetch_b = 2.0 * c.get("FETCH_SIZE", 0.0) * 1024.0
     write_b = c.get("WRITE_SIZE", 0.0) * 1024.0
-    summ = {"tag": tag, "kernel": kernel, "counters_avg_per_launch": c,
+    summ = {"tag": tag, "kernel": kernel, "counters_median_per_launch": c,
             "hbm_read_bytes_per_launch(2x FETCH_SIZE KiB)": fetch_b,
             "hbm_write_bytes_per_launch(WRITE_SIZE KiB)": write_b,
             "hbm_bytes_per_launch": fetch_b + write_b}
