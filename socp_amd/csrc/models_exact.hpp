@@ -21,7 +21,9 @@ namespace socp {
 // NaN, subnormal, or when the exponents are extreme; otherwise they pass the operands through and the first five
 // steps depend on d alone.  `Den` does those five steps once and `n / Den` the last three, with the SAME
 // instructions in the same order -- so for a denominator within 2^-400 .. 2^400 and numerators within
-// 2^-568 .. 2^368 every quotient has exactly the bits of the compiler's n / d.  The models below ask den_ok()
+// 2^-568 .. 2^368 every quotient has exactly the bits of the compiler's n / d -- with one exception that no
+// arithmetic can see: a NEGATIVE-ZERO numerator over a positive denominator gives +0 where the fix-up step would
+// restore -0 (the shared denominators r, v, m, |p_v| are positive; a zero quotient only ever meets an addition).  The models below ask den_ok()
 // for each shared denominator and fall back to plain division (DenT = double) otherwise; the reference's
 // right-hand sides divide ~56 times by four distinct quantities (r, v, m, |p_v|).
 struct Den {
