@@ -7,6 +7,11 @@
 //                       85 unknowns in <zfile> (node states + tf), the state testGoddard.cpp is in
 //                       just before its k-th SolveOCP call
 // Run by tests/test_host_flow.py on the GPU box; expected solutions are in tests/golden/.
+//
+// The program only uses the reference's public API, so it also compiles against the REFERENCE's own headers and
+// sources (-DSOCP_REFERENCE_BUILD, oracle/Makefile target `link`): that binary is the reference's shooting.cpp bound
+// to this library's hybrd/hybrj at link level (boundary test, tests/test_link_dropin.py) and the "as shipped" CPU
+// baseline B0 of bench.py.  SOCP_FLOW_THREADS = numThread handed to the shooting constructor (default 1).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -38,8 +43,13 @@ void report_body(const char *stage, int info, const shooting &s)
     std::vector<real> z;
     s.GetParameters(z);
     std::vector<int> calls = s.GetCallNumber();
+#ifdef SOCP_REFERENCE_BUILD
+    const long long trajectories = -1;               // the reference does not count them
+#else
+    const long long trajectories = s.GetTrajectoryCount();
+#endif
     std::printf("\"stage\": \"%s\", \"info\": %d, \"nfev\": %d, \"n\": %d, \"trajectories\": %lld, \"z\": [", stage, info,
-                calls[0], (int)z.size(), s.GetTrajectoryCount());
+                calls[0], (int)z.size(), trajectories);
     for (size_t k = 0; k < z.size(); k++) std::printf("%s%.17g", k ? ", " : "", z[k]);
     std::printf("]}\n");
     std::fflush(stdout);
@@ -89,13 +99,21 @@ int main(int argc, char **argv)
     const std::string extra = argc > a + 3 ? argv[a + 3] : "";
 
     const std::string trace = single ? (argc > a + 4 ? argv[a + 4] : "") : extra;
+#ifndef SOCP_REFERENCE_BUILD
     if (std::getenv("SOCP_FLOW_ADAPTIVE")) odeTools::UseAdaptiveIntegrator(true);     // the -D_USE_BOOST configuration
+#endif
+    const char *thr = std::getenv("SOCP_FLOW_THREADS");
+    const int numThread = thr ? std::atoi(thr) : 1;
     goddard my_goddard(trace, stepNbr);
     const int dim = my_goddard.GetDim();
     my_goddard.SetParameterDataName("mu2", 1.0);
-    shooting my_shooting(my_goddard, kMulti, 1);
+    shooting my_shooting(my_goddard, kMulti, numThread);
     my_shooting.SetPrecision(xtol);
+#ifndef SOCP_REFERENCE_BUILD
     my_shooting.SetJacobianDedup(dedup);
+#else
+    (void)dedup;
+#endif
     my_shooting.SetMode(model::FREE, final_modes(dim));
 
     model::mstate Xf(2 * dim);
