@@ -9,19 +9,38 @@ forward-difference-Jacobian batch of every start: base residual + 14 perturbed r
 (socp_fd_rows_dev), followed by the small difference kernel that forms the Jacobians.  Inputs are
 resident in HBM before the timed region.  value = trajectories of ALL ranks / max-over-ranks time.
 
-Extra objects in the JSON line:
-  roofline      dominant kernel (fdrows_lane_kernel).  This path has no dense contraction and moves
-                224 B per trajectory, so neither "mfma" nor "hbm" bounds it: the binding resource is
-                FP64 vector issue.  `bound` is therefore "valu_fp64" (peak = 256 CU x 4 SIMD x 16
-                FP64 lanes x 2 flop x 2.4 GHz = 78.6 TFLOP/s, half the FP32 vector peak of
-                MI355X_MICROARCH.md); the HBM view the contract asks for is in roofline.hbm.
-  cpu_baseline  the reference's own model::ComputeTraj (oracle/_ref, kind "reference") or the C
-                oracle (kind "port") timed on this box's host cores on a bounded sample.
-  single_problem  (--single-problem) the latency-bound case: ONE problem (15 trajectories) per launch.
+Launch forms (both end in one process per GPU over RCCL, no data-path collective: "replicas of
+independent problems", the only exchange is the gather of per-rank result records after the timed region):
+  python bench.py --gpus N ...                                  N > 1 without WORLD_SIZE: this process starts
+                                                                `python -m torch.distributed.run --nproc-per-node N
+                                                                bench.py ...` as a child BEFORE touching the GPU,
+                                                                relays its JSON line and fails if fewer than N ranks report
+  python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...     the driver's form
+
+Objects in the JSON line beside the contract's fields (N = 1; `--lean` drops the extra timed legs):
+  roofline        dominant kernel (fdrows_lane_kernel).  This path has no dense contraction and moves 224 B per
+                  trajectory, so neither "mfma" nor "hbm" bounds it: the binding resource is FP64 vector issue.
+                  `bound` is therefore "valu_fp64" (peak = 256 CU x 4 SIMD x 16 FP64 lanes x 2 flop x 2.4 GHz =
+                  78.6 TFLOP/s, half the FP32 vector peak of MI355X_MICROARCH.md); the HBM view the contract asks for
+                  is in roofline.hbm.  `traffic` is NOT measured in this run: it is the PMC figure of the same launch
+                  recorded under profiles/ (`traffic_source` names the file).
+  exact           the same workload on the bit-identical (reference operation order) flavour -- what a drop-in user gets
+                  by default (SOCP_VARIANT_AUTO) -- from a second timed region: value, kernel_ms, roofline frac.
+  parity          after the timed regions: FD-batch rows of the first starts recomputed by the CPU oracle (checker, never
+                  timed here) and compared with what the two flavours left in HBM: max relative error, bitwise flag.
+  single_problem  ONE problem (15 trajectories) per launch: the latency-bound case, stated not hidden.
+  north_star_128  north_star's target size: Goddard, M = 9 segments, n = 128 unknowns: one FD Jacobian (1152 trajectories
+                  of 1e4 steps as the reference integrates them; fewer with the segment dedup), ms, trajectories/s and the
+                  ratio to cpu_baseline (B1) -- north_star asks for >= 10x.
+  cpu_baseline    B1: the reference's own model::ComputeTraj (oracle/_ref, kind "reference") or the C oracle (kind
+                  "port") on this box's host cores, bounded sample.  cpu_baseline.b0 = "as shipped": the reference's
+                  shooting.cpp + its per-call std::threads, bound to this library's hybrd (oracle/_ref/link), one
+                  continuation solve at 1e4 steps per segment, trajectories/s = nfev x M / wall.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -41,6 +60,64 @@ PSTAR = np.array([-8.121947733, 7.775439382e-3, 0.7775438809, -0.4779369965, 5.7
                   5.715009222e-2, 9.958404873e-2])
 TF = 0.2640825
 GODDARD_PARAMS = [3.5, 7.0, 310.0, 500.0, 1.0, 1.0, 1.0, -1.0]
+EPSFCN = 1e-15
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--starts", type=int, default=13107,
+                    help="independent shooting problems per GPU; default: 15 x 13107 = 196 605 trajectories = 3072 "
+                         "wavefronts = 3 per SIMD (an exactly full chip); any size >= 4096 runs within 10 %% of it")
+    ap.add_argument("--rk4-steps", type=int, default=10000)
+    ap.add_argument("--variant", choices=["exact", "fast"], default="fast",
+                    help="flavour of the headline `value`.  fast: restructured arithmetic (<= 1e-8 vs the reference order "
+                         "after 1e4 steps, converged solutions within 1e-8: tests/test_gpu_parity.py, test_host_flow.py); "
+                         "exact: reference operation order, bit-identical.  The other flavour is reported beside it.")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="0 disables the CPU baseline legs")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo + --share-device0: rehearse the multi-rank path on a one-GPU box (collectives on CPU tensors)")
+    ap.add_argument("--share-device0", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--lean", action="store_true",
+                    help="N = 1: only the headline timed region, roofline and cpu_baseline (no exact / parity / "
+                         "single_problem / north_star_128 legs)")
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-launched N > 1 job (0: pick a free one)")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: start one process per GPU before anything here touches the GPU
+# ------------------------------------------------------------------------------------------------------------------
+def self_launch(args):
+    import socket
+    port = args.master_port
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MASTER_ADDR"] = "127.0.0.1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    child = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for l in child.stdout.splitlines():
+        if l.startswith("{"):
+            try:
+                line = json.loads(l)
+            except ValueError:
+                pass
+    if child.returncode != 0 or line is None:
+        sys.stderr.write("bench.py: the %d-rank child job failed (exit %d)\n%s\n" % (args.gpus, child.returncode, child.stdout[-2000:]))
+        return child.returncode or 1
+    if line.get("n_gpus") != args.gpus or line.get("ranks_reported") != args.gpus:
+        sys.stderr.write("bench.py: %d ranks were asked for, %s reported\n" % (args.gpus, line.get("ranks_reported")))
+        return 1
+    print(json.dumps(line), flush=True)
+    return 0
 
 
 def make_starts(P, seed):
@@ -66,43 +143,46 @@ def setup_context(device, steps_rk4, variant):
     return ctx
 
 
+def fd_rows_inputs(Z, count):
+    """The first `count` trajectories of the step's batch as initial states: row 0 of a start is z, row j + 1 is
+    z + h_j e_j with MINPACK's h."""
+    eps = np.sqrt(EPSFCN)
+    X0 = np.empty((count, 14))
+    for k in range(count):
+        p, row = divmod(k, ROWS)
+        X0[k] = Z[p % len(Z)]
+        if row > 0:
+            j = row - 1
+            h = eps * abs(X0[k, j]) or eps
+            X0[k, j] += h
+    return X0
+
+
 def cpu_baseline(steps_rk4, Z, target_seconds):
-    """Reference (or port) on the host cores, bounded sample of the SAME trajectories (rows of the
-    FD batch of the first starts)."""
+    """B1: reference (or port) on the host cores, bounded sample of the SAME trajectories (rows of the FD batch of the
+    first starts)."""
     from oracle import oracle as orc
     threads = min(16, os.cpu_count() or 1)      # the GPU box's CPU share for one GPU
-    eps = np.sqrt(1e-15)
-
-    def sample_rows(count):
-        X0 = np.empty((count, 14))
-        for k in range(count):
-            p, row = divmod(k, ROWS)
-            X0[k] = Z[p % len(Z)]
-            if row > 0:
-                j = row - 1
-                h = eps * abs(X0[k, j]) or eps
-                X0[k, j] += h
-        return X0
 
     if orc.have_ref():
         ref = orc.Ref(orc.MODEL_GODDARD, step_nbr=steps_rk4)
-        probe = sample_rows(threads)
+        probe = fd_rows_inputs(Z, threads)
         _, sec = ref.goddard_traj_batch(threads, steps_rk4, GODDARD_PARAMS, 0.0, TF, probe)
         count = int(max(threads, min(65536, threads * round(target_seconds / max(sec, 1e-3)))))
-        X0 = sample_rows(count)
+        X0 = fd_rows_inputs(Z, count)
         _, sec = ref.goddard_traj_batch(threads, steps_rk4, GODDARD_PARAMS, 0.0, TF, X0)
         return {"value": count / sec, "unit": "trajectories/s", "cores": threads, "kind": "reference",
                 "per_core": count / sec / threads,
-                "sample": "%d trajectories (FD-batch rows of the first %d starts), %d RK4 steps each, "
+                "sample": "B1: %d trajectories (FD-batch rows of the first %d starts), %d RK4 steps each, "
                           "reference model::ComputeTraj, one goddard object per std::thread, %.1f s"
                           % (count, (count + ROWS - 1) // ROWS, steps_rk4, sec)}
     o = orc.Oracle(orc.MODEL_GODDARD, step_nbr=steps_rk4, params=GODDARD_PARAMS)
-    probe = sample_rows(2)
+    probe = fd_rows_inputs(Z, 2)
     t = time.perf_counter()
     o.integrate_batch(0.0, TF, probe)
     per = (time.perf_counter() - t) / 2
     count = int(max(2, min(4096, round(target_seconds / max(per, 1e-4)))))
-    X0 = sample_rows(count)
+    X0 = fd_rows_inputs(Z, count)
     t = time.perf_counter()
     o.integrate_batch(0.0, TF, X0)
     sec = time.perf_counter() - t
@@ -110,32 +190,190 @@ def cpu_baseline(steps_rk4, Z, target_seconds):
             "sample": "%d trajectories, %d RK4 steps each, C oracle single thread, %.1f s" % (count, steps_rk4, sec)}
 
 
+def cpu_baseline_b0(steps_rk4, target_seconds):
+    """B0 "as shipped" (BASELINE.md 3): the reference's shooting.cpp (residual callbacks, a std::thread per segment block
+    created and joined on every call, shooting.cpp:1142-1157) bound to this library's hybrd at link level, numThread =
+    min(M, cores) = 6: the KD 0 -> 310 continuation solve of testGoddard (M = 6, n = 85) from the test's own state before
+    that call, with `steps_rk4` RK4 steps per segment.  trajectories/s = nfev x M / wall."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "link", "goddard_flow_ref")
+    gold = os.path.join(ROOT, "tests", "golden", "goddard_flow.json")
+    if not (os.path.exists(exe) and os.path.exists(gold)):
+        return None
+    import tempfile
+    M = 6
+    threads = min(M, os.cpu_count() or 1)
+    init = [g for g in json.load(open(gold))["goddard_single_stage"] if g["stage"] == 2 and g["xtol"] == 1e-6][0]["init_z"]
+    # bound the sample: one evaluation at 1e4 steps is ~6 x 8 ms / threads; a continuation solve is ~190-400 evaluations
+    steps = steps_rk4 if target_seconds >= 4 else max(10, steps_rk4 // 10)
+    with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as f:
+        f.write(" ".join(repr(v) for v in init))
+        zfile = f.name
+    try:
+        t = time.perf_counter()
+        out = subprocess.run([exe, "stage", "2", str(steps), "1", "1e-6", zfile], capture_output=True, text=True,
+                             timeout=600, env=dict(os.environ, SOCP_FLOW_THREADS=str(threads)))
+        wall = time.perf_counter() - t
+    finally:
+        os.unlink(zfile)
+    recs = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    if not recs:
+        return None
+    r = recs[0]
+    traj = r["nfev"] * M
+    return {"value": traj / r["seconds"] * (steps / steps_rk4), "unit": "trajectories/s", "cores": threads, "kind": "reference",
+            "info": r["info"], "nfev": r["nfev"], "segments": M, "rk4_steps_sampled": steps,
+            "sample": "B0: reference shooting.cpp + per-call std::threads (numThread = %d) + this library's hybrd; testGoddard's "
+                      "KD 0 -> 310 continuation solve, n = 85, %d evaluations x %d segments of %d RK4 steps in %.2f s (process %.2f s)%s"
+                      % (threads, r["nfev"], M, steps, r["seconds"], wall,
+                         "" if steps == steps_rk4 else "; rate scaled to %d steps" % steps_rk4)}
+
+
+def timed_region(torch, dist, ctx, stream, dev, cdev, world, P, d_Z, d_rows, d_J, steps, warmup):
+    """W untimed steps, then exactly K steps between fences (sync + barrier + sync); returns (max-over-ranks seconds,
+    mean HIP-event ms of the dominant kernel on the stream it is launched on)."""
+    def step(events=None):
+        if events is not None:
+            events[0].record(stream)
+        ctx.fd_rows_dev(P, d_Z.data_ptr(), EPSFCN, d_rows.data_ptr())
+        if events is not None:
+            events[1].record(stream)
+        ctx.fd_diff_dev(P, d_Z.data_ptr(), EPSFCN, d_rows.data_ptr(), d_J.data_ptr())
+
+    def fence():
+        torch.cuda.synchronize(dev)          # this rank's own launches are done ...
+        if world > 1:
+            dist.barrier()                   # ... and so are everybody else's
+        torch.cuda.synchronize(dev)
+
+    for _ in range(warmup):
+        step()
+    fence()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step(evs[k])
+    fence()
+    elapsed = time.perf_counter() - t0
+    t_max = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+    if world > 1:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+    return float(t_max.item()), float(np.mean([a.elapsed_time(b) for a, b in evs]))
+
+
+def roofline_of(traj_per_launch, kernel_ms):
+    tflops = FLOP_PER_TRAJ * traj_per_launch / (kernel_ms * 1e-3) / 1e12
+    gbs = BYTES_PER_TRAJ * traj_per_launch / (kernel_ms * 1e-3) / 1e9
+    return tflops, gbs
+
+
+def recorded_traffic(P, variant, rk4_steps):
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(tpath):
+        try:
+            with open(tpath) as f:
+                entries = json.load(f)
+            for tj in (entries if isinstance(entries, list) else [entries]):
+                if tj.get("starts") == P and tj.get("variant") == variant and tj.get("rk4_steps") == rk4_steps:
+                    return tj.get("hbm_bytes_per_launch"), "profiles/traffic_latest.json <- " + str(tj.get("source", "rocprofv3 --pmc passes"))
+        except Exception:
+            pass
+    return None, None
+
+
+def parity_leg(torch, ctxs, dev, Z_host, rows_by_variant, rk4_steps, K):
+    """FD-batch rows of the first K starts against the CPU oracle (the checker; never inside a timed region)."""
+    from oracle import oracle as orc
+    o = orc.Oracle(orc.MODEL_GODDARD, step_nbr=rk4_steps, params=GODDARD_PARAMS)
+    mode_x = np.zeros((2, 7), dtype=np.int32)
+    mode_x[1, 3:7] = orc.FREE
+    X = np.zeros((2, 14))
+    X[0, :7] = X0_STATE
+    X[1, 0] = 1.01
+    prob = orc.Problem(7, [orc.FIXED, orc.FIXED], mode_x, np.array([0.0, TF]), X)
+    eps = np.sqrt(EPSFCN)
+    Zp = np.repeat(Z_host[:K], ROWS, axis=0)
+    for k in range(K):
+        for j in range(N_UNKNOWN):
+            h = eps * abs(Zp[k * ROWS + j + 1, j]) or eps
+            Zp[k * ROWS + j + 1, j] += h
+    t = time.perf_counter()
+    want = o.residual_batch(prob, Zp).reshape(K, ROWS, N_UNKNOWN)
+    sec = time.perf_counter() - t
+    out = {"rows_checked": K * ROWS, "starts_checked": K, "oracle_seconds": sec,
+           "metric": "max |row_gpu - row_cpu| / max(1, |row_cpu|_inf) over the FD-batch residual rows (1e4 RK4 steps each)",
+           "tolerance": {"exact": 0.0, "fast": 1e-8}}
+    for name, d_rows in rows_by_variant.items():
+        got = d_rows[:K].cpu().numpy()
+        scale = np.maximum(1.0, np.max(np.abs(want), axis=2, keepdims=True))
+        err = float(np.max(np.abs(got - want) / scale))
+        out[name] = {"max_rel_err": err, "bitwise_equal": bool(np.array_equal(got, want))}
+    out["pass"] = bool(out.get("fast", {"max_rel_err": 0})["max_rel_err"] <= 1e-8 and
+                       out.get("exact", {"max_rel_err": 0})["max_rel_err"] <= 1e-10)
+    return out
+
+
+def north_star_128(capi, device, rk4_steps, cpu_traj_per_s):
+    """Goddard, M = 9, FREE tf + one FREE interior time -> n = 128: one FD Jacobian at a fixed z through the
+    host-pointer entry point (PCIe and launch included), nodes along the p* trajectory integrated on the device."""
+    from socp_amd import sweep
+    out = {"unknowns": 128, "segments": 9, "rk4_steps": rk4_steps,
+           "trajectories_as_reference": 128 * 9, "note": "host-pointer socp_fd_jacobian, wall incl. PCIe + launch; "
+           "trajectories_as_reference = n x M integrations the reference's fdjac1 performs per Jacobian"}
+    for tag, variant in (("fast", capi.VARIANT_LANE_FAST), ("exact", capi.VARIANT_LANE_EXACT)):
+        ctx = capi.Context(capi.MODEL_GODDARD, device=device)
+        ctx.set_params(GODDARD_PARAMS)
+        ctx.set_step_number(rk4_steps)
+        ctx.set_variant(variant)
+        M, d, s = 9, 7, 14
+        mode_t = [capi.FIXED] + [capi.CONTINUOUS] * (M - 1) + [capi.FREE]
+        mode_t[M // 2] = capi.FREE
+        mode_x = np.full((M + 1, d), capi.CONTINUOUS, dtype=np.int32)
+        mode_x[0] = capi.FIXED
+        mode_x[M] = capi.FIXED
+        mode_x[M, 3:7] = capi.FREE
+        tn = np.linspace(0.0, sweep.TF, M + 1)
+        X = np.zeros((M + 1, s))
+        X[0] = np.concatenate([sweep.X0_STATE, sweep.PSTAR])
+        X[M, 0] = 1.01
+        X[1:M] = ctx.integrate_batch(np.zeros(M - 1), tn[1:M], np.repeat(X[0][None, :], M - 1, axis=0))
+        n = ctx.problem_set(mode_t, mode_x, tn, X)
+        z = np.concatenate([X[:M].ravel(), [tn[j] for j in range(M + 1) if mode_t[j] == capi.FREE]])
+        assert n == 128 and len(z) == n
+        F0 = ctx.residual(z)
+        res = {}
+        for dd, key in ((False, "full"), (True, "dedup")):
+            ctx.fd_jacobian(z, F0, dedup=dd)
+            c0 = ctx.counters()[0]
+            reps = 3
+            t = time.perf_counter()
+            for _ in range(reps):
+                J = ctx.fd_jacobian(z, F0, dedup=dd)
+            sec = (time.perf_counter() - t) / reps
+            res[key] = {"ms": 1e3 * sec, "trajectories_integrated": int((ctx.counters()[0] - c0) // reps), "finite": bool(np.isfinite(J).all())}
+        best = min(res["full"]["ms"], res["dedup"]["ms"])
+        res["jacobian_ms"] = best
+        res["trajectories_per_s"] = 128 * 9 / (best * 1e-3)          # the reference's count of integrations per Jacobian
+        if cpu_traj_per_s:
+            res["x_over_cpu_baseline"] = res["trajectories_per_s"] / cpu_traj_per_s
+        out[tag] = res
+        ctx.close()
+    return out
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--starts", type=int, default=13107,
-                    help="independent shooting problems per GPU; default: 15 x 13107 = 196 605 trajectories = 3072 "
-                         "wavefronts = 3 per SIMD (an exactly full chip); any size >= 4096 runs within 10 %% of it")
-    ap.add_argument("--rk4-steps", type=int, default=10000)
-    ap.add_argument("--variant", choices=["exact", "fast"], default="fast",
-                    help="fast: restructured arithmetic (<= 1e-8 vs the reference order after 1e4 steps, converged "
-                         "solutions within 1e-8: tests/test_gpu_parity.py, test_host_flow.py); exact: reference operation order")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="0 disables the CPU baseline leg")
-    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
-                    help="gloo + --share-device0: rehearse the multi-rank path on a one-GPU box (collectives on CPU tensors)")
-    ap.add_argument("--share-device0", action="store_true", help="rehearsal only: every rank uses cuda:0")
-    ap.add_argument("--single-problem", action="store_true",
-                    help="also time ONE problem (15 trajectories) per launch: the latency-bound case")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))            # nothing above has touched the GPU (torch is not even imported yet)
 
     import torch
     import torch.distributed as dist
+    from socp_amd import capi
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started %d ranks; reporting n_gpus = %d\n" % (args.gpus, world, world))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -164,39 +402,9 @@ def main():
     d_Z = torch.from_numpy(Z_host).to(dev)
     d_rows = torch.empty((P, ROWS, N_UNKNOWN), dtype=torch.float64, device=dev)
     d_J = torch.empty((P, N_UNKNOWN, N_UNKNOWN), dtype=torch.float64, device=dev)
-    epsfcn = 1e-15
 
-    def step(events=None):
-        if events is not None:
-            events[0].record(stream)
-        ctx.fd_rows_dev(P, d_Z.data_ptr(), epsfcn, d_rows.data_ptr())
-        if events is not None:
-            events[1].record(stream)
-        ctx.fd_diff_dev(P, d_Z.data_ptr(), epsfcn, d_rows.data_ptr(), d_J.data_ptr())
-
-    def fence():
-        torch.cuda.synchronize(dev)          # this rank's own launches are done ...
-        if world > 1:
-            dist.barrier()                   # ... and so are everybody else's
-        torch.cuda.synchronize(dev)
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(evs[k])
-    fence()
-    elapsed = time.perf_counter() - t0
-
-    t_max = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-    if world > 1:
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-    elapsed_max = float(t_max.item())
-
+    elapsed_max, kernel_ms = timed_region(torch, dist, ctx, stream, dev, cdev, world, P, d_Z, d_rows, d_J, args.steps, args.warmup)
     traj_per_step_rank = P * ROWS
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
 
     # result record of this rank (checksum of the Jacobians, finite count): the only exchange of the
     # multi-start sweep is this small gather of per-rank records -- after the timed region.
@@ -210,22 +418,18 @@ def main():
     else:
         recs = [rec.tolist()]
 
+    status = 0
     if rank == 0:
+        ranks_seen = sorted(int(r[0]) for r in recs)
         total_traj = traj_per_step_rank * world * args.steps
         value = total_traj / elapsed_max
-        tflops = FLOP_PER_TRAJ * traj_per_step_rank / (kernel_ms * 1e-3) / 1e12
-        gbs = BYTES_PER_TRAJ * traj_per_step_rank / (kernel_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
-            try:
-                with open(tpath) as f:
-                    entries = json.load(f)
-                for tj in (entries if isinstance(entries, list) else [entries]):
-                    if tj.get("starts") == P and tj.get("variant") == args.variant and tj.get("rk4_steps") == args.rk4_steps:
-                        traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        tflops, gbs = roofline_of(traj_per_step_rank, kernel_ms)
+        traffic, traffic_source = recorded_traffic(P, args.variant, args.rk4_steps)
+        smooth = GODDARD_PARAMS[6] > 0
+        # VGPR budget -> waves per SIMD the launcher may use: fast smooth law 156 VGPRs (3), fast general law 252-254 (2),
+        # exact 248 (2) -- socp_amd/csrc/launch.hpp picks min(that, ceil(waves / 1024))
+        wpe_max = 3 if (args.variant == "fast" and smooth) else 2
+        waves = (traj_per_step_rank + 63) // 64
         out = {
             "metric": "trajectories integrated/sec (Goddard, 14-dim state+costate, 1e4 RK4 steps)",
             "value": value, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -234,43 +438,82 @@ def main():
             "config": {"workload": "goddard_single_shooting_n14_fd_jacobian_batch (BASELINE configs[1])",
                        "starts_per_gpu": P, "trajectories_per_step_per_gpu": traj_per_step_rank,
                        "rk4_steps": args.rk4_steps, "unknowns": N_UNKNOWN, "variant": args.variant,
-                       "costate_eps": 1e-3},
+                       "costate_eps": 1e-3,
+                       "parallelism": "independent problems per GPU (replicas of the workload with rank-seeded starts); "
+                                      "no data-path collective, one gather of result records after the timed region"},
+            "ranks_reported": len(ranks_seen),
             "roofline": {"bound": "valu_fp64", "achieved": tflops, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tflops / PEAK_FP64_TFLOPS, "traffic": traffic,
+                         "frac": tflops / PEAK_FP64_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "fdrows_lane_kernel", "kernel_ms": kernel_ms,
                          "flop_per_trajectory": FLOP_PER_TRAJ,
                          "hbm": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                  "frac": gbs / PEAK_HBM_GBS, "bytes_per_trajectory": BYTES_PER_TRAJ}},
-            # Newton-level rate and wave occupancy beside the trajectory rate
             # Newton-level rates: with M = 1 a residual evaluation is one trajectory, and a forward-difference
             # Jacobian is the n + 1 = 15 evaluations of one start (single shooting has nothing to dedup)
             "jacobians_per_s": P * world * args.steps / elapsed_max,
             "residual_evaluations_per_s": value,
-            "occupancy": {"waves_per_launch": (traj_per_step_rank + 63) // 64,
-                          "waves_per_simd_cap": min(3 if args.variant == "fast" else 2, max(1, -(-((traj_per_step_rank + 63) // 64) // 1024))),
-                          "simds": 1024},
+            "occupancy": {"waves_per_launch": waves, "waves_per_simd_cap": min(wpe_max, max(1, -(-waves // 1024))), "simds": 1024},
             "finite_jacobians": [int(r[1]) for r in recs],
         }
-        if world == 1 and args.single_problem:
-            # latency-bound case: one problem (15 trajectories) per launch
-            one = torch.from_numpy(Z_host[:1].copy()).to(dev)
-            ctx.fd_rows_dev(1, one.data_ptr(), epsfcn, d_rows.data_ptr())
-            torch.cuda.synchronize(dev)
-            reps = 3
-            t1 = time.perf_counter()
-            for _ in range(reps):
-                ctx.fd_rows_dev(1, one.data_ptr(), epsfcn, d_rows.data_ptr())
-            torch.cuda.synchronize(dev)
-            ms = 1e3 * (time.perf_counter() - t1) / reps
-            out["single_problem"] = {"trajectories": ROWS, "ms": ms, "value": ROWS / (ms * 1e-3), "unit": "trajectories/s"}
+        if ranks_seen != list(range(world)):
+            sys.stderr.write("bench.py: records of ranks %s, expected 0..%d\n" % (ranks_seen, world - 1))
+            status = 1
+        if world == 1 and not args.lean:
+            rows_by_variant = {args.variant: d_rows}
+            # ---- the other flavour, same workload, its own timed region --------------------------------------------
+            other = "exact" if args.variant == "fast" else "fast"
+            ctx2 = setup_context(local_rank, args.rk4_steps, other)
+            ctx2.set_stream(stream.cuda_stream)
+            d_rows2 = torch.empty_like(d_rows)
+            k2 = max(1, min(args.steps, 5))
+            e2, kms2 = timed_region(torch, dist, ctx2, stream, dev, cdev, 1, P, d_Z, d_rows2, d_J, k2, 1)
+            tf2, _ = roofline_of(traj_per_step_rank, kms2)
+            out[other] = {"value": traj_per_step_rank * k2 / e2, "unit": "trajectories/s", "steps": k2, "warmup": 1,
+                          "ms_per_step": 1e3 * e2 / k2, "kernel_ms": kms2,
+                          "roofline_frac": tf2 / PEAK_FP64_TFLOPS, "achieved_tflops": tf2,
+                          "note": ("reference operation order, bit-identical to the CPU path; the default of the C-ABI and of the "
+                                   "C++ mirror (SOCP_VARIANT_AUTO)") if other == "exact" else "restructured arithmetic, <= 1e-8"}
+            rows_by_variant[other] = d_rows2
+            # ---- in-run parity of both flavours against the oracle -------------------------------------------------
+            try:
+                out["parity"] = parity_leg(torch, None, dev, Z_host, rows_by_variant, args.rk4_steps, K=min(P, 16))
+                if not out["parity"]["pass"]:
+                    status = 1
+            except Exception as exc:       # the checker is absent: say so, do not guess
+                out["parity"] = {"error": "oracle unavailable: %s" % exc}
+            # ---- latency-bound case: one problem (15 trajectories) per launch --------------------------------------
+            single = {}
+            for name, c in ((args.variant, ctx), (other, ctx2)):
+                one = torch.from_numpy(Z_host[:1].copy()).to(dev)
+                c.fd_rows_dev(1, one.data_ptr(), EPSFCN, d_rows.data_ptr())
+                torch.cuda.synchronize(dev)
+                reps = 3
+                t1 = time.perf_counter()
+                for _ in range(reps):
+                    c.fd_rows_dev(1, one.data_ptr(), EPSFCN, d_rows.data_ptr())
+                torch.cuda.synchronize(dev)
+                ms = 1e3 * (time.perf_counter() - t1) / reps
+                single[name] = {"ms": ms, "value": ROWS / (ms * 1e-3)}
+            out["single_problem"] = {"trajectories": ROWS, "unit": "trajectories/s", **single,
+                                     "note": "latency-bound: one wave on one SIMD, 4e4 serially dependent RHS evaluations"}
+            ctx2.close()
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(args.rk4_steps, Z_host, args.cpu_seconds)
+            b0 = cpu_baseline_b0(args.rk4_steps, args.cpu_seconds)
+            if b0:
+                out["cpu_baseline"]["b0"] = b0
+        if world == 1 and not args.lean:
+            cpu_v = out.get("cpu_baseline", {}).get("value")
+            out["north_star_128"] = north_star_128(capi, local_rank, args.rk4_steps, cpu_v)
+            if cpu_v:
+                out["north_star_128"]["cpu_baseline_value"] = cpu_v
         print(json.dumps(out), flush=True)
 
     ctx.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    sys.exit(status)
 
 
 if __name__ == "__main__":

@@ -10,15 +10,20 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_bench_line_contract():
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--starts", "4096",
-                          "--cpu-seconds", "2"], capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
+def _line(out):
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-2000:])
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, lines
-    d = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+def test_bench_line_contract():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--starts", "4096",
+                          "--cpu-seconds", "2"], capture_output=True, text=True, timeout=900)
+    d = _line(out)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "exact", "parity", "single_problem",
+                "north_star_128"):
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["dtype"] == "f64"
     assert d["vs_baseline"] is None and d["higher_is_better"] is True and d["data"] == "synthetic"
@@ -26,10 +31,37 @@ def test_bench_line_contract():
     per_step = d["config"]["trajectories_per_step_per_gpu"]
     assert abs(d["value"] - per_step / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
     r = d["roofline"]
-    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source"):
         assert key in r, key
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] < 1.2
     assert r["kernel_ms"] <= d["ms_per_step"] * 1.05                 # the kernel is (nearly all of) the step
     assert r["hbm"]["bound"] == "hbm" and r["hbm"]["peak"] == 8000.0
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    # the bit-identical flavour beside the headline one, and the in-run parity of both against the oracle
+    assert d["config"]["variant"] == "fast" and d["exact"]["value"] > 0 and 0 < d["exact"]["roofline_frac"] < d["roofline"]["frac"]
+    p = d["parity"]
+    assert p["pass"] is True and p["rows_checked"] >= 15
+    assert p["fast"]["max_rel_err"] <= 1e-8
+    assert p["exact"]["max_rel_err"] <= 1e-10
+    assert set(d["single_problem"]) >= {"fast", "exact", "trajectories"}
+    ns = d["north_star_128"]
+    assert ns["unknowns"] == 128 and ns["fast"]["full"]["trajectories_integrated"] == 128 * 9
+    assert ns["fast"]["dedup"]["trajectories_integrated"] < ns["fast"]["full"]["trajectories_integrated"]
+    assert ns["fast"]["full"]["finite"] and ns["exact"]["full"]["finite"]
+    if "b0" in c:
+        assert c["b0"]["info"] == 1 and c["b0"]["value"] > 0
+
+
+def test_gpus_2_really_runs_two_ranks():
+    """`python bench.py --gpus 2` (no launcher): the parent starts two ranks; here both share device 0 and the collectives
+    run over gloo (a one-GPU box), the code path is otherwise the N > 1 path of the driver."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-device0",
+                          "--steps", "2", "--warmup", "1", "--starts", "1024", "--rk4-steps", "1000"],
+                         capture_output=True, text=True, timeout=900)
+    d = _line(out)
+    assert d["n_gpus"] == 2 and d["ranks_reported"] == 2 and len(d["finite_jacobians"]) == 2
+    assert d["finite_jacobians"] == [1024, 1024]
+    assert d["config"]["trajectories_per_step_per_gpu"] == 1024 * 15
+    assert abs(d["value"] - 2 * 1024 * 15 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    assert "cpu_baseline" not in d and "exact" not in d               # N = 1 extras only
