@@ -96,6 +96,7 @@ int socp_ctx_get_stream(const socp_ctx *ctx, void **hip_stream);
 int socp_ctx_synchronize(socp_ctx *ctx);
 int socp_ctx_dims(const socp_ctx *ctx, int *dim, int *state_len, int *state_len_jac);
 int socp_ctx_control_dim(const socp_ctx *ctx);
+int socp_ctx_device(const socp_ctx *ctx);            /* HIP device index the context lives on (< 0: error) */
 
 /* counters since creation: trajectories integrated, kernel launches */
 int socp_ctx_counters(const socp_ctx *ctx, long long *trajectories, long long *launches);
@@ -174,7 +175,8 @@ int socp_fd_diff_dev(socp_ctx *ctx, int np, const double *d_Z, double epsfcn, co
                      double *d_Fjac);
 
 /* replaces: shooting::ShootingFunctionJacobian (shooting.cpp:996-1130), variational Jacobian
- * for models with modelOrder == 1; fjac column-major as handed to hybrj (shooting.cpp:889-893). */
+ * for models with modelOrder == 1; fjac column-major as handed to hybrj (shooting.cpp:889-893).
+ * The variational state is integrated with fixed-step RK4 only: SOCP_ERR_UNSUPPORTED under SOCP_INT_DOPRI5. */
 int socp_var_jacobian(socp_ctx *ctx, const double *z, double *fjac);
 
 #ifdef __cplusplus

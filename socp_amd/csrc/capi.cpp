@@ -320,6 +320,7 @@ int socp_ctx_dims(const socp_ctx *c, int *dim, int *state_len, int *state_len_ja
 }
 
 int socp_ctx_control_dim(const socp_ctx *c) { return c ? c->nu : SOCP_ERR_ARG; }
+int socp_ctx_device(const socp_ctx *c) { return c ? c->device : SOCP_ERR_ARG; }
 
 int socp_ctx_counters(const socp_ctx *c, long long *trajectories, long long *launches)
 {
@@ -394,6 +395,8 @@ int socp_integrate_dense_aux(socp_ctx *c, double t0, double tf, const double *sw
 {
     if (!c) return SOCP_ERR_ARG;
     if (!X0 || !dense || !times || !rows || cap < 1) return fail(c, SOCP_ERR_ARG, "integrate_dense: bad argument");
+    if (c->P.integrator != SOCP_INT_RK4)
+        return fail(c, SOCP_ERR_UNSUPPORTED, "integrate_dense: dense output exists for the fixed-step integrator only");
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t S = c->S;
     HIP_TRY(c, c->s_in.reserve(sizeof(double) * S));
@@ -744,6 +747,8 @@ int socp_var_jacobian(socp_ctx *c, const double *z, double *fjac)
     if (!z || !fjac) return fail(c, SOCP_ERR_ARG, "var_jacobian: null argument");
     if (c->model_id != SOCP_MODEL_DOUBLE_INTEGRATOR)
         return fail(c, SOCP_ERR_UNSUPPORTED, "var_jacobian: this model has no variational equations (modelOrder 0)");
+    if (c->P.integrator != SOCP_INT_RK4)
+        return fail(c, SOCP_ERR_UNSUPPORTED, "var_jacobian: the variational state is integrated with fixed-step RK4 only");
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t n = c->n, M = c->M, L = (size_t)(c->S + 1) * c->S;
     HIP_TRY(c, c->s_in.reserve(sizeof(double) * n));

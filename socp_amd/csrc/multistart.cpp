@@ -49,6 +49,15 @@ extern "C" int socp_multistart_solve(socp_ctx *ctx, int P, const double *Z0, dou
     const int n = socp_problem_num_param(ctx);
     if (n <= 0) return SOCP_ERR_ARG;
     if (P == 0) return SOCP_OK;
+    // every allocation, copy and stream below must live on the context's device, whatever the calling thread's
+    // current device is (a fresh std::thread starts on device 0); the caller's device is restored on exit
+    struct DeviceGuard {
+        int prev = -1;
+        bool ok = false;
+        explicit DeviceGuard(int dev) { ok = hipGetDevice(&prev) == hipSuccess && hipSetDevice(dev) == hipSuccess; }
+        ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    } device_guard(socp_ctx_device(ctx));
+    if (!device_guard.ok) return SOCP_ERR_HIP;
 
     const std::chrono::steady_clock::time_point t_begin = std::chrono::steady_clock::now();
     // host threads for the per-start work (state-machine advances, workspace set-up, Jacobian scatter): all cores

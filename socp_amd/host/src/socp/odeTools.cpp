@@ -82,11 +82,12 @@ void odeTools::integrate(modelStruct const &_model, odeVector &X, double const &
     if (AdaptiveIntegrator()) throw std::runtime_error("odeTools::integrate: trace replay is available with the fixed-step integrator only");
     socp_ctx *ctx = m->DeviceContext();
     const int S = (int)X.size();
-    const int cap = m->DeviceStepNumber() + 2;
+    const int cap = m->DeviceStepNumber() + 10;      // the device loop stops after at most stepNbr + 8 steps (integrator.hpp)
     std::vector<double> dense((size_t)cap * S), times(cap);
     int rows = 0;
     if (socp_integrate_dense(ctx, t0, tf, nullptr, X.data(), dense.data(), times.data(), cap, &rows) != SOCP_OK)
         throw std::runtime_error(std::string("odeTools::integrate: ") + socp_last_error(ctx));
+    if (rows > cap) throw std::runtime_error("odeTools::integrate: the device reported more rows than the step guard allows");
     for (int k = 0; k < rows; k++) {
         odeVector row(dense.begin() + (size_t)k * S, dense.begin() + (size_t)(k + 1) * S);
         _observer(row, times[k]);

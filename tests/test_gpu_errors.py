@@ -80,3 +80,51 @@ def test_stalled_time_loop_terminates():
     Xf = ctx.integrate_batch(t0, tf, X0)
     assert Xf.shape == (1, 14)
     ctx.close()
+
+
+def test_adaptive_integrator_is_rejected_where_only_fixed_step_exists():
+    """dense output and the variational Jacobian run fixed-step RK4 only; with SOCP_INT_DOPRI5 selected they
+    must say so instead of returning fixed-step numbers with SOCP_OK."""
+    from socp_amd import capi
+    ctx = capi.Context(capi.MODEL_GODDARD)
+    ctx.set_param("mu2", 1.0)
+    X0 = np.array([0.999949994, 1e-4, 0.01, 1e-10, 1e-10, 1e-10, 1.0, -8.12, 7.8e-3, 0.78, -0.48, 5.7e-4, 5.7e-2, 0.0996])
+    rows, _ = ctx.integrate_dense(0.0, 0.01, X0)
+    assert len(rows) == 11
+    ctx.set_integrator(capi.INT_DOPRI5, 1e-8)
+    with pytest.raises(capi.SocpError) as e:
+        ctx.integrate_dense(0.0, 0.01, X0)
+    assert e.value.code == capi.ERR_UNSUPPORTED
+    ctx.close()
+    di = capi.Context(capi.MODEL_DOUBLE_INTEGRATOR)
+    mx = np.zeros((2, 6), dtype=np.int32)
+    n = di.problem_set([capi.FIXED, capi.FIXED], mx, [0.0, 1.0], np.zeros((2, 12)))
+    z = np.full(n, 0.01)
+    J = di.var_jacobian(z)
+    assert J.shape == (n, n) and np.isfinite(J).all()
+    di.set_integrator(capi.INT_DOPRI5, 1e-8)
+    with pytest.raises(capi.SocpError) as e:
+        di.var_jacobian(z)
+    assert e.value.code == capi.ERR_UNSUPPORTED
+    di.close()
+
+
+def test_multistart_from_a_fresh_thread_uses_the_context_device():
+    """socp_multistart_solve allocates staging buffers and a second stream; it must do so on the CONTEXT's device
+    whatever the calling thread's current device is.  One GPU here, so what can be checked is that a call from a new
+    thread (which starts on device 0 with no prior hipSetDevice) works and leaves the caller's device alone; the context
+    reports the device it lives on."""
+    import threading
+    from socp_amd import capi, sweep
+    ctx = capi.Context(capi.MODEL_GODDARD, device=0)
+    assert capi.lib().socp_ctx_device(ctx.h) == 0
+    ctx.set_params(sweep.GODDARD_PARAMS)
+    ctx.set_step_number(50)
+    sweep.goddard_single_shooting_problem(ctx)
+    Z0 = sweep.goddard_starts(8, 1e-3)
+    ref = ctx.multistart_solve(Z0, xtol=1e-8)
+    got = {}
+    th = threading.Thread(target=lambda: got.update(ctx.multistart_solve(Z0, xtol=1e-8)))
+    th.start(); th.join()
+    assert np.array_equal(got["z"], ref["z"]) and np.array_equal(got["info"], ref["info"])
+    ctx.close()
