@@ -226,6 +226,16 @@ class Oracle:
         self.lib.orc_compute_timeline(C.byref(self.m), C.byref(ps), _d(z), _d(tl))
         return tl
 
+    def residual_block(self, which, t, X, other, mode, is_jac=0):
+        """One default residual block of model.hpp:90-328 (BLOCK_* below), value or Jacobian form."""
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        other = np.ascontiguousarray(other, dtype=np.float64)
+        mode = np.ascontiguousarray(mode, dtype=np.int32)
+        out = np.empty(1024)
+        k = self.lib.orc_residual_block(C.byref(self.m), int(which), C.c_double(t), _d(X), _d(other),
+                                        mode.ctypes.data_as(C.POINTER(C.c_int)), int(is_jac), _d(out))
+        return out[:k].copy()
+
     def residual(self, prob, z):
         z = np.ascontiguousarray(z, dtype=np.float64)
         assert z.shape == (prob.n,)
@@ -259,6 +269,9 @@ class Oracle:
         ps = prob.c_struct()
         self.lib.orc_fdjac1(C.byref(self.m), C.byref(ps), _d(z), _d(fvec), C.c_double(epsfcn), _d(Jcm))
         return Jcm.T.copy()
+
+
+BLOCK_INITIAL, BLOCK_INITIAL_H, BLOCK_FINAL, BLOCK_FINAL_H, BLOCK_SWITCHING_TIMES = 0, 1, 2, 3, 4
 
 
 def have_ref():
@@ -324,6 +337,17 @@ class Ref:
         X = np.ascontiguousarray(X, dtype=np.float64)
         out = np.empty(64)
         k = self.lib.ref_model_hamiltonian(self.h, C.c_double(t), _d(X), len(X), int(is_jac), _d(out), 64)
+        return out[:k].copy()
+
+    def residual_block(self, which, t, X, other, mode, is_jac=0):
+        """model::Initial[H]Function / Final[H]Function / SwitchingTimesFunction of the reference object."""
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        other = np.ascontiguousarray(other, dtype=np.float64)
+        mode = np.ascontiguousarray(mode, dtype=np.int32)
+        out = np.empty(1024)
+        k = self.lib.ref_model_block(self.h, int(which), C.c_double(t), _d(X), len(X), _d(other), len(other),
+                                     mode.ctypes.data_as(C.POINTER(C.c_int)), int(is_jac), _d(out), 1024)
+        assert k >= 0
         return out[:k].copy()
 
     def rk4_step(self, t, X, step, is_jac=0):

@@ -156,6 +156,39 @@ void ref_model_final_function(void *h, double tf, const double *Xtf, int len, co
     std::memcpy(out, f.data(), sizeof(double) * f.size());
 }
 
+/* Default residual blocks of the reference's header-only model.hpp (:90-328), both forms (rows a16 of SURVEY 8a):
+ * which = 0 InitialFunction, 1 InitialHFunction, 2 FinalFunction, 3 FinalHFunction (X = state at the boundary, len 2d or
+ * (2d+1)*2d; other = desired boundary state, 2d; mode = d state modes), 4 SwitchingTimesFunction (X, other = states
+ * before / after the free interior time, same length; mode unused; goddard overrides it, goddard.cpp:343-370).
+ * Returns the number of values written (the block's own size), -1 if cap is too small. */
+int ref_model_block(void *h, int which, double t, const double *X, int len, const double *other, int other_len,
+                    const int *mode, int is_jac, double *out, int cap)
+{
+    model *m = static_cast<RefModel *>(h)->m;
+    const int d = m->GetDim();
+    if (which == 4) {
+        model::mstate f = m->SwitchingTimesFunction(t, to_vec(X, len), to_vec(other, other_len), is_jac);
+        if ((int)f.size() > cap) return -1;
+        std::memcpy(out, f.data(), sizeof(double) * f.size());
+        return (int)f.size();
+    }
+    const bool with_h = (which == 1 || which == 3);
+    const int count = is_jac ? (with_h ? (d + 1) * (2 * d + 1) : d * 2 * d) : (with_h ? d + 1 : d);
+    if (count > cap) return -1;
+    std::vector<int> md(mode, mode + d);
+    std::vector<real> f(count, 0.0);
+    const model::mstate Xv = to_vec(X, len), Ov = to_vec(other, other_len);
+    switch (which) {
+    case 0: m->InitialFunction(t, Xv, Ov, md, f, is_jac); break;
+    case 1: m->InitialHFunction(t, Xv, Ov, md, f, is_jac); break;
+    case 2: m->FinalFunction(t, Xv, Ov, md, f, is_jac); break;
+    case 3: m->FinalHFunction(t, Xv, Ov, md, f, is_jac); break;
+    default: return -2;
+    }
+    std::memcpy(out, f.data(), sizeof(double) * count);
+    return count;
+}
+
 /*
  * CPU baseline B1: B Goddard trajectories through the reference's model::ComputeTraj,
  * split over `threads` std::threads, one goddard object per thread.  Returns seconds.

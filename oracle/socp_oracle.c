@@ -583,6 +583,28 @@ static void switching_times_function_jac(const orc_model *m, double t, const dou
     f[4 * d] += dH[s] - dHp[s];
 }
 
+/* one residual block by name (model.hpp:90-328); the assembly below uses the same static pieces */
+int orc_residual_block(const orc_model *m, int which, double t, const double *X, const double *other,
+                       const int *mode, int is_jac, double *out)
+{
+    const int d = m->dim, s = 2 * d;
+    if (which == 4) {
+        if (!is_jac) { out[0] = switching_times_function(m, t, X, other); return 1; }
+        if (m->model_id == ORC_MODEL_GODDARD) { orc_hamiltonian(m, t, X, 1, out); return 1; }   /* goddard.cpp:369: H(t, X, isJac), and its Hamiltonian ignores isJac (:256-295) */
+        switching_times_function_jac(m, t, X, other, out);
+        return 4 * d + 1;
+    }
+    const int with_h = (which == 1 || which == 3);
+    if (!is_jac) {
+        boundary_rows(d, X, other, mode, out);
+        if (with_h) orc_hamiltonian(m, t, X, 0, &out[d]);
+        return with_h ? d + 1 : d;
+    }
+    if (with_h) { boundary_h_rows_jac(m, t, X, mode, out); return (d + 1) * (s + 1); }
+    boundary_rows_jac(d, X, mode, out);
+    return d * s;
+}
+
 /* shooting.cpp:1511-1576, isJac == 0.  FREE state mode at an interior node defers to
  * model::SwitchingStateFunction, a no-op by default (model.hpp:339-341): rows untouched. */
 static void multiple_shooting_rows(int d, const double *X, const double *Xp, const double *Xd,

@@ -106,6 +106,14 @@ void orc_interceptor_final_rows(const orc_model *m, const double *Xtf, const dou
 void orc_interceptor_init_analytical(const orc_model *m, double ti, double *Xi, double tf, const double *Xf);
 
 /* ---- shooting layer ---- */
+/* The default residual blocks of model.hpp:90-328 one at a time, in both forms, so that each can be
+ * pinned against the reference's own objects (oracle/ref_driver.cpp: ref_model_block; tests/test_oracle.py):
+ * which = 0 InitialFunction, 1 InitialHFunction, 2 FinalFunction, 3 FinalHFunction, 4 SwitchingTimesFunction (the
+ * model's own, i.e. goddard.cpp:343-370 for Goddard).  X: state at the node (2d, or (2d+1)*2d when is_jac);
+ * other: desired boundary state (2d) resp. the state after the switching time (same length as X); mode: d state modes.
+ * Returns the number of values written. */
+int  orc_residual_block(const orc_model *m, int which, double t, const double *X, const double *other,
+                        const int *mode, int is_jac, double *out);
 int  orc_num_param(const orc_problem *p);
 void orc_compute_timeline(orc_model *m, const orc_problem *p, const double *z, double *timeline);
 void orc_shooting_function(orc_model *m, const orc_problem *p, const double *z, double *fvec);

@@ -240,3 +240,70 @@ def test_dopri5_single_step_equals_scipy_tableau_step(built):
     K = np.empty((RK45.n_stages + 1, 14))
     y_new, _ = rk_step(fun, 0.0, X0, fun(0.0, X0), h, RK45.A, RK45.B, RK45.C, K)
     assert np.max(np.abs(X - y_new) / np.maximum(1e-3, np.abs(y_new))) < 5e-15
+
+
+# ---- default residual blocks of model.hpp, pinned to the reference's own objects -----------------
+BLOCKS = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_blocks.npz"))
+BLOCK_NAMES = ["InitialFunction", "InitialHFunction", "FinalFunction", "FinalHFunction", "SwitchingTimesFunction"]
+
+
+def _block_models():
+    from oracle.oracle import MODEL_COVID
+    g = Oracle(MODEL_GODDARD)
+    g.set_param("mu2", 0.2)
+    c = Oracle(MODEL_COVID)
+    c.set_params([3.4, 14, 5, 1, 0.1, 1, -10, 20])
+    return {"g": g, "d": Oracle(MODEL_DINT), "c": c}
+
+
+@pytest.mark.parametrize("which", range(5))
+def test_residual_blocks_value_form_equal_reference_bit_for_bit(built, which):
+    """model.hpp:90-122,133-147,196-228,239-253,299-304 (+ goddard.cpp:343-370), isJac = 0: the fixtures were produced by
+    the reference's header-only model.hpp through oracle/ref_driver.cpp: ref_model_block."""
+    for tag, o in _block_models().items():
+        other = BLOCKS[tag + ("_Xp" if which == 4 else "_Xd")]
+        want = BLOCKS["%s_block%d" % (tag, which)]
+        for k in range(len(want)):
+            got = o.residual_block(which, BLOCKS[tag + "_t"][k], BLOCKS[tag + "_X"][k], other[k], BLOCKS[tag + "_mode"][k], 0)
+            assert got.shape == want[k].shape, (tag, BLOCK_NAMES[which])
+            if tag == "d":
+                assert np.array_equal(got, want[k]), (tag, BLOCK_NAMES[which], k)      # IEEE + - * only
+            else:
+                assert same(got, want[k]), (tag, BLOCK_NAMES[which], k)                # exp in the Hamiltonian (goddard)
+    # both mode branches are in the fixture: case 0 all FIXED, case 1 all FREE (transversality rows)
+    assert np.all(BLOCKS["d_mode"][0] == FIXED) and np.all(BLOCKS["d_mode"][1] == FREE)
+
+
+@pytest.mark.parametrize("which", range(5))
+def test_residual_blocks_jacobian_form_equal_reference_bit_for_bit(built, which):
+    """isJac = 1 forms (model.hpp:104-120,149-183,212-226,255-288,305-326) on the model that has variational equations."""
+    o = Oracle(MODEL_DINT)
+    other = BLOCKS["d_Xpaug"] if which == 4 else BLOCKS["d_Xd"]
+    want = BLOCKS["d_block%d_jac" % which]
+    for k in range(len(want)):
+        got = o.residual_block(which, BLOCKS["d_t"][k], BLOCKS["d_Xaug"][k], other[k], BLOCKS["d_mode"][k], 1)
+        assert got.shape == want[k].shape == ({0: 72, 1: 91, 2: 72, 3: 91, 4: 25}[which],)
+        assert np.array_equal(got, want[k]), (BLOCK_NAMES[which], k)
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built")
+def test_residual_blocks_live_reference_agreement(built):
+    """Same comparison against the reference objects themselves (fresh random inputs), when oracle/_ref is present."""
+    from oracle.oracle import MODEL_COVID
+    rng = np.random.default_rng(7)
+    pairs = [(Oracle(MODEL_GODDARD), Ref(MODEL_GODDARD), 7), (Oracle(MODEL_DINT), Ref(MODEL_DINT, model_order=1), 6),
+             (Oracle(MODEL_COVID), Ref(MODEL_COVID), 4)]
+    for o, r, d in pairs:
+        for _ in range(8):
+            X = rng.uniform(0.2, 1.5, 2 * d)
+            other = rng.uniform(0.2, 1.5, 2 * d)
+            mode = rng.integers(0, 2, d).astype(np.int32)
+            t = float(rng.uniform(0, 0.1))
+            for which in range(5):
+                assert same(o.residual_block(which, t, X, other, mode, 0), r.residual_block(which, t, X, other, mode, 0))
+            if d == 6:
+                Xa = np.concatenate([X, rng.uniform(-1, 1, 144)])
+                Oa = np.concatenate([other, rng.uniform(-1, 1, 144)])
+                for which in range(5):
+                    oth = Oa if which == 4 else other
+                    assert np.array_equal(o.residual_block(which, t, Xa, oth, mode, 1), r.residual_block(which, t, Xa, oth, mode, 1))
