@@ -458,6 +458,32 @@ void orc_interceptor_compute_traj_obs(orc_model *m, double t0, const double *X0,
     memcpy(Xf, X, sizeof(X));
 }
 
+static int set_chart_hook(orc_model *m, double t, double *X)
+{
+    (void)t;
+    const int before = m->chart;
+    set_chart(m, X);
+    return m->chart != before;
+}
+
+void orc_interceptor_compute_traj_adaptive(orc_model *m, double t0, const double *X0, double tf, double tol, double *Xf)
+{
+    double X[12];
+    memcpy(X, X0, sizeof(X));
+    m->chart = 1;
+    const double t1 = m->p[IP_PROP] / m->p[IP_Q];
+    const int two = t0 < t1 && tf > t1;
+    m->stage = t0 < t1 ? 1 : 0;
+    for (int ph = 0; ph < (two ? 2 : 1); ph++) {
+        const double ta = ph == 0 ? t0 : t1;
+        const double tb = (two && ph == 0) ? t1 : tf;
+        if (ph == 1) m->stage = 0;
+        orc_integrate_dopri5_hook(m, X, ta, tb, (tb - ta) / m->step_nbr, tol, 0, set_chart_hook);
+    }
+    if (m->chart == 2) orc_interceptor_chart21(m, X, X);
+    memcpy(Xf, X, sizeof(X));
+}
+
 void orc_interceptor_compute_traj(orc_model *m, double t0, const double *X0, double tf, double *Xf)
 {
     orc_interceptor_compute_traj_obs(m, t0, X0, tf, Xf, 0, 0);

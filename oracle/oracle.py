@@ -42,7 +42,7 @@ def build(ref=True):
 class _OrcModel(C.Structure):
     _fields_ = [("model_id", C.c_int), ("dim", C.c_int), ("step_nbr", C.c_int),
                 ("p", C.c_double * 24), ("nsw", C.c_int), ("sw", C.c_double * 64),
-                ("chart", C.c_int), ("stage", C.c_int)]
+                ("chart", C.c_int), ("stage", C.c_int), ("integrator", C.c_int), ("tol", C.c_double)]
 
 
 class _OrcProblem(C.Structure):
@@ -93,6 +93,11 @@ class Oracle:
 
     def params(self):
         return np.array(self.m.p[:], dtype=np.float64)
+
+    def set_integrator(self, kind, tol=1e-8):
+        """0: fixed-step RK4; 1: adaptive Dormand-Prince for every trajectory the residual / FD Jacobian integrates."""
+        self.m.integrator = int(kind)
+        self.m.tol = float(tol)
 
     def set_switching(self, sw):
         self.m.nsw = len(sw)

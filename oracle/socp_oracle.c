@@ -416,22 +416,30 @@ static int dopri5_try_step(const orc_model *m, int n, const double *x, const dou
     return 1;
 }
 
-long orc_integrate_dopri5(const orc_model *m, double *X, double t0, double tf, double dt, double tol, long *rejected)
+long orc_integrate_dopri5_hook(orc_model *m, double *X, double t0, double tf, double dt, double tol, long *rejected,
+                               orc_step_hook hook)
 {
     const int n = 2 * m->dim;
     const double eps = DBL_EPSILON;
     double k1[ORC_MAX_LEN], xn[ORC_MAX_LEN], kn[ORC_MAX_LEN];
     double t = t0, h = dt;
-    long steps = 0, rej = 0;
+    long steps = 0, rej = 0, budget = ORC_ADAPTIVE_BUDGET;
     int have_k1 = 0;
     if (!(h > 0)) { if (rejected) *rejected = 0; return 0; }          /* zero-length / backward: nothing to do */
-    while (tf - t > eps) {                                            /* less_with_sign(t, tf, dt) */
-        while (t + h - tf <= eps) {                                   /* less_eq_with_sign(t + dt, tf, dt) */
+    while (tf - t > eps && budget > 0) {                              /* less_with_sign(t, tf, dt) */
+        while (t + h - tf <= eps && budget > 0) {                     /* less_eq_with_sign(t + dt, tf, dt) */
+            if (hook && hook(m, t, X)) have_k1 = 0;
             if (!have_k1) { orc_rhs(m, t, X, 0, k1); have_k1 = 1; }
-            int tries = 0;
-            while (!dopri5_try_step(m, n, X, k1, &t, &h, tol, xn, kn)) {
-                rej++;
-                if (++tries >= 500) { if (rejected) *rejected = rej; return -1; }   /* odeint's step_adjustment_error */
+            int tries = 0, ok;
+            do {
+                ok = dopri5_try_step(m, n, X, k1, &t, &h, tol, xn, kn);
+                budget--;
+                if (!ok) rej++;
+            } while (!ok && ++tries < 500);
+            if (!ok) {                                                /* odeint's step_adjustment_error */
+                for (int i = 0; i < n; i++) X[i] = NAN;
+                if (rejected) *rejected = rej;
+                return -1;
             }
             memcpy(X, xn, sizeof(double) * n);
             memcpy(k1, kn, sizeof(double) * n);
@@ -440,8 +448,15 @@ long orc_integrate_dopri5(const orc_model *m, double *X, double t0, double tf, d
         h = tf - t;                                                   /* initialize(x, t, tf - t) */
         have_k1 = 0;
     }
+    if (budget <= 0 && tf - t > eps)
+        for (int i = 0; i < n; i++) X[i] = NAN;
     if (rejected) *rejected = rej;
     return steps;
+}
+
+long orc_integrate_dopri5(const orc_model *m, double *X, double t0, double tf, double dt, double tol, long *rejected)
+{
+    return orc_integrate_dopri5_hook((orc_model *)m, X, t0, tf, dt, tol, rejected, 0);
 }
 
 /* model.hpp:395-414 / goddard.cpp:298-317: dt = (tf - t0)/stepNbr, then integrate. */
@@ -458,7 +473,12 @@ void orc_compute_traj(orc_model *m, double t0, const double *X0, double tf, int 
     if (m->model_id == ORC_MODEL_INTERCEPTOR) {
         double X[12];
         memcpy(X, X0, sizeof(X));
-        orc_interceptor_compute_traj(m, t0, X, tf, Xf);
+        if (m->integrator == 1) orc_interceptor_compute_traj_adaptive(m, t0, X, tf, m->tol, Xf);
+        else orc_interceptor_compute_traj(m, t0, X, tf, Xf);
+    } else if (m->integrator == 1 && !is_jac) {
+        int n = 2 * m->dim;
+        if (Xf != X0) memcpy(Xf, X0, sizeof(double) * n);
+        orc_integrate_dopri5(m, Xf, t0, tf, (tf - t0) / m->step_nbr, m->tol, 0);
     } else {
         orc_model_int(m, t0, X0, tf, is_jac, Xf);
     }

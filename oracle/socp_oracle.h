@@ -49,6 +49,9 @@ typedef struct {
     double sw[ORC_MAX_SWITCH];    /* goddard data->switchingTimes */
     int chart;                    /* interceptor data->currentChart (1 / 2), left as the last trajectory set it */
     int stage;                    /* interceptor data->stageMode (1 = powered), likewise */
+    int integrator;               /* 0 = fixed-step RK4 (default), 1 = adaptive Dormand-Prince: what model::ComputeTraj runs
+                                     in a -D_USE_BOOST build (odeTools.cpp:129-134) */
+    double tol;                   /* odeTools::odeIntTol of that build (abs = rel) */
 } orc_model;
 
 typedef struct {
@@ -81,6 +84,13 @@ long orc_model_int(const orc_model *m, double t0, const double *X0, double tf, i
  * (controlled Dormand-Prince 5(4) with FSAL); validated by tolerance only.
  * Returns accepted steps; *rejected (may be NULL) counts rejected trial steps. */
 long orc_integrate_dopri5(const orc_model *m, double *X, double t0, double tf, double dt, double tol, long *rejected);
+/* The same loop with a hook called before every step (may be NULL); a hook that rewrites X (the interceptor's chart
+ * change, interceptor.cpp:953-978) returns 1 and the FSAL derivative is recomputed.  At most ORC_ADAPTIVE_BUDGET trial
+ * steps per call, then the state is NaN (odeint's step_adjustment_error; the device kernels do the same). */
+#define ORC_ADAPTIVE_BUDGET 50000
+typedef int (*orc_step_hook)(orc_model *m, double t, double *X);
+long orc_integrate_dopri5_hook(orc_model *m, double *X, double t0, double tf, double dt, double tol, long *rejected,
+                               orc_step_hook hook);
 /* batch of independent trajectories, one per row; aux_sw may be NULL, else [B][2] */
 void orc_integrate_batch(const orc_model *m, int B, const double *t0, const double *tf,
                          const double *aux_sw, const double *X0, double *Xf, int is_jac);
@@ -102,6 +112,9 @@ void orc_lu6_solve(const double A[6][6], const double *b, double *x);
 void orc_interceptor_compute_traj(orc_model *m, double t0, const double *X0, double tf, double *Xf);
 void orc_interceptor_compute_traj_obs(orc_model *m, double t0, const double *X0, double tf, double *Xf,
                                       orc_interceptor_observer obs, void *ctx);
+/* ComputeTraj with the adaptive integrator in place of the 50 fixed steps per stage (BASELINE config 5: the reference's
+ * interceptor is RK4-only, so this combination is an extrapolation): same stage split, chart re-chosen before every step */
+void orc_interceptor_compute_traj_adaptive(orc_model *m, double t0, const double *X0, double tf, double tol, double *Xf);
 void orc_interceptor_final_rows(const orc_model *m, const double *Xtf, const double *Xf, const int *mode_x, double *fvec);
 void orc_interceptor_init_analytical(const orc_model *m, double ti, double *Xi, double tf, const double *Xf);
 

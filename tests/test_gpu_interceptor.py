@@ -161,6 +161,65 @@ def test_residual_and_fd_rows(ictx, built, M):
     ictx.set_param("mu_gft", 1.0)
 
 
+def config5_problem(o):
+    """BASELINE config 5: M = 21 segments -> n = 253, nodes along the CONVERGED scenario-1 trajectory of the test program
+    (tests/golden/interceptor_flow.json): the Jacobian a multiple-shooting solve of that scenario evaluates."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gold = json.load(open(os.path.join(root, "tests", "golden", "interceptor_flow.json")))["scenario1_xtol1e-12"][-1]["z"]
+    Xf = np.zeros(12)
+    Xf[:6] = [12000, 1000, 0.0, np.pi / 8, 5475000 / R_E, 42000 / R_E]
+    return multi_shooting_problem(o, 21, tf=gold[12], X0=np.array(gold[:12]), Xf=Xf)
+
+
+@pytest.mark.parametrize("variant", ["exact", "fast"])
+def test_config5_interceptor_dopri5_253_unknowns(built, variant):
+    """BASELINE config 5 AS STATED: interceptor model, adaptive Dormand-Prince (per-lane step control), multiple shooting
+    with M = 21 segments -> n = 253 unknowns.  Residual and all 254 FD rows against the CPU restatement running the same
+    adaptive integrator (oracle/interceptor_oracle.c: orc_interceptor_compute_traj_adaptive -- PARITY UNPINNED: no Boost,
+    no Eigen, no reference-held vectors, and the reference's interceptor is RK4-only, so this combination is an
+    extrapolation of the reference; the tolerance is the one the single-trajectory adaptive tests use, 100 x tol),
+    the FD Jacobian identical with and without the segment dedup, and every entry finite."""
+    from socp_amd import capi
+    tol = 1e-8
+    o = Oracle(MODEL_INTERCEPTOR)
+    prob, z = config5_problem(o)                     # nodes integrated with the fixed-step path
+    assert prob.n == 253
+    o.set_integrator(1, tol)
+    c = capi.Context(capi.MODEL_INTERCEPTOR)
+    c.set_variant(capi.VARIANT_LANE_EXACT if variant == "exact" else capi.VARIANT_LANE_FAST)
+    c.set_integrator(capi.INT_DOPRI5, tol)
+    assert c.problem_set(prob.mode_t, prob.mode_x, prob.time, prob.xnode) == 253
+    Fo = o.residual(prob, z)
+    F = c.residual(z)
+    scale = np.maximum(1.0, np.abs(Fo))
+    assert np.all(np.isfinite(F)) and np.max(np.abs(F - Fo) / scale) <= 100 * tol
+    # the adaptive integrator is really the one that ran: the fixed-step residual differs by far more than rounding
+    c.set_integrator(capi.INT_RK4)
+    F_rk4 = c.residual(z)
+    c.set_integrator(capi.INT_DOPRI5, tol)
+    assert np.max(np.abs(F - F_rk4) / scale) > 1e-12
+    # all n + 1 rows of the FD batch in one launch vs residuals of the perturbed vectors
+    rows = c.fd_rows(z[None, :], epsfcn=1e-15)[0]
+    assert rows.shape == (254, 253) and np.all(np.isfinite(rows))
+    eps = np.sqrt(1e-15)
+    Zp = np.repeat(z[None, :], 254, axis=0)
+    for j in range(253):
+        h = eps * abs(z[j]) or eps
+        Zp[j + 1, j] += h
+    want = o.residual_batch(prob, Zp)
+    assert np.max(np.abs(rows - want) / np.maximum(1.0, np.abs(want))) <= 100 * tol
+    assert np.array_equal(rows[0], F)                       # same kernel arithmetic for the base row
+    # FD Jacobian: dedup on / off identical, and equal to the differences of the rows
+    J_full = c.fd_jacobian(z, F, epsfcn=1e-15, dedup=False)
+    J_ded = c.fd_jacobian(z, F, epsfcn=1e-15, dedup=True)
+    assert np.array_equal(J_full, J_ded) and np.all(np.isfinite(J_full))
+    hs = np.array([eps * abs(v) or eps for v in z])
+    assert np.array_equal(J_full, ((rows[1:] - rows[0]) / hs[:, None]).T)
+    c.close()
+
+
 def test_adaptive_integrator_matches_fine_fixed_step(ictx):
     """Dormand-Prince with the per-step chart choice (extension; the reference's interceptor is RK4-only):
     converges to what a very fine fixed-step run gives."""

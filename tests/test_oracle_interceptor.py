@@ -135,3 +135,26 @@ def test_restated_test_program_converges(built, solver):
         assert [(s["stage"], s["info"], s["nfev"]) for s in got] == [(s["stage"], s["info"], s["nfev"]) for s in want]
         for s, w in zip(got, want):
             assert np.array_equal(s["z"], np.array(w["z"]))
+
+
+def test_adaptive_residual_of_the_config5_problem_converges_to_the_fixed_step_limit(built):
+    """BASELINE config 5 (interceptor + adaptive Dormand-Prince + M = 21, n = 253) on the CPU restatement: with the
+    adaptive integrator selected, the residual approaches the fine fixed-step residual as the tolerance shrinks (5(4) pair:
+    error ~ tol), the chart hook included.  This is the checker the GPU test of the same configuration compares with."""
+    from test_gpu_interceptor import config5_problem
+    o = Oracle(MODEL_INTERCEPTOR)
+    prob, z = config5_problem(o)
+    assert prob.n == 253
+    fine = Oracle(MODEL_INTERCEPTOR, step_nbr=2000)
+    F_fine = fine.residual(prob, z)
+    scale = np.maximum(1.0, np.abs(F_fine))
+    errs = []
+    for tol in (1e-6, 1e-8, 1e-10):
+        o.set_integrator(1, tol)
+        F = o.residual(prob, z)
+        assert np.all(np.isfinite(F))
+        errs.append(float(np.max(np.abs(F - F_fine) / scale)))
+    assert errs[0] < 1e-3 and errs[1] < 1e-5 and errs[2] < 1e-7, errs
+    assert errs[2] < errs[0]
+    o.set_integrator(0)
+    assert np.max(np.abs(o.residual(prob, z) - F_fine) / scale) < 1e-6      # the 50-step RK4 default, for scale
