@@ -140,6 +140,20 @@ int socp_problem_set(socp_ctx *ctx, int num_multi, const int *mode_t, const int 
                      const double *time, const double *xnode);
 int socp_problem_num_param(const socp_ctx *ctx);   /* n = 2 d M + #FREE times (shooting.cpp:179,196) */
 
+/* Per-problem blocks for the batch entry points below (batched continuation chains: shooting.cpp:598-692 blends the
+ * boundary data of ONE problem per Newton solve, :695-778 moves ONE model parameter through a real&; with many chains in
+ * one launch every row needs its own).  Device pointers, or NULL for "shared" (the context's parameters / the tables of
+ * socp_problem_set); they stay in force for every later *_dev batch call until replaced:
+ *   d_params[q][stride]   stride = nparams + 2: the packed parameters of problem q, then its two default switching times
+ *   d_time[q][M+1], d_xnode[q][(M+1)*2d]   current node times / node states of problem q (what socp_problem_set takes)
+ * Row q of socp_residual_batch_dev, problem q of socp_fd_jacobian_multi_dev / socp_fd_rows_dev read block q.  Modes, M and n
+ * are those of socp_problem_set.  With d_params the Goddard control law is chosen per problem from its own mu2. */
+int socp_problem_set_blocks_dev(socp_ctx *ctx, const double *d_params, int stride, const double *d_time,
+                                const double *d_xnode);
+/* host-pointer form of socp_residual_batch with per-row blocks (any of params / time / xnode may be NULL) */
+int socp_residual_batch_blocks(socp_ctx *ctx, int B, const double *Z, const double *params, int stride,
+                               const double *time, const double *xnode, double *F);
+
 /* replaces: shooting::ComputeTimeLine (shooting.cpp:1579-1617) for one unknown vector */
 int socp_timeline(socp_ctx *ctx, const double *z, double *timeline);
 

@@ -580,8 +580,47 @@ int socp_problem_set(socp_ctx *c, int M, const int *mode_t, const int *mode_x, c
     c->pb.node_kind = di + off_kind; c->pb.lo = di + off_lo; c->pb.hi = di + off_hi;
     c->pb.ft_row = di + off_ft; c->pb.mode_x = di + off_mx;
     c->pb.time = dd; c->pb.xnode = dd + nI;
+    c->pb.pp_params = c->pb.pp_time = c->pb.pp_xnode = nullptr; c->pb.pp_stride = 0;   // a new problem starts without per-problem blocks
     c->has_problem = true;
     return SOCP_OK;
+}
+
+int socp_problem_set_blocks_dev(socp_ctx *c, const double *d_params, int stride, const double *d_time, const double *d_xnode)
+{
+    if (!c) return SOCP_ERR_ARG;
+    if (!c->has_problem) return fail(c, SOCP_ERR_ARG, "problem_set_blocks: no problem set");
+    if (d_params && stride != c->nparams + 2)
+        return fail(c, SOCP_ERR_ARG, "problem_set_blocks: stride must be nparams + 2 (parameters, then two switching times)");
+    if (d_params && c->nparams + 2 > kMaxParams + 2) return fail(c, SOCP_ERR_ARG, "problem_set_blocks: too many parameters");
+    c->pb.pp_params = d_params;
+    c->pb.pp_stride = d_params ? stride : 0;
+    c->pb.pp_time = d_time;
+    c->pb.pp_xnode = d_xnode;
+    return SOCP_OK;
+}
+
+int socp_residual_batch_blocks(socp_ctx *c, int B, const double *Z, const double *params, int stride, const double *time,
+                               const double *xnode, double *F)
+{
+    if (!c) return SOCP_ERR_ARG;
+    if (!c->has_problem) return fail(c, SOCP_ERR_ARG, "residual_batch_blocks: no problem set");
+    if (B < 0 || (B > 0 && (!Z || !F))) return fail(c, SOCP_ERR_ARG, "residual_batch_blocks: null argument");
+    if (B == 0) return SOCP_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t nodes = (size_t)c->M + 1;
+    const size_t nbP = params ? sizeof(double) * (size_t)B * stride : 0, nbT = time ? sizeof(double) * B * nodes : 0,
+                 nbX = xnode ? sizeof(double) * B * nodes * c->S : 0;
+    HIP_TRY(c, c->s_aux.reserve(nbP + nbT + nbX + 64));
+    char *base = c->s_aux.as<char>();
+    double *dP = reinterpret_cast<double *>(base), *dT = reinterpret_cast<double *>(base + nbP), *dX = reinterpret_cast<double *>(base + nbP + nbT);
+    if (params) HIP_TRY(c, hipMemcpyAsync(dP, params, nbP, hipMemcpyHostToDevice, c->stream));
+    if (time) HIP_TRY(c, hipMemcpyAsync(dT, time, nbT, hipMemcpyHostToDevice, c->stream));
+    if (xnode) HIP_TRY(c, hipMemcpyAsync(dX, xnode, nbX, hipMemcpyHostToDevice, c->stream));
+    const ProblemDev saved = c->pb;
+    int rc = socp_problem_set_blocks_dev(c, params ? dP : nullptr, stride, time ? dT : nullptr, xnode ? dX : nullptr);
+    if (rc == SOCP_OK) rc = socp_residual_batch(c, B, Z, F);
+    c->pb = saved;
+    return rc;
 }
 
 int socp_problem_num_param(const socp_ctx *c) { return (c && c->has_problem) ? c->n : SOCP_ERR_ARG; }

@@ -32,7 +32,32 @@ struct ProblemDev {
     const int *mode_x;                 // [(M+1)*d]
     const double *time;                // [M+1]
     const double *xnode;               // [(M+1)*2d]
+    // Per-problem blocks (batched continuation chains, shooting.cpp:598-778 run for many chains at once): when set, row /
+    // problem q of a launch reads its OWN packed model parameters and / or boundary tables instead of the shared ones --
+    //   pp_params[q][pp_stride]: p[0 .. pp_stride-2) then sw0, sw1      (parameter homotopy: the real& the loop mutates)
+    //   pp_time[q][M+1], pp_xnode[q][(M+1)*2d]                          (boundary-data homotopy, shooting.cpp:609-611)
+    // Structure (modes, M, n) is shared by all problems of a launch.  Null = shared value.
+    const double *pp_params;
+    const double *pp_time;
+    const double *pp_xnode;
+    int pp_stride;
 };
+
+// the per-problem view of (P, pb) for problem q; every index is static so the blocks stay in registers
+__device__ __forceinline__ void load_problem_block(const ProblemDev &pb, long q, ModelParams &Pq, ProblemDev &pq)
+{
+    if (pb.pp_params) {
+        const double *src = pb.pp_params + q * pb.pp_stride;
+        const int np = pb.pp_stride - 2;
+#pragma unroll
+        for (int k = 0; k < kMaxParams; k++)
+            if (k < np) Pq.p[k] = src[k];
+        Pq.sw0 = src[np];
+        Pq.sw1 = src[np + 1];
+    }
+    if (pb.pp_time) pq.time = pb.pp_time + q * (pb.M + 1);
+    if (pb.pp_xnode) pq.xnode = pb.pp_xnode + q * (long)(pb.M + 1) * 2 * pb.dim;
+}
 
 // shooting::ComputeTimeLine, one node (shooting.cpp:1586-1613): junction value, or the uniform
 // interpolation  tl[cur] + (k-cur)*(tl[j]-tl[cur])/(j-cur)  in that operation order.

@@ -220,7 +220,7 @@ struct Lane {
 // WPE = cap on waves per SIMD (amdgpu_waves_per_eu max): the launcher picks ceil(waves / 1024) so that a
 // grid smaller than the chip is spread one (or two) waves per SIMD instead of being packed three deep on
 // a fraction of the SIMDs (launch_impl.hpp).
-template <class Mdl, int WPE, int INTEG = 0>
+template <class Mdl, int WPE, int INTEG = 0, bool PERPROB = false>      // PERPROB unused here (one launch-macro shape for all hot kernels)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, WPE))) void traj_lane_kernel(ModelParams P, int B,
                                                        const double *__restrict__ t0,
                                                        const double *__restrict__ tf,
@@ -419,7 +419,9 @@ __device__ __forceinline__ void store_tile(const double *tile, double *dst, long
 }
 
 // K_res: Z[B][n] -> F[B][n]; one lane = (row, segment).
-template <class Mdl, int WPE, int INTEG = 0>
+// PERPROB: row b carries its own parameter / boundary blocks (dev_common.hpp load_problem_block) -- a separate
+// instantiation, so the shared-parameter kernels keep their parameters in scalar registers.
+template <class Mdl, int WPE, int INTEG = 0, bool PERPROB = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, WPE))) void residual_lane_kernel(ModelParams P, ProblemDev pb, int B,
                                                               const double *__restrict__ Z,
                                                               double *__restrict__ F, int rows_per_block)
@@ -449,7 +451,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, WPE))) vo
     if (live) {
         const double *zr = Z + b * n;
         auto z = [=](int k) -> double { return zr[k]; };
-        segment_residual<Mdl, INTEG>(P, pb, z, i, [=](int row, double v) { out[row] = v; });
+        if constexpr (PERPROB) {
+            ModelParams Pq = P;
+            ProblemDev pq = pb;
+            load_problem_block(pb, b, Pq, pq);
+            segment_residual<Mdl, INTEG>(Pq, pq, z, i, [=](int row, double v) { out[row] = v; });
+        } else {
+            segment_residual<Mdl, INTEG>(P, pb, z, i, [=](int row, double v) { out[row] = v; });
+        }
     }
     if (rows_per_block == 0) return;                 // uniform over the workgroup
     __syncthreads();
@@ -467,7 +476,7 @@ __device__ __forceinline__ double fd_step(double zj, double eps)
 // integrate; the unknown vector of column j is z with z_j + h_j generated on the fly, so the
 // perturbation matrix never exists in HBM: reads are z[n] and fvec[n] per problem (cache
 // resident), writes are the Jacobian entries fjac[row + n*j] = (F_j[row] - fvec[row]) / h_j.
-template <class Mdl, int WPE, int INTEG = 0>
+template <class Mdl, int WPE, int INTEG = 0, bool PERPROB = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, WPE))) void fdjac_lane_kernel(ModelParams P, ProblemDev pb, int np, int T,
                                                            const int2 *__restrict__ pairs,
                                                            const double *__restrict__ Zb,
@@ -482,17 +491,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, WPE))) vo
     const double *zb = Zb + prob * pb.n;
     const double *fvec = Fvec + prob * pb.n;
     const double h = fd_step(zb[j], eps);
-    const double zj = zb[j] + h;
-    auto z = [=](int k) -> double { const double v = zb[k]; return k == j ? zj : v; };
+    // z_k (+ h when k is the perturbed column).  Written as an ADD of h or -0.0 (x + -0.0 == x bit for bit, -0.0 included):
+    // a select between the loaded value and a precomputed z_j + h makes the compiler select between two ADDRESSES
+    // (the global one and a stack copy of z_j + h) and load through a flat pointer -- 16 bytes of scratch per lane.
+    auto z = [=](int k) -> double { return zb[k] + (k == j ? h : -0.0); };
     double *col = Fjac + prob * (long)pb.n * pb.n + (long)pb.n * j;
-    segment_residual<Mdl, INTEG>(P, pb, z, i, [=](int row, double v) { col[row] = (v - fvec[row]) / h; });
+    if constexpr (PERPROB) {
+        ModelParams Pq = P;
+        ProblemDev pq = pb;
+        load_problem_block(pb, prob, Pq, pq);
+        segment_residual<Mdl, INTEG>(Pq, pq, z, i, [=](int row, double v) { col[row] = (v - fvec[row]) / h; });
+    } else {
+        segment_residual<Mdl, INTEG>(P, pb, z, i, [=](int row, double v) { col[row] = (v - fvec[row]) / h; });
+    }
 }
 
 // K_fdr: the (n+1) residual rows of a forward-difference Jacobian -- row 0 at z, row j+1 at
 // z + h_j e_j -- for `np` problems in ONE launch (no dependency between base and perturbed
 // trajectories).  Rows[np][n+1][n]; the perturbation matrix is generated on the fly; output through
 // row-owned LDS tiles (see above) so that the residual rows are written as full lines.
-template <class Mdl, int WPE, int INTEG = 0>
+template <class Mdl, int WPE, int INTEG = 0, bool PERPROB = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, WPE))) void fdrows_lane_kernel(ModelParams P, ProblemDev pb, int np,
                                                             const double *__restrict__ Zb, double eps,
                                                             double *__restrict__ Rows, int rows_per_block)
@@ -525,9 +543,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, WPE))) vo
         const int row = (int)(vrow - prob * (n + 1));    // 0 = base, j+1 = column j
         const int j = row - 1;
         const double *zb = Zb + prob * n;
-        const double zj = j >= 0 ? zb[j] + fd_step(zb[j], eps) : 0.0;
-        auto z = [=](int k) -> double { const double v = zb[k]; return k == j ? zj : v; };
-        segment_residual<Mdl, INTEG>(P, pb, z, i, [=](int r, double v) { out[r] = v; });
+        const double hj = j >= 0 ? fd_step(zb[j], eps) : -0.0;
+        auto z = [=](int k) -> double { return zb[k] + (k == j ? hj : -0.0); };      // see fdjac_lane_kernel
+        if constexpr (PERPROB) {
+            ModelParams Pq = P;
+            ProblemDev pq = pb;
+            load_problem_block(pb, prob, Pq, pq);
+            segment_residual<Mdl, INTEG>(Pq, pq, z, i, [=](int r, double v) { out[r] = v; });
+        } else {
+            segment_residual<Mdl, INTEG>(P, pb, z, i, [=](int r, double v) { out[r] = v; });
+        }
     }
     if (rows_per_block == 0) return;                 // uniform over the workgroup
     __syncthreads();

@@ -56,7 +56,7 @@ inline int rows_per_block(int M, int n)
 
 // Launch table of an out-of-tree model (include/socp_plugin.h, plugin_impl.hpp): what the C-ABI layer calls
 // instead of the built-in flavour launchers when a context is created with a registered model id.
-constexpr int kPluginAbi = 2;
+constexpr int kPluginAbi = 3;      // 3: ProblemDev carries per-problem blocks
 struct ModelLaunchers {
     int abi, dim, control_dim, nparams, default_step_nbr;
     double default_params[kMaxParams];

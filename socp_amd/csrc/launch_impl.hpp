@@ -11,32 +11,45 @@ namespace socp {
 
 // SOCP_HAVE_DOPRI5: this translation unit also carries the adaptive-integrator instantiations (one wave per
 // SIMD: seven stage vectors live in registers)
+// PP: the PERPROB template argument (true: per-problem parameter / boundary blocks; always false for the trajectory kernel)
 #ifdef SOCP_HAVE_DOPRI5
-#define SOCP_LAUNCH_ADAPTIVE(KERNEL, MDL, GRID, LDS, ST, ...) \
-    if (P.integrator == 1) { hipLaunchKernelGGL((KERNEL<MDL, 1, 1>), dim3(GRID), dim3(64), LDS, ST, __VA_ARGS__); break; }
+#define SOCP_LAUNCH_ADAPTIVE(KERNEL, MDL, PP, GRID, LDS, ST, ...) \
+    if (P.integrator == 1) { hipLaunchKernelGGL((KERNEL<MDL, 1, 1, PP>), dim3(GRID), dim3(64), LDS, ST, __VA_ARGS__); break; }
 #else
-#define SOCP_LAUNCH_ADAPTIVE(KERNEL, MDL, GRID, LDS, ST, ...)
+#define SOCP_LAUNCH_ADAPTIVE(KERNEL, MDL, PP, GRID, LDS, ST, ...)
 #endif
 
-#define SOCP_LAUNCH_MDL(KERNEL, MDL, WAVES, GRID, LDS, ST, ...)                                            \
-    do {                                                                                                  \
-        SOCP_LAUNCH_ADAPTIVE(KERNEL, MDL, GRID, LDS, ST, __VA_ARGS__)                                     \
-        switch (wpe_for(WAVES)) {                                                                         \
-        case 1: hipLaunchKernelGGL((KERNEL<MDL, 1>), dim3(GRID), dim3(64), LDS, ST, __VA_ARGS__); break;  \
-        case 2: hipLaunchKernelGGL((KERNEL<MDL, 2>), dim3(GRID), dim3(64), LDS, ST, __VA_ARGS__); break;  \
-        default: hipLaunchKernelGGL((KERNEL<MDL, 3>), dim3(GRID), dim3(64), LDS, ST, __VA_ARGS__); break; \
-        }                                                                                                 \
+#define SOCP_LAUNCH_MDL(KERNEL, MDL, PP, WAVES, GRID, LDS, ST, ...)                                              \
+    do {                                                                                                           \
+        SOCP_LAUNCH_ADAPTIVE(KERNEL, MDL, PP, GRID, LDS, ST, __VA_ARGS__)                                       \
+        switch (wpe_for(WAVES)) {                                                                                  \
+        case 1: hipLaunchKernelGGL((KERNEL<MDL, 1, 0, PP>), dim3(GRID), dim3(64), LDS, ST, __VA_ARGS__); break;   \
+        case 2: hipLaunchKernelGGL((KERNEL<MDL, 2, 0, PP>), dim3(GRID), dim3(64), LDS, ST, __VA_ARGS__); break;   \
+        default: hipLaunchKernelGGL((KERNEL<MDL, 3, 0, PP>), dim3(GRID), dim3(64), LDS, ST, __VA_ARGS__); break;  \
+        }                                                                                                          \
     } while (0)
 
 // model_id 1 = Goddard (smooth-law specialisation when mu2 > 0, parameter slot 6), 2 = double integrator
-#define SOCP_DISPATCH_HOT_LDS(KERNEL, GRID, LDS, ST, ...)                                               \
+// With per-problem parameter blocks the control law may differ between problems of one launch, so the Goddard
+// smooth-law specialisation (chosen from the SHARED mu2) is not used there.
+#define SOCP_DISPATCH_MODELS(KERNEL, PP, SMOOTH_OK, GRID, LDS, ST, ...)                                  \
     do {                                                                                                \
-        if (model_id == 1 && P.p[6] > 0) SOCP_LAUNCH_MDL(KERNEL, SOCP_GODDARD_SMOOTH, GRID, GRID, LDS, ST, __VA_ARGS__); \
-        else if (model_id == 1) SOCP_LAUNCH_MDL(KERNEL, SOCP_GODDARD, GRID, GRID, LDS, ST, __VA_ARGS__); \
-        else if (model_id == 3) SOCP_LAUNCH_MDL(KERNEL, SOCP_COVID, GRID, GRID, LDS, ST, __VA_ARGS__);  \
-        else SOCP_LAUNCH_MDL(KERNEL, SOCP_DINT, GRID, GRID, LDS, ST, __VA_ARGS__);                      \
+        if (model_id == 1 && (SMOOTH_OK) && P.p[6] > 0) SOCP_LAUNCH_MDL(KERNEL, SOCP_GODDARD_SMOOTH, PP, GRID, GRID, LDS, ST, __VA_ARGS__); \
+        else if (model_id == 1) SOCP_LAUNCH_MDL(KERNEL, SOCP_GODDARD, PP, GRID, GRID, LDS, ST, __VA_ARGS__); \
+        else if (model_id == 3) SOCP_LAUNCH_MDL(KERNEL, SOCP_COVID, PP, GRID, GRID, LDS, ST, __VA_ARGS__);  \
+        else SOCP_LAUNCH_MDL(KERNEL, SOCP_DINT, PP, GRID, GRID, LDS, ST, __VA_ARGS__);                      \
     } while (0)
-#define SOCP_DISPATCH_HOT(KERNEL, GRID, ST, ...) SOCP_DISPATCH_HOT_LDS(KERNEL, GRID, 0, ST, __VA_ARGS__)
+// trajectory kernel (no shooting problem)
+#define SOCP_DISPATCH_HOT(KERNEL, GRID, ST, ...) SOCP_DISPATCH_MODELS(KERNEL, false, true, GRID, 0, ST, __VA_ARGS__)
+// kernels that read a shooting problem `pb`: per-problem blocks select the PERPROB instantiation
+#define SOCP_DISPATCH_PB_LDS(KERNEL, GRID, LDS, ST, ...)                                                \
+    do {                                                                                                \
+        if (pb.pp_params || pb.pp_time || pb.pp_xnode)                                                  \
+            SOCP_DISPATCH_MODELS(KERNEL, true, pb.pp_params == nullptr, GRID, LDS, ST, __VA_ARGS__); \
+        else                                                                                            \
+            SOCP_DISPATCH_MODELS(KERNEL, false, true, GRID, LDS, ST, __VA_ARGS__);                \
+    } while (0)
+#define SOCP_DISPATCH_PB(KERNEL, GRID, ST, ...) SOCP_DISPATCH_PB_LDS(KERNEL, GRID, 0, ST, __VA_ARGS__)
 
 #define SOCP_DISPATCH(KERNEL, GRID, ST, ...)                                                            \
     do {                                                                                                \
@@ -65,7 +78,7 @@ hipError_t SOCP_CAT(residual_, SOCP_FLAVOUR)(int model_id, hipStream_t st, const
     if (B <= 0) return hipSuccess;
     const int R = rows_per_block(pb.M, pb.n);
     const unsigned grid = R ? (unsigned)((B + R - 1) / R) : blocks_for((long)B * pb.M);
-    SOCP_DISPATCH_HOT_LDS(residual_lane_kernel, grid, (unsigned)((long)R * pb.n * 8), st, P, pb, B, Z, F, R);
+    SOCP_DISPATCH_PB_LDS(residual_lane_kernel, grid, (unsigned)((long)R * pb.n * 8), st, P, pb, B, Z, F, R);
     return hipGetLastError();
 }
 
@@ -75,7 +88,7 @@ hipError_t SOCP_CAT(fdjac_, SOCP_FLAVOUR)(int model_id, hipStream_t st, const Mo
 {
     if (T <= 0 || np <= 0) return hipSuccess;
     const long total = (long)np * T;
-    SOCP_DISPATCH_HOT(fdjac_lane_kernel, blocks_for(total), st, P, pb, np, T, pairs, z, fvec, eps, fjac);
+    SOCP_DISPATCH_PB(fdjac_lane_kernel, blocks_for(total), st, P, pb, np, T, pairs, z, fvec, eps, fjac);
     return hipGetLastError();
 }
 
@@ -86,7 +99,7 @@ hipError_t SOCP_CAT(fdrows_, SOCP_FLAVOUR)(int model_id, hipStream_t st, const M
     const long vrows = (long)np * (pb.n + 1);
     const int R = rows_per_block(pb.M, pb.n);
     const unsigned grid = R ? (unsigned)((vrows + R - 1) / R) : blocks_for(vrows * pb.M);
-    SOCP_DISPATCH_HOT_LDS(fdrows_lane_kernel, grid, (unsigned)((long)R * pb.n * 8), st, P, pb, np, z, eps, rows, R);
+    SOCP_DISPATCH_PB_LDS(fdrows_lane_kernel, grid, (unsigned)((long)R * pb.n * 8), st, P, pb, np, z, eps, rows, R);
     return hipGetLastError();
 }
 

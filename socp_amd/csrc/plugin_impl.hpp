@@ -36,19 +36,27 @@ namespace plugin {
 template <class M, class = void> struct one_wave_per_simd : std::false_type {};
 template <class M> struct one_wave_per_simd<M, std::void_t<decltype(M::kOneWavePerSimd)>> : std::bool_constant<M::kOneWavePerSimd> {};
 
-// one launch of a hot kernel: adaptive integrator -> one wave per SIMD; otherwise occupancy cap from the grid
-#define SOCP_PLUGIN_LAUNCH_LDS(KERNEL, GRID, LDS, ST, ...)                                                       \
-    do {                                                                                                         \
-        if (P.integrator == 1) hipLaunchKernelGGL((KERNEL<Mdl, 1, 1>), dim3(GRID), dim3(64), LDS, ST, __VA_ARGS__); \
-        else if constexpr (one_wave_per_simd<Mdl>::value)                                                        \
-            hipLaunchKernelGGL((KERNEL<Mdl, 1, 0>), dim3(GRID), dim3(64), LDS, ST, __VA_ARGS__);                 \
-        else switch (wpe_for(GRID)) {                                                                            \
-        case 1: hipLaunchKernelGGL((KERNEL<Mdl, 1, 0>), dim3(GRID), dim3(64), LDS, ST, __VA_ARGS__); break;       \
-        case 2: hipLaunchKernelGGL((KERNEL<Mdl, 2, 0>), dim3(GRID), dim3(64), LDS, ST, __VA_ARGS__); break;       \
-        default: hipLaunchKernelGGL((KERNEL<Mdl, 3, 0>), dim3(GRID), dim3(64), LDS, ST, __VA_ARGS__); break;      \
-        }                                                                                                        \
+// one launch of a hot kernel: adaptive integrator -> one wave per SIMD; otherwise occupancy cap from the grid.
+// PP: the PERPROB template argument (always false for the trajectory kernel)
+#define SOCP_PLUGIN_LAUNCH_T(KERNEL, PP, GRID, LDS, ST, ...)                                                        \
+    do {                                                                                                               \
+        if (P.integrator == 1) hipLaunchKernelGGL((KERNEL<Mdl, 1, 1, PP>), dim3(GRID), dim3(64), LDS, ST, __VA_ARGS__); \
+        else if constexpr (one_wave_per_simd<Mdl>::value)                                                              \
+            hipLaunchKernelGGL((KERNEL<Mdl, 1, 0, PP>), dim3(GRID), dim3(64), LDS, ST, __VA_ARGS__);                 \
+        else switch (wpe_for(GRID)) {                                                                                  \
+        case 1: hipLaunchKernelGGL((KERNEL<Mdl, 1, 0, PP>), dim3(GRID), dim3(64), LDS, ST, __VA_ARGS__); break;       \
+        case 2: hipLaunchKernelGGL((KERNEL<Mdl, 2, 0, PP>), dim3(GRID), dim3(64), LDS, ST, __VA_ARGS__); break;       \
+        default: hipLaunchKernelGGL((KERNEL<Mdl, 3, 0, PP>), dim3(GRID), dim3(64), LDS, ST, __VA_ARGS__); break;      \
+        }                                                                                                              \
     } while (0)
-#define SOCP_PLUGIN_LAUNCH(KERNEL, GRID, ST, ...) SOCP_PLUGIN_LAUNCH_LDS(KERNEL, GRID, 0, ST, __VA_ARGS__)
+#define SOCP_PLUGIN_LAUNCH(KERNEL, GRID, ST, ...) SOCP_PLUGIN_LAUNCH_T(KERNEL, false, GRID, 0, ST, __VA_ARGS__)
+// kernels that read a shooting problem `pb`: per-problem blocks (dev_common.hpp) select the PERPROB instantiation
+#define SOCP_PLUGIN_LAUNCH_PB_LDS(KERNEL, GRID, LDS, ST, ...)                                                           \
+    do {                                                                                                               \
+        if (pb.pp_params || pb.pp_time || pb.pp_xnode) SOCP_PLUGIN_LAUNCH_T(KERNEL, true, GRID, LDS, ST, __VA_ARGS__); \
+        else SOCP_PLUGIN_LAUNCH_T(KERNEL, false, GRID, LDS, ST, __VA_ARGS__);                             \
+    } while (0)
+#define SOCP_PLUGIN_LAUNCH_PB(KERNEL, GRID, ST, ...) SOCP_PLUGIN_LAUNCH_PB_LDS(KERNEL, GRID, 0, ST, __VA_ARGS__)
 
 template <class Mdl>
 hipError_t traj(hipStream_t st, const ModelParams &P, int B, const double *t0, const double *tf, const double *sw,
@@ -64,7 +72,7 @@ hipError_t residual(hipStream_t st, const ModelParams &P, const ProblemDev &pb, 
     if (B <= 0) return hipSuccess;
     const int R = rows_per_block(pb.M, pb.n);
     const unsigned grid = R ? (unsigned)((B + R - 1) / R) : blocks_for((long)B * pb.M);
-    SOCP_PLUGIN_LAUNCH_LDS(residual_lane_kernel, grid, (unsigned)((long)R * pb.n * 8), st, P, pb, B, Z, F, R);
+    SOCP_PLUGIN_LAUNCH_PB_LDS(residual_lane_kernel, grid, (unsigned)((long)R * pb.n * 8), st, P, pb, B, Z, F, R);
     return hipGetLastError();
 }
 template <class Mdl>
@@ -72,7 +80,7 @@ hipError_t fdjac(hipStream_t st, const ModelParams &P, const ProblemDev &pb, int
                  const double *z, const double *fvec, double eps, double *fjac)
 {
     if (np <= 0 || T <= 0) return hipSuccess;
-    SOCP_PLUGIN_LAUNCH(fdjac_lane_kernel, blocks_for((long)np * T), st, P, pb, np, T, pairs, z, fvec, eps, fjac);
+    SOCP_PLUGIN_LAUNCH_PB(fdjac_lane_kernel, blocks_for((long)np * T), st, P, pb, np, T, pairs, z, fvec, eps, fjac);
     return hipGetLastError();
 }
 template <class Mdl>
@@ -82,7 +90,7 @@ hipError_t fdrows(hipStream_t st, const ModelParams &P, const ProblemDev &pb, in
     const long vrows = (long)np * (pb.n + 1);
     const int R = rows_per_block(pb.M, pb.n);
     const unsigned grid = R ? (unsigned)((vrows + R - 1) / R) : blocks_for(vrows * pb.M);
-    SOCP_PLUGIN_LAUNCH_LDS(fdrows_lane_kernel, grid, (unsigned)((long)R * pb.n * 8), st, P, pb, np, z, eps, rows, R);
+    SOCP_PLUGIN_LAUNCH_PB_LDS(fdrows_lane_kernel, grid, (unsigned)((long)R * pb.n * 8), st, P, pb, np, z, eps, rows, R);
     return hipGetLastError();
 }
 template <class Mdl>
