@@ -87,6 +87,7 @@ int socp_ctx_set_step_number(socp_ctx *ctx, int step_nbr);      /* model::stepNb
 #define SOCP_INT_DOPRI5 1
 int socp_ctx_set_integrator(socp_ctx *ctx, int kind, double tol);
 int socp_ctx_set_switching_times(socp_ctx *ctx, const double *sw, int nsw);  /* goddard.cpp:373-377 */
+int socp_ctx_get_switching_times(const socp_ctx *ctx, double *sw2);          /* the two values the control law reads */
 int socp_ctx_set_variant(socp_ctx *ctx, int variant);
 /* enqueue on the caller's hipStream_t (NULL is the device's default stream); use_own != 0 switches
  * back to the context's private non-blocking stream */
@@ -139,6 +140,7 @@ int socp_eval_batch(socp_ctx *ctx, int what, int B, const double *t, const doubl
 int socp_problem_set(socp_ctx *ctx, int num_multi, const int *mode_t, const int *mode_x,
                      const double *time, const double *xnode);
 int socp_problem_num_param(const socp_ctx *ctx);   /* n = 2 d M + #FREE times (shooting.cpp:179,196) */
+int socp_problem_num_nodes(const socp_ctx *ctx);   /* M + 1 of the problem set (< 0: none) */
 
 /* Per-problem blocks for the batch entry points below (batched continuation chains: shooting.cpp:598-692 blends the
  * boundary data of ONE problem per Newton solve, :695-778 moves ONE model parameter through a real&; with many chains in

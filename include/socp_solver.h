@@ -63,7 +63,7 @@ const double *socp_hybr_x(const socp_hybr *s);
 const double *socp_hybr_fvec(const socp_hybr *s);
 double socp_hybr_epsfcn(const socp_hybr *s);
 
-/* ---- lock-step multi-start (BASELINE config 4; the sequential continuation loops of
+/* ---- lock-step multi-start = socp_chains_solve with SOCP_CHAIN_PLAIN (BASELINE config 4; the sequential continuation loops of
  * shooting.cpp:598-778 solve one problem at a time -- a sweep over P independent starts does not have to).
  * P starts Z0[P][n] of the problem currently set on ctx (socp_problem_set); each start runs its own
  * hybrd state machine with the reference's knobs; per round all residual requests are one
@@ -74,6 +74,55 @@ struct socp_ctx;
 int socp_multistart_solve(struct socp_ctx *ctx, int P, const double *Z0, double xtol, int maxfev, double epsfcn,
                           double factor, int dedup, double *Zout, int *info, int *nfev, double *fnorm,
                           long long *rounds);
+
+/* ---- lock-step continuation chains.  The reference's two continuation loops are sequential: homotopy
+ * on the boundary data, (1-b) previous + b desired (shooting.cpp:598-692), and on one model parameter reached through a
+ * real& (shooting.cpp:695-778, shooting.hpp:120-128), each iteration one full Newton solve, with step bisection on failure
+ * (:627-648, b - b_prec below continuationStepMin ends the loop) and b += step on success.  Here P chains of ONE problem
+ * structure run those loops at once: every chain has its own homotopy state, hybrd state machine, packed parameters and
+ * boundary data; per round all residual requests are one launch and all Jacobian requests one launch.  Every chain's solves
+ * are, bit for bit, the ones shooting::SolveOCP(step[, Rdata, Rgoal]) of the host mirror performs for it alone. */
+#define SOCP_CHAIN_PLAIN 0   /* one Newton solve per chain: the multi-start sweep (SolveOCP(0)) */
+#define SOCP_CHAIN_PARAM 1   /* SolveOCP(step, Rdata, Rgoal): packed parameter `param_index` moves from its value to goal[p] */
+#define SOCP_CHAIN_DATA  2   /* SolveOCP(step): boundary data move from (time_prev, x_prev) to (time_goal, x_goal) */
+
+typedef struct socp_chain_options {
+    int kind;                 /* SOCP_CHAIN_* */
+    int param_index;          /* SOCP_CHAIN_PARAM: slot of the packed parameter block (SOCP_*_NPARAMS order) */
+    double step;              /* continuationStep > 0 (the mirror maps SolveOCP(<= 0, Rdata, Rgoal) to 1.0) */
+    double step_min;          /* continuationStepMin, shooting.cpp:89: 1e-12 */
+    double xtol;              /* hybrd knobs, shooting.cpp:95-105 */
+    int maxfev;
+    double epsfcn;
+    double factor;
+    int dedup;                /* launched FD Jacobians integrate only the segments a column can change */
+    int speculate;            /* residual requests evaluated as whole FD batches so that later Jacobian requests at an accepted
+                                 point need no launch: -1 = when the chip has idle SIMDs (default), 0 = never, 1 = always.
+                                 No iterate depends on it.  Environment SOCP_CHAINS_SPECULATE overrides. */
+} socp_chain_options;
+
+typedef struct socp_chain_stats {
+    long long rounds;                 /* launch rounds */
+    long long jacobians_launched;     /* Jacobian requests that needed trajectories */
+    long long jacobians_from_cache;   /* Jacobian requests formed from rows already in HBM */
+    long long speculative_rounds;     /* rounds in which residual requests ran as FD batches */
+    long long restarts;               /* Newton solves started after the first one of each chain (homotopy steps) */
+    double wall_ms;
+} socp_chain_stats;
+
+/* Host pointers.  Z0[P][n]: start of every chain (shooting's tab_param).  params: NULL (every chain uses the context's
+ * parameters) or [P][nparams].  goal[P]: SOCP_CHAIN_PARAM only.  time_prev[P][M+1], x_prev[P][(M+1)*2d], time_goal, x_goal:
+ * SOCP_CHAIN_DATA (only the first d entries of each node row are blended and read, as in shooting.cpp:609-611); for the
+ * other kinds time_goal / x_goal may give every chain its own fixed boundary data (NULL: the problem's).
+ * Outputs per chain (any but Zout / info may be NULL): Zout = the unknowns of the last CONVERGED solve (tab_param; the start
+ * if none converged) -- for SOCP_CHAIN_PLAIN the final iterate whatever info says, as socp_multistart_solve returns it;
+ * info / nfev_last of the last solve; nfev_total and solves over the chain; b_reached = largest homotopy value solved
+ * (1 = goal reached); param_final = the moving parameter at exit (the reference leaves Rdata there); fnorm = |F| of the last
+ * solve's final iterate. */
+int socp_chains_solve(struct socp_ctx *ctx, int P, const socp_chain_options *opt, const double *Z0, const double *params,
+                      const double *goal, const double *time_prev, const double *x_prev, const double *time_goal,
+                      const double *x_goal, double *Zout, int *info, int *nfev_last, int *nfev_total, int *solves,
+                      double *b_reached, double *param_final, double *fnorm, socp_chain_stats *stats);
 
 #ifdef __cplusplus
 }

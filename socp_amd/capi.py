@@ -33,6 +33,21 @@ FDJAC = C.CFUNCTYPE(C.c_int, _vp, C.c_int, _dp, _dp, C.c_double, _dp, C.c_int)
 _lib = None
 
 
+CHAIN_PLAIN, CHAIN_PARAM, CHAIN_DATA = 0, 1, 2
+
+
+class ChainOptions(C.Structure):
+    """socp_chain_options (include/socp_solver.h)."""
+    _fields_ = [("kind", C.c_int), ("param_index", C.c_int), ("step", C.c_double), ("step_min", C.c_double),
+                ("xtol", C.c_double), ("maxfev", C.c_int), ("epsfcn", C.c_double), ("factor", C.c_double),
+                ("dedup", C.c_int), ("speculate", C.c_int)]
+
+
+class ChainStats(C.Structure):
+    _fields_ = [("rounds", C.c_longlong), ("jacobians_launched", C.c_longlong), ("jacobians_from_cache", C.c_longlong),
+                ("speculative_rounds", C.c_longlong), ("restarts", C.c_longlong), ("wall_ms", C.c_double)]
+
+
 class SocpError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("libsocp_hip error %d: %s" % (code, msg))
@@ -94,6 +109,12 @@ def lib():
         L.socp_fd_rows.argtypes = [_vp, C.c_int, _dp, C.c_double, _dp]
         L.socp_fd_diff_dev.argtypes = [_vp, C.c_int, _vp, C.c_double, _vp, _vp]
         L.socp_plugin_load.argtypes = [C.c_char_p]
+        L.socp_problem_set_blocks_dev.argtypes = [_vp, _vp, C.c_int, _vp, _vp]
+        L.socp_residual_batch_blocks.argtypes = [_vp, C.c_int, _dp, _dp, C.c_int, _dp, _dp, _dp]
+        L.socp_problem_num_nodes.argtypes = [_vp]
+        L.socp_ctx_get_switching_times.argtypes = [_vp, _dp]
+        L.socp_chains_solve.argtypes = [_vp, C.c_int, C.POINTER(ChainOptions), _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _ip,
+                                        _ip, _dp, _dp, _dp, C.POINTER(ChainStats)]
         L.socp_multistart_solve.argtypes = [_vp, C.c_int, _dp, C.c_double, C.c_int, C.c_double, C.c_double, C.c_int,
                                             _dp, _ip, _ip, _dp, C.POINTER(C.c_longlong)]
         L.hybrd.argtypes = [FCN, _vp, C.c_int, _dp, _dp, C.c_double, C.c_int, C.c_int, C.c_int, C.c_double,
@@ -342,6 +363,54 @@ class Context:
                                                int(bool(dedup)), _d(Z), info.ctypes.data_as(_ip),
                                                nfev.ctypes.data_as(_ip), _d(fnorm), C.byref(rounds)))
         return dict(z=Z, info=info, nfev=nfev, fnorm=fnorm, rounds=rounds.value)
+
+    def residual_batch_blocks(self, Z, params=None, time=None, xnode=None):
+        """Residual of every row of Z with that row's OWN parameter block [B][nparams + 2] (parameters, sw0, sw1) and / or
+        boundary tables time [B][M+1], xnode [B][(M+1)*2d] (None: the shared ones)."""
+        Z = _f64(Z).reshape(-1, self.n)
+        B = Z.shape[0]
+        F = np.empty_like(Z)
+        pp = _f64(params).reshape(B, -1) if params is not None else None
+        tt = _f64(time).reshape(B, -1) if time is not None else None
+        xx = _f64(xnode).reshape(B, -1) if xnode is not None else None
+        self._chk(self.L.socp_residual_batch_blocks(self.h, B, _d(Z), _d(pp) if pp is not None else None,
+                                                    pp.shape[1] if pp is not None else 0, _d(tt) if tt is not None else None,
+                                                    _d(xx) if xx is not None else None, _d(F)))
+        return F
+
+    def chains_solve(self, Z0, kind=CHAIN_PLAIN, param_index=0, step=1.0, step_min=1e-12, goal=None, params=None,
+                     time_prev=None, x_prev=None, time_goal=None, x_goal=None, xtol=1e-8, maxfev=10000, epsfcn=1e-15,
+                     factor=1.0, dedup=True, speculate=-1):
+        """Lock-step continuation chains (socp_chains_solve).  Returns a dict of per-chain arrays + 'stats'."""
+        Z0 = _f64(Z0).reshape(-1, self.n)
+        P = Z0.shape[0]
+        opt = ChainOptions(int(kind), int(param_index), float(step), float(step_min), float(xtol), int(maxfev), float(epsfcn),
+                           float(factor), int(bool(dedup)), int(speculate))
+        keep = []
+
+        def arr(a, width=None):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64), (P,) if width is None else (P, width)))
+            keep.append(a)
+            return _d(a)
+        nodes = self.L.socp_problem_num_nodes(self.h)
+        Z = np.empty_like(Z0)
+        info = np.zeros(P, dtype=np.int32)
+        nfev_last = np.zeros(P, dtype=np.int32)
+        nfev_total = np.zeros(P, dtype=np.int32)
+        solves = np.zeros(P, dtype=np.int32)
+        b = np.zeros(P)
+        pf = np.zeros(P)
+        fn = np.zeros(P)
+        st = ChainStats()
+        ip = lambda a: a.ctypes.data_as(_ip)  # noqa: E731
+        self._chk(self.L.socp_chains_solve(self.h, P, C.byref(opt), _d(Z0), arr(params, len(self.get_params())), arr(goal),
+                                           arr(time_prev, nodes), arr(x_prev, nodes * self.s), arr(time_goal, nodes),
+                                           arr(x_goal, nodes * self.s), _d(Z), ip(info), ip(nfev_last), ip(nfev_total), ip(solves),
+                                           _d(b), _d(pf), _d(fn), C.byref(st)))
+        return dict(z=Z, info=info, nfev=nfev_last, nfev_total=nfev_total, solves=solves, b_reached=b, param_final=pf, fnorm=fn,
+                    stats={k: getattr(st, k) for k, _ in ChainStats._fields_})
 
     def fd_jacobian_dev(self, d_z, d_fvec, epsfcn, d_fjac, dedup=False):
         self._chk(self.L.socp_fd_jacobian_dev(self.h, _vp(d_z), _vp(d_fvec), float(epsfcn), _vp(d_fjac),

@@ -108,8 +108,6 @@ extern "C" int socp_chains_solve(socp_ctx *ctx, int P, const socp_chain_options 
     if (n <= 0) return SOCP_ERR_ARG;
     int dim = 0, S = 0;
     socp_ctx_dims(ctx, &dim, &S, nullptr);
-    const int M = (n - 0) >= S ? 0 : 0;     // placeholder, set below
-    (void)M;
     int nparams = 0;
     double shared_params[SOCP_MAX_NPARAMS + 2] = {0};
     {
@@ -235,8 +233,6 @@ extern "C" int socp_chains_solve(socp_ctx *ctx, int P, const socp_chain_options 
     const double t_setup = ms_since(t_begin);
     int rc = SOCP_OK;
     std::vector<int> reqF, reqJ, reqJc, accepted;
-    const double eps = std::sqrt(std::max(opt->epsfcn, 2.220446049250313e-16));
-    (void)eps;
 
     // chain logic at the end of one Newton solve: the bisection rules of shooting.cpp:627-660 / 724-760
     auto solve_finished = [&](int p) {
@@ -273,7 +269,6 @@ extern "C" int socp_chains_solve(socp_ctx *ctx, int P, const socp_chain_options 
         c.stage_idx = -1;
         c.flag = 0;
         c.need_advance = true;
-        restarts++;
     };
 
     for (;;) {
@@ -356,11 +351,9 @@ extern "C" int socp_chains_solve(socp_ctx *ctx, int P, const socp_chain_options 
         if (spec_on && kF) {
             if (speculate > 0) kS = kF;
             else {
-                const long wavesJ = ((long)kJ * n * segs + 63) / 64;
-                const long budget = 1024 - wavesJ - ((long)kF * segs + 63) / 64;
-                const long per = ((long)(n + 1) * segs + 63) / 64;          // upper bound of the extra waves of one request
-                kS = budget <= 0 ? 0 : (int)std::min<long>(kF, budget * 64 / std::max<long>(1, (long)n * segs));
-                (void)per;
+                // lanes: kS (n+1) segs + (kF - kS) segs + the Jacobian launch <= 1024 waves x 64
+                const long lanes = (1024 - ((long)kJ * n * segs + 63) / 64) * 64 - (long)kF * segs;
+                kS = lanes <= 0 ? 0 : (int)std::min<long>(kF, lanes / ((long)n * segs));
             }
         }
         if (trace) std::fprintf(stderr, "[socp_chains] round %lld: %d residual requests (%d as FD batches), %d Jacobian requests\n", rounds, kF, kS, kJ);
@@ -464,6 +457,7 @@ extern "C" int socp_chains_solve(socp_ctx *ctx, int P, const socp_chain_options 
             }
         }
     }
+    for (int p = 0; p < P; p++) restarts += std::max(0, ch[p].solves - 1);
     if (trace)
         std::fprintf(stderr, "[socp_chains] set-up %.1f ms, host advance %.1f ms, launches + wait (Jacobian rounds) %.1f ms, Jacobian read-back + scatter %.1f ms, "
                              "total %.1f ms; %lld rounds, %lld Jacobians launched, %lld from cached rows, %lld solver restarts\n",

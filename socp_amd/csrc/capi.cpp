@@ -280,6 +280,13 @@ int socp_ctx_set_switching_times(socp_ctx *c, const double *sw, int nsw)
     return SOCP_OK;
 }
 
+int socp_ctx_get_switching_times(const socp_ctx *c, double *sw2)
+{
+    if (!c || !sw2) return SOCP_ERR_ARG;
+    sw2[0] = c->P.sw0; sw2[1] = c->P.sw1;
+    return SOCP_OK;
+}
+
 int socp_ctx_set_variant(socp_ctx *c, int variant)
 {
     if (!c) return SOCP_ERR_ARG;
@@ -623,6 +630,7 @@ int socp_residual_batch_blocks(socp_ctx *c, int B, const double *Z, const double
     return rc;
 }
 
+int socp_problem_num_nodes(const socp_ctx *c) { return (c && c->has_problem) ? c->M + 1 : SOCP_ERR_ARG; }
 int socp_problem_num_param(const socp_ctx *c) { return (c && c->has_problem) ? c->n : SOCP_ERR_ARG; }
 
 int socp_timeline(socp_ctx *c, const double *z, double *tl)

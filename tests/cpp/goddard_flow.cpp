@@ -151,7 +151,16 @@ int main(int argc, char **argv)
     int info = 0;
     switch (stage) {
     case 1: my_goddard.SetParameterDataName("KD", 0.0); info = my_shooting.SolveOCP(0.0); report("no_drag", info, my_shooting); break;
-    case 2: my_goddard.SetParameterDataName("KD", 0.0); info = my_shooting.SolveOCP(1.0, "KD", 310.0); report("drag_continuation", info, my_shooting); break;
+    case 2: {
+        // SOCP_FLOW_KD_GOAL / SOCP_FLOW_STEP / SOCP_FLOW_KD_START: other goals, continuation steps and start values of the same
+        // parameter continuation (the sequential twin of the batched chains, tests/test_gpu_chains.py)
+        const char *kg = std::getenv("SOCP_FLOW_KD_GOAL"), *ks = std::getenv("SOCP_FLOW_STEP"), *k0 = std::getenv("SOCP_FLOW_KD_START");
+        my_goddard.SetParameterDataName("KD", k0 ? std::atof(k0) : 0.0);
+        info = my_shooting.SolveOCP(ks ? std::atof(ks) : 1.0, "KD", kg ? std::atof(kg) : 310.0);
+        report("drag_continuation", info, my_shooting);
+        std::printf("{\"KD_final\": %.17g}\n", my_goddard.GetParameterDataName("KD"));
+        break;
+    }
     case 3: info = my_shooting.SolveOCP(1.0, "mu2", 0.2); report("mu2_continuation", info, my_shooting); break;
     case 4: my_goddard.SetParameterDataName("mu2", 0.2); info = singular_stage(my_goddard, my_shooting, dim); report("singular_arc", info, my_shooting); break;
     default: return 64;

@@ -1,0 +1,228 @@
+"""GPU: batched continuation chains (socp_chains_solve) and the per-problem blocks under them.
+
+The reference's continuation loops are sequential (shooting.cpp:598-692 on the boundary data, :695-778 on one model parameter);
+the engine runs P chains of one problem structure in lock-step.  The bar: every chain's solves are bit-identical to the
+sequential loop run for that chain alone -- checked against (a) the C++ host mirror itself (`goddard_flow stage 2` =
+shooting::SolveOCP(step, "KD", goal), tests/cpp/goddard_flow.cpp) and (b) a sequential restatement of the same loop over the
+one-problem C-ABI entry points the mirror calls (socp_problem_set / socp_hybrd_batched / socp_residual_batch / socp_fd_jacobian),
+for every chain; bisection after a failed solve included."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "goddard_flow.json")))
+STAGE2_INIT = np.array([g for g in GOLD["goddard_single_stage"] if g["stage"] == 2 and g["xtol"] == 1e-6][0]["init_z"])
+PARAMS0 = [3.5, 7.0, 0.0, 500.0, 1.0, 1.0, 1.0, -1.0]            # testGoddard before its KD continuation: KD = 0, mu2 = 1
+KD = 2
+
+
+def goddard_m6(ctx, x_final0=1.01):
+    """The testGoddard layout (testGoddard.cpp:24-82): M = 6, tf FREE, final velocity and mass free; node times from the
+    stage-2 start (uniform grid up to its tf)."""
+    from socp_amd import capi
+    M, d = 6, 7
+    mode_t = [capi.FIXED] + [capi.CONTINUOUS] * (M - 1) + [capi.FREE]
+    mode_x = np.zeros((M + 1, d), dtype=np.int32)
+    mode_x[1:M] = capi.CONTINUOUS
+    mode_x[M, 3:7] = capi.FREE
+    tf = STAGE2_INIT[-1]
+    time = np.array([0.0 + i * (tf - 0.0) / M for i in range(M + 1)])
+    X = np.zeros((M + 1, 14))
+    X[:M] = STAGE2_INIT[:84].reshape(M, 14)
+    X[M, 0] = x_final0
+    assert ctx.problem_set(mode_t, mode_x, time, X) == 85
+    return mode_t, mode_x, time, X
+
+
+def make_ctx(variant="exact", steps=10):
+    from socp_amd import capi
+    ctx = capi.Context(capi.MODEL_GODDARD)
+    ctx.set_params(PARAMS0)
+    ctx.set_step_number(steps)
+    ctx.set_variant(capi.VARIANT_LANE_EXACT if variant == "exact" else capi.VARIANT_LANE_FAST)
+    return ctx
+
+
+def sequential_solve(ctx, z, xtol):
+    """One Newton solve exactly as shooting::SolveShootingFunction of the mirror performs it (shooting.cpp:433-452 there)."""
+    from socp_amd import capi
+    r = capi.hybrd(lambda v: ctx.residual(v), z, xtol=xtol, epsfcn=1e-15, factor=1.0,
+                   fdjac=lambda v, f, e: ctx.fd_jacobian(v, f, epsfcn=e, dedup=True))
+    return r["info"], r["x"], r["nfev"]
+
+
+def sequential_chain(ctx, z0, step, step_min, xtol, set_b):
+    """shooting::SolveShootingContinuation (both forms share this skeleton): set_b(b) installs the blended data."""
+    b, b_prec = min(step, 1.0), 0.0
+    set_b(b)
+    committed, temp = z0.copy(), z0.copy()
+    solves, nfev_total = 0, 0
+    while True:
+        info, x, nfev = sequential_solve(ctx, temp, xtol)
+        solves += 1
+        nfev_total += nfev
+        if info != 1:
+            stop = abs(b - b_prec) < step_min
+            b = b_prec + (b - b_prec) / 2
+            temp = committed.copy()
+            set_b(b)
+            if stop:
+                break
+        elif b == 1:
+            committed = x.copy()
+            break
+        else:
+            b_prec = b
+            b = min(b + step, 1.0)
+            committed = x.copy()
+            temp = x.copy()
+            set_b(b)
+    return dict(z=committed, info=info, nfev=nfev, nfev_total=nfev_total, solves=solves, b=b if info == 1 else b_prec)
+
+
+@pytest.mark.parametrize("variant", ["exact", "fast"])
+def test_per_problem_blocks_equal_one_problem_at_a_time(variant):
+    """Row q of a batch with its own (parameters, boundary data) == the residual of that problem evaluated alone with the
+    shared-parameter kernels: bit for bit in the reference-order flavour (the PERPROB instantiation changes where the
+    parameters live, not the arithmetic), to rounding in the throughput flavour; including a row whose control law differs
+    from the others' (mu2 = 0: bang / singular / off)."""
+    ctx = make_ctx(variant)
+    mode_t, mode_x, time, X = goddard_m6(ctx)
+    rng = np.random.default_rng(5)
+    B = 9
+    Z = STAGE2_INIT[None, :] * (1 + 1e-3 * rng.uniform(-1, 1, (B, 85)))
+    P = np.tile(np.array(PARAMS0 + [0.0227, 0.08]), (B, 1))
+    P[:, KD] = np.linspace(0.0, 400.0, B)
+    P[3, 6] = 0.0                                     # one row on the imposed bang / singular / off law
+    P[4, 6] = 0.2
+    T = np.tile(time, (B, 1)) * (1 + 1e-2 * rng.uniform(-1, 1, (B, 1)))
+    T[:, 0] = 0.0
+    XN = np.tile(X.ravel(), (B, 1))
+    XN[:, 6 * 14] = 1.01 + 1e-3 * np.arange(B)        # final altitude target per row
+    F = ctx.residual_batch_blocks(Z, params=P, time=T, xnode=XN)
+    F_p = ctx.residual_batch_blocks(Z, params=P)      # parameters only
+    F_b = ctx.residual_batch_blocks(Z, time=T, xnode=XN)
+
+    def same(a, b):
+        # exact flavour: no contraction, IEEE operations in one order => the same bits from any instantiation.  The
+        # throughput flavour is compiled with FMA contraction, which the compiler applies per instantiation (the per-problem
+        # kernel is the general-law one, the shared-parameter launch may pick the smooth-law specialisation): rounding level.
+        if variant == "exact":
+            return np.array_equal(a, b)
+        return np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))) <= 1e-12
+    for q in range(B):
+        ctx.set_params(P[q, :8])
+        ctx.set_switching_times(P[q, 8:])
+        ctx.problem_set(mode_t, mode_x, T[q], XN[q].reshape(7, 14))
+        assert same(F[q], ctx.residual(Z[q])), q
+        ctx.problem_set(mode_t, mode_x, time, X)
+        assert same(F_p[q], ctx.residual(Z[q])), q
+        ctx.set_params(PARAMS0)
+        ctx.set_switching_times([0.0227, 0.08])
+        ctx.problem_set(mode_t, mode_x, T[q], XN[q].reshape(7, 14))
+        assert same(F_b[q], ctx.residual(Z[q])), q
+    ctx.problem_set(mode_t, mode_x, time, X)
+    assert not np.array_equal(F[1], F[2])
+    ctx.close()
+
+
+def test_kd_continuation_chains_equal_the_sequential_loop_and_the_cpp_mirror(tmp_path):
+    """P chains of testGoddard's KD continuation (SolveOCP(step, "KD", goal)), every chain its own goal; some with a step
+    < 1, one with a goal far enough that a solve fails and the step is bisected."""
+    ctx = make_ctx("exact")
+    goddard_m6(ctx)
+    goals = np.array([310.0, 250.0, 400.0, 310.0, 120.0, 5000.0, 310.0, 600.0])
+    P = len(goals)
+    Z0 = np.tile(STAGE2_INIT, (P, 1))
+    Z0[3, 7:14] *= 1 + 1e-6                          # one chain starts elsewhere
+    for step in (1.0, 0.4):
+        res = ctx.chains_solve(Z0, kind=1, param_index=KD, step=step, goal=goals, params=np.tile(PARAMS0, (P, 1)), xtol=1e-6)
+        assert res["stats"]["rounds"] > 0
+        seq = []
+        for p in range(P):
+            def set_b(b, goal=goals[p]):
+                ctx.set_param("KD", (1 - b) * 0.0 + b * goal)
+            seq.append(sequential_chain(ctx, Z0[p], step, 1e-12, 1e-6, set_b))
+            ctx.set_params(PARAMS0)
+        for p in range(P):
+            assert res["info"][p] == seq[p]["info"], (step, p)
+            assert np.array_equal(res["z"][p], seq[p]["z"]), (step, p)
+            assert res["solves"][p] == seq[p]["solves"] and res["nfev_total"][p] == seq[p]["nfev_total"], (step, p)
+            assert res["nfev"][p] == seq[p]["nfev"]
+            assert res["b_reached"][p] == seq[p]["b"]
+        assert np.all(res["info"][[0, 1, 2, 3, 4]] == 1) and np.all(res["param_final"][[0, 1, 2]] == goals[[0, 1, 2]])
+        if step == 1.0:
+            assert np.max(res["solves"]) > 1 or np.any(res["info"] != 1)            # the far goal needed bisection (or gave up)
+            gold2 = [g for g in GOLD["goddard_single_stage"] if g["stage"] == 2 and g["xtol"] == 1e-6][0]
+            assert np.array_equal(res["z"][0], np.array(gold2["z"])) and res["nfev"][0] == gold2["nfev"]     # testGoddard's own stage 2 (CPU golden)
+    # the C++ host mirror itself, for three of the chains (goal 310 is testGoddard's own stage 2)
+    exe = os.path.join(ROOT, "socp_amd", "_build", "bin", "goddard_flow")
+    res = ctx.chains_solve(Z0, kind=1, param_index=KD, step=1.0, goal=goals, params=np.tile(PARAMS0, (P, 1)), xtol=1e-6)
+    for p in (0, 2, 5):
+        zf = tmp_path / ("z%d.txt" % p)
+        zf.write_text(" ".join(repr(float(v)) for v in Z0[p]))
+        out = subprocess.run([exe, "stage", "2", "10", "1", "1e-6", str(zf)], capture_output=True, text=True, timeout=600,
+                             env=dict(os.environ, SOCP_VARIANT="exact", SOCP_FLOW_KD_GOAL=repr(float(goals[p]))))
+        recs = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+        assert recs and recs[0]["info"] == res["info"][p], (p, out.returncode, out.stdout[-500:], out.stderr[-500:])
+        assert np.array_equal(np.array(recs[0]["z"]), res["z"][p]), p
+        assert recs[0]["nfev"] == res["nfev"][p]
+        assert recs[1]["KD_final"] == res["param_final"][p]
+    ctx.close()
+
+
+def test_boundary_data_chains_equal_the_sequential_loop():
+    """SolveOCP(step): homotopy on the boundary data, (1 - b) previous + b desired (shooting.cpp:598-692) -- here the final
+    altitude target of every chain moves from 1.01 to its own goal, KD = 310 (testGoddard's state after its stage 2)."""
+    ctx = make_ctx("exact")
+    ctx.set_param("KD", 310.0)
+    mode_t, mode_x, time, X = goddard_m6(ctx)
+    z_conv = np.array(GOLD["goddard_N10_M6"][1]["z"])              # converged with drag
+    goals = np.array([1.0102, 1.0105, 1.011, 1.03])
+    P = len(goals)
+    Xp = np.tile(X.ravel(), (P, 1))
+    Xg = Xp.copy()
+    Xg[:, 6 * 14] = goals
+    Tp = np.tile(time, (P, 1))
+    Z0 = np.tile(z_conv, (P, 1))
+    for step in (1.0, 0.5):
+        res = ctx.chains_solve(Z0, kind=2, step=step, time_prev=Tp, x_prev=Xp, time_goal=Tp, x_goal=Xg, xtol=1e-6)
+        for p in range(P):
+            def set_b(b, p=p):
+                Xb = X.copy()
+                Xb[6, 0] = (1 - b) * 1.01 + b * goals[p]
+                ctx.problem_set(mode_t, mode_x, (1 - b) * time + b * time, Xb)
+            s = sequential_chain(ctx, Z0[p], step, 1e-12, 1e-6, set_b)
+            assert res["info"][p] == s["info"] and np.array_equal(res["z"][p], s["z"]), (step, p)
+            assert res["solves"][p] == s["solves"] and res["nfev_total"][p] == s["nfev_total"], (step, p)
+        assert np.all(res["info"][:3] == 1)
+        ctx.problem_set(mode_t, mode_x, time, X)
+    ctx.close()
+
+
+@pytest.mark.parametrize("variant", ["exact", "fast"])
+def test_speculative_jacobians_change_no_iterate(variant):
+    """Residual requests evaluated as whole FD batches (speculate = 1) / never (0) / when the chip has idle SIMDs (-1): same
+    solutions, same evaluation counts, fewer launch rounds and no launched Jacobian when every request is speculated."""
+    from socp_amd import sweep
+    ctx = make_ctx(variant, steps=200)
+    ctx.set_params(sweep.GODDARD_PARAMS)
+    sweep.goddard_single_shooting_problem(ctx)
+    Z0 = sweep.goddard_starts(96, 1e-3)
+    runs = {s: ctx.chains_solve(Z0, kind=0, xtol=1e-8, speculate=s) for s in (0, 1, -1)}
+    for s in (1, -1):
+        for key in ("z", "info", "nfev", "fnorm"):
+            assert np.array_equal(runs[0][key], runs[s][key]), (s, key)
+    assert runs[0]["stats"]["jacobians_from_cache"] == 0 and runs[0]["stats"]["jacobians_launched"] > 0
+    assert runs[1]["stats"]["jacobians_launched"] == 0 and runs[1]["stats"]["jacobians_from_cache"] == runs[0]["stats"]["jacobians_launched"]
+    assert runs[1]["stats"]["rounds"] < runs[0]["stats"]["rounds"]
+    assert runs[-1]["stats"]["rounds"] == runs[1]["stats"]["rounds"]              # 96 starts: everything fits the idle SIMDs
+    # multi-start through the old entry point = the same engine
+    ms = ctx.multistart_solve(Z0, xtol=1e-8)
+    assert np.array_equal(ms["z"], runs[0]["z"]) and np.array_equal(ms["info"], runs[0]["info"])
+    ctx.close()
