@@ -99,7 +99,12 @@ typedef struct socp_chain_options {
     int speculate;            /* residual requests evaluated as whole FD batches so that later Jacobian requests at an accepted
                                  point need no launch: -1 = when the chip has idle SIMDs (default), 0 = never, 1 = always.
                                  No iterate depends on it.  Environment SOCP_CHAINS_SPECULATE overrides. */
+    int max_rounds;           /* 0 = no limit.  > 0: chains still solving after that many launch rounds are stopped with
+                                 info = SOCP_INFO_ROUND_LIMIT, like a callback returning < 0 (shooting.cpp:873): a sweep's wall
+                                 time is rounds x one trajectory latency and the round count is set by its slowest chain
+                                 (typically one that ends in info 4/5 anyway).  The other chains' iterates do not change. */
 } socp_chain_options;
+#define SOCP_INFO_ROUND_LIMIT (-3)
 
 typedef struct socp_chain_stats {
     long long rounds;                 /* launch rounds */

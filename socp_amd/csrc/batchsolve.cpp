@@ -228,6 +228,7 @@ extern "C" int socp_chains_solve(socp_ctx *ctx, int P, const socp_chain_options 
     hipStream_t main_stream = static_cast<hipStream_t>(main_stream_v);
     hipStream_t fstream = overlap ? aux : main_stream;      // residual-type work (and everything speculative) goes here
 
+    bool round_limit_hit = false;
     long long rounds = 0, spec_rows_rounds = 0, jac_from_cache = 0, jac_launched = 0, restarts = 0;
     double t_adv = 0, t_gpu = 0, t_copy = 0;
     const double t_setup = ms_since(t_begin);
@@ -247,6 +248,7 @@ extern "C" int socp_chains_solve(socp_ctx *ctx, int P, const socp_chain_options 
             c.finished = true;
             return;
         }
+        if (c.info < 0) { c.finished = true; return; }             // aborted (round limit): no further homotopy step
         bool running = true;
         std::vector<double> next;                                  // tab_param_temp for the next solve
         if (c.info != 1) {
@@ -342,6 +344,13 @@ extern "C" int socp_chains_solve(socp_ctx *ctx, int P, const socp_chain_options 
         }
         t_adv += ms_since(ta);
         if (reqF.empty() && reqJ.empty()) break;
+        if (opt->max_rounds > 0 && rounds >= opt->max_rounds) {
+            // round budget spent: the chains still solving stop the way a negative callback return stops hybrd
+            for (int p : reqF) { ch[p].flag = SOCP_INFO_ROUND_LIMIT; ch[p].need_advance = true; }
+            for (int p : reqJ) { ch[p].flag = SOCP_INFO_ROUND_LIMIT; ch[p].need_advance = true; }
+            round_limit_hit = true;
+            continue;
+        }
         rounds++;
         const clk::time_point tg = clk::now();
         const int kF = (int)reqF.size(), kJ = (int)reqJ.size();
@@ -458,6 +467,7 @@ extern "C" int socp_chains_solve(socp_ctx *ctx, int P, const socp_chain_options 
         }
     }
     for (int p = 0; p < P; p++) restarts += std::max(0, ch[p].solves - 1);
+    if (trace && round_limit_hit) std::fprintf(stderr, "[socp_chains] round limit %d reached: the chains still solving were stopped\n", opt->max_rounds);
     if (trace)
         std::fprintf(stderr, "[socp_chains] set-up %.1f ms, host advance %.1f ms, launches + wait (Jacobian rounds) %.1f ms, Jacobian read-back + scatter %.1f ms, "
                              "total %.1f ms; %lld rounds, %lld Jacobians launched, %lld from cached rows, %lld solver restarts\n",

@@ -142,6 +142,16 @@ def main():
     ap.add_argument("--rk4-steps", type=int, default=10000)
     ap.add_argument("--xtol", type=float, default=1e-8)
     ap.add_argument("--variant", choices=["exact", "fast"], default="fast")
+    ap.add_argument("--continuation", choices=["none", "kd"], default="none",
+                    help="kd: every start is a CHAIN of testGoddard's drag continuation, SolveOCP(step, \"KD\", goal) "
+                         "(shooting.cpp:695-778), started from the no-drag solution of the test (tests/golden) with node-0 "
+                         "costates perturbed by --eps; all chains advance in lock-step (socp_chains_solve)")
+    ap.add_argument("--kd-goal", type=float, default=310.0)
+    ap.add_argument("--kd-spread", type=float, default=0.0, help="chain p's goal = kd-goal * (1 + spread * xi_p), xi uniform(-1, 1)")
+    ap.add_argument("--step", type=float, default=1.0, help="continuationStep of the chains")
+    ap.add_argument("--max-rounds", type=int, default=0, help="socp_chain_options.max_rounds: stop chains still solving after "
+                    "that many launch rounds (info = -3); 0 = no limit")
+    ap.add_argument("--speculate", type=int, default=-1, help="socp_chain_options.speculate: -1 auto, 0 never, 1 always")
     args = ap.parse_args()
 
     import torch
@@ -161,9 +171,24 @@ def main():
     ctx.set_params(GODDARD_PARAMS)
     ctx.set_step_number(args.rk4_steps)
     ctx.set_variant(capi.VARIANT_LANE_FAST if args.variant == "fast" else capi.VARIANT_LANE_EXACT)
-    eps = args.eps if args.eps is not None else (1e-3 if args.segments == 1 else 0.05)
+    eps = args.eps if args.eps is not None else (1e-3 if (args.segments == 1 and args.continuation == "none") else 0.05)
     Z0 = goddard_starts(args.starts, eps)
-    if args.segments == 1:
+    chain_kw = None
+    if args.continuation == "kd":
+        # testGoddard's state before its KD continuation: M = 6, free tf, KD = 0, the converged no-drag unknowns
+        import json as _json
+        gold = _json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "goddard_flow.json")))
+        z_nd = np.array([g for g in gold["goddard_single_stage"] if g["stage"] == 2 and g["xtol"] == 1e-6][0]["init_z"])
+        args.segments = 6
+        goddard_multiple_shooting_problem(ctx, 6, tf=z_nd[-1])
+        xi = (Z0[:, 7:] / PSTAR - 1.0) / eps                              # the sweep's own uniform(-1, 1) draws
+        Z0 = np.tile(z_nd, (args.starts, 1))
+        Z0[:, 7:14] *= 1.0 + eps * xi
+        params = np.tile(np.array(GODDARD_PARAMS), (args.starts, 1))
+        params[:, 2] = 0.0
+        goals = args.kd_goal * (1.0 + args.kd_spread * xi[:, 0])
+        chain_kw = dict(kind=capi.CHAIN_PARAM, param_index=2, step=args.step, speculate=args.speculate)
+    elif args.segments == 1:
         goddard_single_shooting_problem(ctx)
     else:
         goddard_multiple_shooting_problem(ctx, args.segments)
@@ -177,7 +202,19 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    table, local = run_sweep(Z0, lambda Zb: ctx.multistart_solve(Zb, xtol=args.xtol), dist if world > 1 else None, dev)
+    stats = {}
+
+    def solve_block(Zb):
+        lo, hi = shard(args.starts, rank, world)
+        if chain_kw is not None:
+            r = ctx.chains_solve(Zb, goal=goals[lo:hi], params=params[lo:hi], xtol=args.xtol, max_rounds=args.max_rounds, **chain_kw)
+        else:
+            r = ctx.chains_solve(Zb, kind=capi.CHAIN_PLAIN, xtol=args.xtol, speculate=args.speculate, max_rounds=args.max_rounds)
+        stats.update(r["stats"])
+        stats["solves"] = int(np.sum(r["solves"]))
+        r["rounds"] = r["stats"]["rounds"]
+        return r
+    table, local = run_sweep(Z0, solve_block, dist if world > 1 else None, dev)
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -190,9 +227,13 @@ def main():
         conv = table[info == 1, :n_unknown]
         spread = float(np.max(np.abs(conv - np.median(conv, axis=0))) / np.max(np.abs(conv))) if len(conv) else None
         print(json.dumps({"solution_spread_rel": spread, "max_fnorm_converged": float(np.max(table[info == 1, -3])) if len(conv) else None,
-                          "sweep": "goddard_single_shooting_n14" if args.segments == 1 else "goddard_multiple_shooting_M%d_n%d" % (args.segments, n_unknown),
+                          "sweep": ("goddard_kd_continuation_chains_M6_n85" if chain_kw is not None else
+                                    "goddard_single_shooting_n14" if args.segments == 1 else "goddard_multiple_shooting_M%d_n%d" % (args.segments, n_unknown)),
+                          "chains_per_s": (args.starts / wall) if chain_kw is not None else None,
+                          "continuation": None if chain_kw is None else {"parameter": "KD", "from": 0.0, "goal": args.kd_goal, "goal_spread": args.kd_spread, "step": args.step},
+                          "engine_rank0": stats,
                           "starts": args.starts, "eps": eps, "n_gpus": world,
-                          "rk4_steps": args.rk4_steps, "variant": args.variant, "xtol": args.xtol, "wall_s": wall,
+                          "rk4_steps": args.rk4_steps, "variant": args.variant, "xtol": args.xtol, "wall_s": wall, "max_rounds": args.max_rounds,
                           "converged": int(np.sum(info == 1)), "info_histogram": {str(k): int(np.sum(info == k)) for k in np.unique(info)},
                           "trajectories": int(traj.item()), "trajectories_per_s": traj.item() / wall,
                           "solves_per_s": args.starts / wall, "rounds_rank0": int(local["rounds"]),

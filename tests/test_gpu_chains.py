@@ -226,3 +226,22 @@ def test_speculative_jacobians_change_no_iterate(variant):
     ms = ctx.multistart_solve(Z0, xtol=1e-8)
     assert np.array_equal(ms["z"], runs[0]["z"]) and np.array_equal(ms["info"], runs[0]["info"])
     ctx.close()
+
+
+def test_round_limit_stops_stragglers_only():
+    """max_rounds: chains still solving after the budget get info = -3 (the negative-callback abort of shooting.cpp:873);
+    every chain that finished within the budget has exactly the result it has without a limit."""
+    from socp_amd import sweep
+    ctx = make_ctx("exact", steps=200)
+    ctx.set_params(sweep.GODDARD_PARAMS)
+    sweep.goddard_single_shooting_problem(ctx)
+    Z0 = sweep.goddard_starts(64, 3e-3)               # wide enough that the starts need different numbers of rounds
+    full = ctx.chains_solve(Z0, kind=0, xtol=1e-8)
+    limit = int(np.sort(full["nfev"])[len(Z0) // 2] // 14 + 6)          # about the median start's number of rounds
+    cut = ctx.chains_solve(Z0, kind=0, xtol=1e-8, max_rounds=limit)
+    assert cut["stats"]["rounds"] == limit < full["stats"]["rounds"]
+    stopped = cut["info"] == -3
+    assert 0 < stopped.sum() < len(Z0)
+    assert np.array_equal(cut["z"][~stopped], full["z"][~stopped]) and np.array_equal(cut["info"][~stopped], full["info"][~stopped])
+    assert np.array_equal(cut["nfev"][~stopped], full["nfev"][~stopped])
+    ctx.close()
