@@ -4,8 +4,10 @@
 // members, the FIXED/FREE/CONTINUOUS enum) so existing user programs and model classes compile
 // unchanged.  New here is the device hook: a model that has a hand-written gfx950 twin of its
 // dynamics reports it through DeviceModelId()/DeviceParams(); ModelInt(), and everything that
-// integrates, then runs on the GPU through the C-ABI (include/socp_hip.h).  A model without a
-// device twin cannot be integrated by this library (std::runtime_error): there is no CPU path.
+// integrates, then runs on the GPU through the C-ABI (include/socp_hip.h); for those models (all in-tree ones) there is
+// no CPU path and no GPU is an error.  A user class WITHOUT a device twin -- only the reference's host virtuals -- still
+// works: odeTools::integrate runs the reference's loop over its virtual Model() on the host and shooting assembles the
+// residual from its virtuals (one-line warning; CPU speed), see odeTools.cpp / shooting.cpp of this mirror.
 #ifndef SOCP_AMD_MODEL_HPP_
 #define SOCP_AMD_MODEL_HPP_
 

@@ -3,8 +3,9 @@
 // Same class name, nested types, members and signatures, so user programs and models written
 // against the reference compile unchanged.  What differs is where the work happens: integrate()
 // hands the whole segment to the gfx950 kernels through the C-ABI (include/socp_hip.h) when the
-// object is a model with device dynamics, and fails loudly otherwise.  There is no host RK4
-// loop in this library.
+// object is a model with device dynamics.  In-tree models always have them: for those there is no host loop and no GPU means
+// an error.  A user class that overrides only the reference's host virtuals (DeviceModelId() == 0) is integrated by the
+// reference's own loop on the host, with a one-line warning -- the plugin surface keeps working, at CPU speed.
 #ifndef SOCP_AMD_ODETOOLS_HPP_
 #define SOCP_AMD_ODETOOLS_HPP_
 
@@ -54,9 +55,8 @@ public:
     static odeVector MultState(real a, odeVector const &X);
     static odeVector AddState(odeVector const &X, odeVector const &Y);
 
-    // One-step helpers of the reference API (odeTools.hpp:107-165).  They take arbitrary host
-    // callbacks, which cannot run on the device; they are declared for source compatibility and
-    // throw std::logic_error -- segments are integrated through integrate() only.
+    // One-step helpers of the reference API (odeTools.hpp:107-165; operation order of odeTools.cpp:46-98).  They take
+    // arbitrary host callbacks and run on the host (interceptor.cpp:117 uses the function-pointer form).
     static odeVector RK1(real const &t, odeVector const &X, real const &step, odeVector (*function)(real const &, odeVector const &, void *), void *context);
     static void RK1(real const &t, odeVector &X, real const &step, modelStruct const &ode);
     static odeVector RK2(real const &t, odeVector const &X, real const &step, odeVector (*function)(real const &, odeVector const &, void *), void *context);

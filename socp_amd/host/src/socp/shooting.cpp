@@ -35,6 +35,7 @@ struct shooting::data_struct {
     std::atomic<int> stopFlag{0};
     bool dedup = true;
     socp_ctx *ctx = nullptr;      // the model's device context, valid during a solve
+    long long hostTrajectories = 0;   // segments integrated on the host (models without device dynamics)
 };
 
 namespace {
@@ -249,6 +250,7 @@ void shooting::SetJacobianDedup(bool on) const { data->dedup = on; }
 
 long long shooting::GetTrajectoryCount() const
 {
+    if (myModel.DeviceModelId() == 0) return data->hostTrajectories;
     long long traj = 0, launches = 0;
     socp_ctx_counters(myModel.DeviceContext(), &traj, &launches);
     return traj;
@@ -433,10 +435,21 @@ int shooting::SolveShootingContinuation(real const &continuationStep, real &Rdat
 int shooting::SolveShootingFunction(int const &numParam, std::vector<real> &param) const
 {
     const int n = numParam;
+    std::vector<real> xscal(n, 1.0), fvec(n), fjac((size_t)n * n), r((size_t)n * (n + 1) / 2), qtf(n), wa1(n), wa2(n), wa3(n), wa4(n);
+    if (myModel.DeviceModelId() == 0) {
+        // A user class with the reference's host virtuals only: the reference's own scheme -- hybrd with n sequential
+        // residual callbacks per forward-difference Jacobian (shooting.cpp:801-827), every trajectory on the host.
+        if (myModel.modelOrder != 0)
+            throw std::runtime_error("shooting: modelOrder 1 (variational Jacobian, hybrj) needs a model with device dynamics");
+        data->ctx = nullptr;
+        data->info = hybrd(StaticHostShootingFunction, (void *)this, n, param.data(), fvec.data(), data->xtol, data->maxfev,
+                           n - 1, n - 1, data->epsfcn, xscal.data(), data->scalingMode, data->factor, data->nprint, &data->nfev,
+                           fjac.data(), n, r.data(), (int)r.size(), qtf.data(), wa1.data(), wa2.data(), wa3.data(), wa4.data());
+        return data->info;
+    }
     data->ctx = myModel.DeviceContext();           // re-packs parameters / step number (continuation mutates them)
     PushProblemToDevice();
 
-    std::vector<real> xscal(n, 1.0), fvec(n), fjac((size_t)n * n), r((size_t)n * (n + 1) / 2), qtf(n), wa1(n), wa2(n), wa3(n), wa4(n);
     if (myModel.modelOrder == 0) {
         data->info = socp_hybrd_batched(StaticShootingFunction, StaticShootingFdJacobian, (void *)this, n, param.data(),
                                         fvec.data(), data->xtol, data->maxfev, n - 1, n - 1, data->epsfcn, xscal.data(),
@@ -449,6 +462,99 @@ int shooting::SolveShootingFunction(int const &numParam, std::vector<real> &para
                            wa1.data(), wa2.data(), wa3.data(), wa4.data());
     }
     return data->info;
+}
+
+// ---- models without device dynamics ------------------------------------------------------------------------------
+// shooting.cpp:918-993 with the rows of SURVEY Appendix B: node k's free-time equation sits at 2 d M + (number of FREE times
+// before node k); segment i ends at node i + 1, whose continuity rows are [2d(i+1), 2d(i+2)).
+void shooting::HostShootingFunction(std::vector<real> const &param, std::vector<real> &fvec) const
+{
+    const int M = data->numMulti, d = data->dim, s = 2 * d;
+    std::vector<real> timeLine(M + 1);
+    ComputeTimeLine(param, timeLine);
+    std::vector<int> free_row(M + 1, -1);
+    for (int k = 0, row = s * M; k <= M; k++)
+        if (data->mode_t[k] == model::FREE) free_row[k] = row++;
+
+    auto boundary = [&](int node, real t, model::mstate const &Xt, int first_row) {
+        // Initial[H]Function at node 0, Final[H]Function at node M (model.hpp:90-290); the H variants add the free-time row
+        const bool with_h = data->mode_t[node] != model::FIXED;
+        std::vector<real> rows(d + (with_h ? 1 : 0));
+        if (node == 0) {
+            if (with_h) myModel.InitialHFunction(t, Xt, data->X[0], data->mode_X[0], rows, 0);
+            else myModel.InitialFunction(t, Xt, data->X[0], data->mode_X[0], rows, 0);
+        } else {
+            if (with_h) myModel.FinalHFunction(t, Xt, data->X[M], data->mode_X[M], rows, 0);
+            else myModel.FinalFunction(t, Xt, data->X[M], data->mode_X[M], rows, 0);
+        }
+        for (int k = 0; k < d; k++) fvec[first_row + k] = rows[k];
+        if (with_h) fvec[free_row[node]] = rows[d];
+    };
+
+    model::mstate Xstart = data->X[0];
+    Xstart.resize(s);
+    for (int k = 0; k < s; k++) Xstart[k] = param[k];
+    for (int i = 0; i < M; i++) {
+        const real ta = timeLine[i], tb = timeLine[i + 1];
+        const model::mstate Xend = Move(ta, Xstart, tb, 0);
+        data->hostTrajectories++;
+        if (i == 0) boundary(0, ta, Xstart, 0);
+        if (i < M - 1) {
+            model::mstate Xnext(s);
+            for (int k = 0; k < s; k++) Xnext[k] = param[s * (i + 1) + k];
+            if (data->mode_t[i + 1] == model::FREE) fvec[free_row[i + 1]] = myModel.SwitchingTimesFunction(tb, Xend, Xnext, 0)[0];
+            // shooting::MultipleShootingFunction, value form (shooting.cpp:1511-1576)
+            for (int j = 0; j < d; j++) {
+                const int row = s * (i + 1) + j;
+                switch (data->mode_X[i + 1][j]) {
+                case model::FIXED:
+                    fvec[row] = Xend[j] - data->X[i + 1][j];
+                    fvec[row + d] = Xnext[j] - data->X[i + 1][j];
+                    break;
+                case model::FREE: {
+                    model::mstate rows(fvec.begin() + s * (i + 1), fvec.begin() + s * (i + 2));
+                    myModel.SwitchingStateFunction(tb, j, Xend, Xnext, data->X[i + 1], rows, 0);
+                    for (int k = 0; k < s; k++) fvec[s * (i + 1) + k] = rows[k];
+                    break;
+                }
+                default:
+                    fvec[row] = Xend[j] - Xnext[j];
+                    fvec[row + d] = Xend[j + d] - Xnext[j + d];
+                }
+            }
+            Xstart = Xnext;
+        } else {
+            boundary(M, tb, Xend, d);
+        }
+    }
+}
+
+std::vector<real> shooting::ResidualAt(std::vector<real> const &param) const
+{
+    const int n = data->numParam;
+    if ((int)param.size() != n) throw std::invalid_argument("shooting::ResidualAt: wrong number of unknowns");
+    for (int i = 0; i <= data->numMulti; i++) {                       // as SolveShooting: the desired boundary data (shooting.cpp:575-580)
+        data->time[i] = data->timed[i];
+        for (int j = 0; j < data->dim; j++) data->X[i][j] = data->Xd[i][j];
+    }
+    std::vector<real> f(n, 0.0);
+    if (myModel.DeviceModelId() == 0) {
+        HostShootingFunction(param, f);
+    } else {
+        data->ctx = myModel.DeviceContext();
+        PushProblemToDevice();
+        if (StaticShootingFunction((void *)this, n, param.data(), f.data(), 1) < 0) throw std::runtime_error("shooting::ResidualAt: residual evaluation failed");
+    }
+    return f;
+}
+
+int shooting::StaticHostShootingFunction(void *userdata, int n, const real *param, real *fvec, int)
+{
+    const shooting *self = static_cast<const shooting *>(userdata);
+    std::vector<real> z(param, param + n), f(n, 0.0);
+    self->HostShootingFunction(z, f);
+    std::copy(f.begin(), f.end(), fvec);
+    return self->data->stopFlag;
 }
 
 // shooting.cpp:859-874: residual callback.  The timeline is also computed on the host so that the

@@ -69,6 +69,10 @@ public:
     long long GetTrajectoryCount() const;
     // integrate only the segments an FD column can change (bit-identical Jacobian); default on
     void SetJacobianDedup(bool on) const;
+    // the shooting residual F(z) at an arbitrary unknown vector with the current (desired) boundary data: what the Newton
+    // solver is shown (StaticShootingFunction, shooting.cpp:859-874) -- on the GPU, or on the host for a model without
+    // device dynamics
+    std::vector<real> ResidualAt(std::vector<real> const &param) const;
 
 private:
     model &myModel;
@@ -83,6 +87,10 @@ private:
     void ComputeTimeLine(std::vector<real> const &param, std::vector<real> &timeLine) const;
     void UpdateSolution() const;
 
+    // residual of a model WITHOUT device dynamics (DeviceModelId() == 0): assembled on the host from the model's own virtuals
+    // (ComputeTraj, Initial[H]Function, Final[H]Function, SwitchingTimesFunction), shooting.cpp:918-993, 1511-1576
+    void HostShootingFunction(std::vector<real> const &param, std::vector<real> &fvec) const;
+    static int StaticHostShootingFunction(void *userdata, int n, const real *param, real *fvec, int iflag);
     static int StaticShootingFunction(void *userdata, int n, const real *param, real *fvec, int iflag);
     static int StaticShootingFdJacobian(void *userdata, int n, const real *param, const real *fvec, real epsfcn, real *fjac, int ldfjac);
     static int StaticShootingFunctionJacobian(void *userdata, int n, const real *param, real *fvec, real *fjac, int ldfjac, int iflag);

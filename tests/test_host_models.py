@@ -1,0 +1,92 @@
+"""CPU: a user model that overrides ONLY the reference's host virtuals (Model / Control / Hamiltonian; no device twin) still
+runs through the mirror: odeTools::RK1/RK2/RK4 in both call forms (odeTools.cpp:46-98, interceptor.cpp:117), the host
+integrate() loop (odeTools.cpp:128-146) and shooting::SolveOCP with the residual assembled from the model's virtuals
+(shooting.cpp:918-993).  VERDICT r1 #4.  This is the plugin surface for classes without device dynamics -- in-tree models
+never take it: without a GPU they fail loudly (last test)."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "socp_amd", "_build", "bin")
+
+
+def run(*args):
+    out = subprocess.run([os.path.join(BIN, "hostmodel_flow")] + [str(a) for a in args], capture_output=True, text=True, timeout=300)
+    recs = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    return out, recs
+
+
+@pytest.mark.parametrize("M", [1, 4])
+def test_host_virtual_model_solves_through_shooting(M):
+    out, recs = run(M)
+    assert out.returncode == 0, out.stderr
+    r = recs[0]
+    assert r["info"] == 1 and r["n"] == 4 * M
+    assert r["steps_ok"] == 1 and r["struct_ok"] == 1          # RK1/RK2/RK4 fn-pointer form bit-equal to the hand formulas
+    # analytic optimum of the rest-to-rest transfer: p_x = -12, p_v(0) = -6, u(0) = 6 (cubic solution: RK4 is exact)
+    assert abs(r["p_x"] + 12) < 1e-9 and abs(r["p_v"] + 6) < 1e-9 and abs(r["u0"] - 6) < 1e-9
+    assert r["trajectories"] == r["nfev"] * M                  # n sequential callbacks per FD Jacobian, as the reference
+    assert out.stderr.count("no device dynamics") == 1         # the one-line warning, once
+
+
+def test_host_residual_rows_against_an_independent_restatement():
+    """Every row kind of the host assembly (shooting.cpp:945-990, model.hpp:90-328): FREE interior time ->
+    SwitchingTimesFunction row, FREE final time -> H row, FIXED / CONTINUOUS interior state modes, FREE final component."""
+    out, recs = run("residual")
+    assert out.returncode == 0, out.stderr
+    z, F = np.array(recs[0]["z"]), np.array(recs[0]["F"])
+    assert len(z) == 14                                         # 3 nodes x 4 + two FREE times
+
+    def rhs(X):
+        return np.array([X[1], -X[3], 0.0, -X[2]])
+
+    def H(X):
+        u = -X[3]
+        return u * u / 2 + X[2] * X[1] + X[3] * u
+
+    def traj(t0, X, tf, N=7):
+        dt = (tf - t0) / N
+        t, X = t0, X.copy()
+        while t < tf - dt / 2:
+            h = tf - t if t + dt > tf else dt
+            F1 = rhs(X); F2 = rhs(X + (h / 2.0) * F1); F3 = rhs(X + (h / 2.0) * F2); F4 = rhs(X + h * F3)
+            X = X + (h / 6.0) * (F1 + (F4 + 2.0 * (F2 + F3)))
+            t += dt
+        return X
+
+    # layout of the program: mode_t = [FIXED, FREE, CONTINUOUS, FREE]; desired data = its initial guess
+    vt = np.array([0.4 * i + 0.01 * i * i for i in range(4)])
+    vX = np.array([[0.3 * i, 0.1 + 0.05 * i, -1.0 - 0.1 * i, -0.7 + 0.2 * i] for i in range(4)])
+    t1, t3 = z[12], z[13]
+    tl = [vt[0], t1, t1 + (t3 - t1) / 2, t3]                  # CONTINUOUS node 2 spaced uniformly between the junctions
+    X0, X1, X2 = z[0:4], z[4:8], z[8:12]
+    want = np.zeros(14)
+    want[0:2] = X0[0:2] - vX[0, 0:2]                            # InitialFunction, both FIXED
+    E0 = traj(tl[0], X0, tl[1])
+    want[12] = H(E0) - H(X1)                                    # default SwitchingTimesFunction at the FREE interior time
+    want[4], want[6] = E0[0] - vX[1, 0], X1[0] - vX[1, 0]       # node 1: position FIXED pins both sides
+    want[5], want[7] = E0[1] - X1[1], E0[3] - X1[3]             #         velocity CONTINUOUS: state and costate jump
+    E1 = traj(tl[1], X1, tl[2])
+    want[8:10] = E1[0:2] - X2[0:2]
+    want[10:12] = E1[2:4] - X2[2:4]
+    E2 = traj(tl[2], X2, tl[3])
+    want[2] = E2[0] - vX[3, 0]                                  # FinalHFunction: position FIXED,
+    want[3] = E2[3]                                             #   velocity FREE -> transversality p_v = 0,
+    want[13] = H(E2)                                            #   free tf -> H = 0
+    assert np.max(np.abs(F - want)) < 1e-14, (F, want)
+
+
+def test_in_tree_models_still_have_no_cpu_path():
+    """The host path is for classes WITHOUT device dynamics only.  goddard has a device twin: without a GPU its solve must
+    fail loudly (no silent CPU fallback), here and in every CPU-only environment."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the device path runs")
+    out = subprocess.run([os.path.join(BIN, "goddard_flow"), "full", "10", "1", "1e-6"], capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0
+    assert "no HIP device" in out.stderr or "no CPU path" in out.stderr or "device" in out.stderr.lower()
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
