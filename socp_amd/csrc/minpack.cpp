@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <thread>
@@ -186,6 +187,209 @@ void qform(int n, double *q, int ldq, double *wa, int threads)
     work(0);
     for (std::thread &th : pool) th.join();
     (void)wa;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// One Jacobian refresh's O(n^3) work -- qrfac without pivoting, qtf = Q^T fvec, R packed by rows, qform -- with the
+// COLUMNS IN SIMD LANES.  MINPACK's column algorithm gives every column its own serial chain (one dot product, one
+// division, one axpy per reflector); chains of different columns never mix.  Walking the matrix row-major, eight columns
+// are one vector (and several vectors per task hide the add latency), so the lanes carry eight independent copies of the
+// scalar recurrence: each number is produced by the same IEEE operations in the same order as in qrfac_nopivot / qform
+// above -- bit-identical (tests/test_minpack.py) -- but the machine is no longer waiting on one 4-cycle add chain.
+// Compiled without FMA contraction; the ISA is chosen at load time (AVX-512 / AVX2 / baseline), which changes the vector
+// width, never a rounding.  The refresh of the 832-unknown doubleIntegrator problem: qrfac + qform 33 ms (16 threads,
+// scalar chains) -> see profiles/ (tests/tools/qr_bench.cpp).
+// ---------------------------------------------------------------------------------------------------------------------
+namespace colvec {
+
+typedef double v8 __attribute__((vector_size(64)));
+typedef long long m8 __attribute__((vector_size(64)));
+constexpr int W = 8;                 // columns per vector
+constexpr int G = 4;                 // vectors per block: 32 columns advance together (four independent add chains)
+constexpr int CB = W * G;            // columns per block = reflectors per panel: a panel's columns are exactly one block
+constexpr int kMinN = 24;            // below this the scalar code is as fast
+
+#define SOCP_ISA_CLONES __attribute__((target_clones("avx512f", "avx2", "default")))
+
+typedef double v8u __attribute__((vector_size(64), aligned(8)));      // the same eight lanes at any address
+// macros, not functions: a helper that returns a 64-byte vector would be compiled for the baseline ISA
+#define ld8(p) ((v8)(*reinterpret_cast<const v8u *>(p)))
+#define st8(p, x) (*reinterpret_cast<v8u *>(p) = (x))
+#define splat(a) (v8{(a), (a), (a), (a), (a), (a), (a), (a)})
+
+// Apply `count` reflectors, in order, to the block of CB columns starting at column first_col of the row-major matrix At
+// (row stride ld).  Reflector t acts on rows row0[t] .. n-1 with the vector v[t][0 .. n - row0[t]) (v[t][0] = pivot entry)
+// and is skipped when skip[t].  keep_upto[t]: columns <= keep_upto[t] of the block are left alone (the panel's own block:
+// reflector j only moves columns > j); pass a value < first_col to move every column.
+SOCP_ISA_CLONES
+void apply_reflectors(int n, int count, const int *row0, const int *keep_upto, const unsigned char *skip, const double *const *v,
+                      double *At, int ld, int first_col)
+{
+    for (int t = 0; t < count; t++) {
+        if (skip[t]) continue;
+        const int j = row0[t], len = n - j;
+        const double *vt = v[t];
+        double *base = At + (size_t)j * ld + first_col;
+        v8 sum[G];
+        for (int g = 0; g < G; g++) sum[g] = splat(0.0);
+        for (int i = 0; i < len; i++) {
+            const v8 vi = splat(vt[i]);
+            const double *row = base + (size_t)i * ld;
+            for (int g = 0; g < G; g++) sum[g] += vi * ld8(row + W * g);
+        }
+        v8 temp[G];
+        const v8 piv = splat(vt[0]);
+        for (int g = 0; g < G; g++) temp[g] = sum[g] / piv;
+        if (keep_upto[t] < first_col) {
+            for (int i = 0; i < len; i++) {
+                const v8 vi = splat(vt[i]);
+                double *row = base + (size_t)i * ld;
+                for (int g = 0; g < G; g++) st8(row + W * g, ld8(row + W * g) - temp[g] * vi);
+            }
+        } else {
+            m8 keep[G] = {};
+            for (int g = 0; g < G; g++)
+                for (int e = 0; e < W; e++) keep[g][e] = (first_col + W * g + e <= keep_upto[t]) ? -1LL : 0LL;
+            for (int i = 0; i < len; i++) {
+                const v8 vi = splat(vt[i]);
+                double *row = base + (size_t)i * ld;
+                for (int g = 0; g < G; g++) {
+                    const v8 old = ld8(row + W * g);
+                    const v8 upd = old - temp[g] * vi;
+                    st8(row + W * g, keep[g] ? old : upd);
+                }
+            }
+        }
+    }
+}
+
+// qform for the block of CB columns j0 .. j0 + CB - 1 of Q (row-major Qt, row stride ld, initialised to the identity): column j
+// is e_j pushed through the reflectors j, j-1, ..., 0 (v_k = V + off[k], rows k .. n-1; skipped when its pivot is zero).
+SOCP_ISA_CLONES
+void qform_block(int n, int j0, const double *V, const size_t *off, double *Qt, int ld)
+{
+    const int jtop = std::min(j0 + CB, n) - 1;
+    for (int k = jtop; k >= 0; k--) {
+        const double *vk = V + off[k];
+        if (vk[0] == 0) continue;
+        const int len = n - k;
+        double *base = Qt + (size_t)k * ld + j0;
+        v8 sum[G];
+        for (int g = 0; g < G; g++) sum[g] = splat(0.0);
+        for (int i = 0; i < len; i++) {
+            const v8 vi = splat(vk[i]);
+            const double *row = base + (size_t)i * ld;
+            for (int g = 0; g < G; g++) sum[g] += ld8(row + W * g) * vi;
+        }
+        v8 temp[G];
+        const v8 piv = splat(vk[0]);
+        for (int g = 0; g < G; g++) temp[g] = sum[g] / piv;
+        if (k <= j0) {
+            for (int i = 0; i < len; i++) {
+                const v8 vi = splat(vk[i]);
+                double *row = base + (size_t)i * ld;
+                for (int g = 0; g < G; g++) st8(row + W * g, ld8(row + W * g) - temp[g] * vi);
+            }
+        } else {
+            m8 keep[G] = {};                           // columns j < k of this block have not reached reflector k yet
+            for (int g = 0; g < G; g++)
+                for (int e = 0; e < W; e++) keep[g][e] = (j0 + W * g + e < k) ? -1LL : 0LL;
+            for (int i = 0; i < len; i++) {
+                const v8 vi = splat(vk[i]);
+                double *row = base + (size_t)i * ld;
+                for (int g = 0; g < G; g++) {
+                    const v8 old = ld8(row + W * g);
+                    const v8 upd = old - temp[g] * vi;
+                    st8(row + W * g, keep[g] ? old : upd);
+                }
+            }
+        }
+    }
+}
+
+template <class Body>
+void run_tasks(int tasks, int threads, Body &&body)
+{
+    const int use = std::max(1, std::min(threads, tasks));
+    if (use == 1) { for (int t = 0; t < tasks; t++) body(t); return; }
+    std::vector<std::thread> pool;
+    for (int w = 1; w < use; w++) pool.emplace_back([&, w]() { for (int t = w; t < tasks; t += use) body(t); });
+    for (int t = 0; t < tasks; t += use) body(t);
+    for (std::thread &th : pool) th.join();
+}
+
+// fjac (column-major, ld ldfjac): in = Jacobian, out = Q.  rdiag / acnorm as qrfac, qtf = Q^T fvec, r = R packed by rows.
+void factor(int n, double *fjac, int ldfjac, const double *fvec, double *rdiag, double *acnorm, double *qtf, double *r, int threads)
+{
+    const int ld = ((n + 1 + CB - 1) / CB) * CB;                 // columns 0..n-1, column n = fvec -> qtf, zero padding
+    // 64-byte aligned: a block's row segment is exactly four cache lines (no split loads, no line shared by two threads)
+    std::vector<double> At_store((size_t)n * ld + 8, 0.0);
+    double *const At = At_store.data() + ((64 - (reinterpret_cast<uintptr_t>(At_store.data()) & 63)) & 63) / sizeof(double);
+    for (int j = 0; j < n; j++) acnorm[j] = enorm(n, fjac + (size_t)j * ldfjac);
+    for (int jb = 0; jb < n; jb += 32)                           // row-major copy, blocked transpose
+        for (int ib = 0; ib < n; ib += 32)
+            for (int j = jb; j < std::min(jb + 32, n); j++)
+                for (int i = ib; i < std::min(ib + 32, n); i++) At[(size_t)i * ld + j] = fjac[i + (size_t)j * ldfjac];
+    // qtf = Q^T fvec rides along as column n: MINPACK's qtf loop (sum = v.q; t = -sum / v_j; q += v t) is the column update
+    // (sum = v.a; t = sum / v_j; a -= t v) with both signs flipped, i.e. the same bits.
+    for (int i = 0; i < n; i++) At[(size_t)i * ld + n] = fvec[i];
+
+    std::vector<size_t> off(n);                                  // packed Householder vectors: v_k = V[off[k] .. off[k] + n - k)
+    size_t total = 0;
+    for (int k = 0; k < n; k++) { off[k] = total; total += (size_t)(n - k); }
+    std::vector<double> V(total);
+
+    int row0[CB], keep_upto[CB], keep_none[CB];
+    unsigned char skip[CB];
+    const double *vp[CB];
+    for (int t = 0; t < CB; t++) keep_none[t] = -1;
+    for (int j0 = 0; j0 < n; j0 += CB) {
+        const int j1 = std::min(j0 + CB, n);
+        for (int j = j0; j < j1; j++) {
+            // finish reflector j on its column, which every earlier reflector has already been through: rows j .. n-1 -> v_j
+            double *vj = V.data() + off[j];
+            for (int i = j; i < n; i++) vj[i - j] = At[(size_t)i * ld + j];
+            double ajnorm = enorm(n - j, vj);
+            if (ajnorm != 0) {
+                if (vj[0] < 0) ajnorm = -ajnorm;
+                for (int i = 0; i < n - j; i++) vj[i] /= ajnorm;
+                vj[0] += 1;
+            }
+            rdiag[j] = -ajnorm;
+            const int t = j - j0;
+            row0[t] = j; keep_upto[t] = j; skip[t] = (ajnorm == 0); vp[t] = vj;
+            // the panel's own block (its later columns; in the last panel also fvec's column): right-looking, at once
+            apply_reflectors(n, 1, row0 + t, keep_upto + t, skip + t, vp + t, At, ld, j0);
+        }
+        // every block to the right: through the panel's reflectors in order, blocks dealt out to threads
+        const int nblk = (ld - (j0 + CB)) / CB;
+        run_tasks(nblk, threads, [&](int b) { apply_reflectors(n, j1 - j0, row0, keep_none, skip, vp, At, ld, j0 + CB * (b + 1)); });
+    }
+    for (int i = 0; i < n; i++) qtf[i] = At[(size_t)i * ld + n];
+    for (int i = 0, l = 0; i < n; i++) {                         // R by rows: row i = [rdiag[i], A(i, i+1 .. n-1)]
+        r[l++] = rdiag[i];
+        for (int k = i + 1; k < n; k++) r[l++] = At[(size_t)i * ld + k];
+    }
+    std::fill(At, At + (size_t)n * ld, 0.0);                        // Q: columns in lanes again, blocks independent of each other
+    for (int j = 0; j < n; j++) At[(size_t)j * ld + j] = 1.0;
+    const int qblocks = (n + CB - 1) / CB;
+    run_tasks(qblocks, threads, [&](int b) { qform_block(n, (qblocks - 1 - b) * CB, V.data(), off.data(), At, ld); });   // heaviest first
+    for (int jb = 0; jb < n; jb += 32)
+        for (int ib = 0; ib < n; ib += 32)
+            for (int i = ib; i < std::min(ib + 32, n); i++)
+                for (int j = jb; j < std::min(jb + 32, n); j++) fjac[i + (size_t)j * ldfjac] = At[(size_t)i * ld + j];
+}
+
+#undef ld8
+#undef st8
+#undef splat
+}  // namespace colvec
+
+// SOCP_LINALG_VECTOR=0: the scalar column algorithm everywhere (A/B measurements, bit-identity tests)
+bool colvec_enabled()
+{
+    static const bool on = [] { const char *e = std::getenv("SOCP_LINALG_VECTOR"); return !(e && e[0] == '0'); }();
+    return on;
 }
 
 // dogleg step: minimiser of |R x - qtb| within the ellipsoid |diag x| <= delta, restricted to
@@ -410,7 +614,9 @@ struct Core {
     void after_jacobian()
     {
         if (analytic) njev += 1; else nfev += msum;
-        qrfac_nopivot(n, fjac, ldfjac, wa1, wa2, lin_threads);      // wa1 = diag(R), wa2 = column norms
+        const bool vec = colvec_enabled() && n >= colvec::kMinN;
+        if (vec) colvec::factor(n, fjac, ldfjac, fvec, wa1, wa2, qtf, r, lin_threads);     // qrfac + qtf + R + qform, columns in SIMD lanes
+        else qrfac_nopivot(n, fjac, ldfjac, wa1, wa2, lin_threads);      // wa1 = diag(R), wa2 = column norms
         if (iter == 1) {
             if (mode != 2)
                 for (int j = 0; j < n; j++) diag[j] = wa2[j] == 0 ? 1.0 : wa2[j];
@@ -418,6 +624,13 @@ struct Core {
             xnorm = enorm(n, wa3);
             delta = factor * xnorm;
             if (delta == 0) delta = factor;
+        }
+        if (vec) {
+            sing = false;
+            for (int j = 0; j < n; j++) if (wa1[j] == 0) sing = true;
+            if (mode != 2)
+                for (int j = 0; j < n; j++) diag[j] = std::max(diag[j], wa2[j]);
+            return;
         }
         // qtf = Q^T fvec from the Householder vectors
         for (int i = 0; i < n; i++) qtf[i] = fvec[i];

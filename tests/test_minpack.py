@@ -173,10 +173,30 @@ r = capi.hybrd(f, np.zeros(n), xtol=1e-12, epsfcn=1e-15)
 print(json.dumps({"info": r["info"], "nfev": r["nfev"], "x": [float(v).hex() for v in r["x"]]}))
 ''' % root
     res = {}
-    for t in ("1", "3", "8"):
-        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
-                             env=dict(os.environ, SOCP_LINALG_THREADS=t))
-        assert out.returncode == 0, out.stderr[-2000:]
-        res[t] = json.loads(out.stdout.strip().splitlines()[-1])
-    assert res["1"]["info"] == 1
-    assert res["1"] == res["3"] == res["8"]
+    # SOCP_LINALG_VECTOR=0: MINPACK's scalar column algorithm; default: the same chains with the columns in SIMD lanes
+    for vec in ("0", "1"):
+        for t in ("1", "3", "8"):
+            out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                                 env=dict(os.environ, SOCP_LINALG_THREADS=t, SOCP_LINALG_VECTOR=vec))
+            assert out.returncode == 0, out.stderr[-2000:]
+            res[vec, t] = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["0", "1"]["info"] == 1
+    assert all(r == res["0", "1"] for r in res.values())
+
+
+def test_simd_column_factor_work_is_bit_identical_to_the_scalar_column_algorithm(tmp_path):
+    """colvec::factor (qrfac + qtf + R + qform with eight columns per vector) against qrfac_nopivot / qform: Q, R, rdiag,
+    column norms and qtf equal to the last bit -- sizes below, at and across the 32-column block / panel boundaries, with a
+    zero column and a zero sub-column (identity reflectors), 1 and several threads (tests/tools/qr_bench.cpp)."""
+    import json
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "qr_bench")
+    cxx = "/opt/rocm/lib/llvm/bin/clang++" if os.path.exists("/opt/rocm/lib/llvm/bin/clang++") else "g++"
+    subprocess.check_call([cxx, "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-psabi", "-I" + os.path.join(root, "include"), "-o", exe,
+                           os.path.join(root, "tests", "tools", "qr_bench.cpp"), "-lpthread"])
+    for n, threads in ((5, 1), (24, 1), (31, 1), (32, 1), (33, 1), (64, 2), (85, 1), (97, 3), (127, 1), (260, 4)):
+        out = subprocess.run([exe, str(n), str(threads), "1"], capture_output=True, text=True, timeout=600)
+        rec = json.loads(out.stdout.strip().splitlines()[-1])
+        assert out.returncode == 0 and rec["bit_identical"] is True, (n, threads, out.stdout, out.stderr)
