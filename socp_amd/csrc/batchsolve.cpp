@@ -360,9 +360,10 @@ extern "C" int socp_chains_solve(socp_ctx *ctx, int P, const socp_chain_options 
         if (spec_on && kF) {
             if (speculate > 0) kS = kF;
             else {
-                // lanes: kS (n+1) segs + (kF - kS) segs + the Jacobian launch <= 1024 waves x 64
-                const long lanes = (1024 - ((long)kJ * n * segs + 63) / 64) * 64 - (long)kF * segs;
-                kS = lanes <= 0 ? 0 : (int)std::min<long>(kF, lanes / ((long)n * segs));
+                // all or nothing: a round that is part FD batches, part plain residuals is two launches on one stream, i.e. two
+                // trajectory latencies.  All of them fit when kF (n+1) segs lanes + the Jacobian launch <= 1024 waves x 64.
+                const long lanes = (1024 - ((long)kJ * n * segs + 63) / 64) * 64;
+                kS = ((long)kF * (n + 1) * segs <= lanes) ? kF : 0;
             }
         }
         if (trace) std::fprintf(stderr, "[socp_chains] round %lld: %d residual requests (%d as FD batches), %d Jacobian requests\n", rounds, kF, kS, kJ);

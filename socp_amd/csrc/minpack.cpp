@@ -16,9 +16,15 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <chrono>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
+#include <atomic>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -307,29 +313,112 @@ void qform_block(int n, int j0, const double *V, const size_t *off, double *Qt, 
     }
 }
 
-template <class Body>
-void run_tasks(int tasks, int threads, Body &&body)
-{
-    const int use = std::max(1, std::min(threads, tasks));
-    if (use == 1) { for (int t = 0; t < tasks; t++) body(t); return; }
-    std::vector<std::thread> pool;
-    for (int w = 1; w < use; w++) pool.emplace_back([&, w]() { for (int t = w; t < tasks; t += use) body(t); });
-    for (int t = 0; t < tasks; t += use) body(t);
-    for (std::thread &th : pool) th.join();
-}
+// Worker threads for ONE factorisation: started once, handed a batch of tasks per panel (an atomic counter deals them out, so
+// a thread that finishes early takes the next block).  Between batches a worker waits actively for at most ~40 us and then
+// parks on a condition variable (the process may run under a CPU quota: no unbounded spinning).  Starting and joining 15
+// threads at each of the 26 panels of n = 832 cost as much as the arithmetic.
+class Pool {
+public:
+    explicit Pool(int threads) : n_(std::max(1, threads))
+    {
+        for (int w = 1; w < n_; w++) th_.emplace_back([this]() { worker(); });
+    }
+    ~Pool()
+    {
+        { std::lock_guard<std::mutex> lk(m_); stop_.store(true); }
+        cv_start_.notify_all();
+        for (std::thread &t : th_) t.join();
+    }
+    template <class Body>
+    void run(int tasks, Body &&body)
+    {
+        if (tasks <= 0) return;
+        if (n_ == 1 || tasks == 1) { for (int t = 0; t < tasks; t++) body(t); return; }
+        std::function<void(int)> fn = body;
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            job_ = &fn; tasks_ = tasks; next_.store(0); busy_.store(n_ - 1); gen_.fetch_add(1);
+        }
+        cv_start_.notify_all();
+        for (int t; (t = next_.fetch_add(1)) < tasks;) fn(t);
+        if (!spin_until([this]() { return busy_.load() == 0; })) {
+            std::unique_lock<std::mutex> lk(m_);
+            cv_done_.wait(lk, [this]() { return busy_.load() == 0; });
+        }
+        std::lock_guard<std::mutex> lk(m_);     // the last worker has left its critical section
+        job_ = nullptr;
+    }
+
+private:
+    // A batch is tens of microseconds of work per thread and the next one follows at once, while waking a parked thread
+    // costs 50-100 us: wait actively for a SHORT, bounded time (about 40 us), then park on the condition variable.
+    template <class Pred>
+    static bool spin_until(Pred &&done)
+    {
+        const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        for (int it = 0;; it++) {
+            if (done()) return true;
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+            if ((it & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(40)) return false;
+        }
+    }
+    void worker()
+    {
+        int seen = 0;
+        for (;;) {
+            if (!spin_until([&]() { return stop_.load() || gen_.load() != seen; })) {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_start_.wait(lk, [&]() { return stop_.load() || gen_.load() != seen; });
+            }
+            if (stop_.load()) return;
+            const std::function<void(int)> *fn;
+            int tasks;
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                seen = gen_.load(); fn = job_; tasks = tasks_;
+            }
+            if (fn)
+                for (int t; (t = next_.fetch_add(1)) < tasks;) (*fn)(t);
+            bool last;
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                last = busy_.fetch_sub(1) == 1;
+            }
+            if (last) cv_done_.notify_one();
+        }
+    }
+    int n_;
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_start_, cv_done_;
+    const std::function<void(int)> *job_ = nullptr;
+    int tasks_ = 0;
+    std::atomic<int> next_{0}, busy_{0}, gen_{0};
+    std::atomic<bool> stop_{false};
+};
 
 // fjac (column-major, ld ldfjac): in = Jacobian, out = Q.  rdiag / acnorm as qrfac, qtf = Q^T fvec, r = R packed by rows.
 void factor(int n, double *fjac, int ldfjac, const double *fvec, double *rdiag, double *acnorm, double *qtf, double *r, int threads)
 {
+    static const bool trace = std::getenv("SOCP_LINALG_TRACE") != nullptr;      // phase times of every call, to stderr
+    using clk = std::chrono::steady_clock;
+    auto lap = [&](clk::time_point &t) { const clk::time_point now = clk::now(); const double ms = std::chrono::duration<double, std::milli>(now - t).count(); t = now; return ms; };
+    clk::time_point tick = clk::now();
+    double t_in = 0, t_panel = 0, t_trail = 0, t_out = 0, t_qform = 0;
     const int ld = ((n + 1 + CB - 1) / CB) * CB;                 // columns 0..n-1, column n = fvec -> qtf, zero padding
+    Pool pool(std::min(threads, std::max(1, n / CB)));
     // 64-byte aligned: a block's row segment is exactly four cache lines (no split loads, no line shared by two threads)
     std::vector<double> At_store((size_t)n * ld + 8, 0.0);
     double *const At = At_store.data() + ((64 - (reinterpret_cast<uintptr_t>(At_store.data()) & 63)) & 63) / sizeof(double);
-    for (int j = 0; j < n; j++) acnorm[j] = enorm(n, fjac + (size_t)j * ldfjac);
-    for (int jb = 0; jb < n; jb += 32)                           // row-major copy, blocked transpose
+    pool.run((n + 31) / 32, [&](int blk) {                       // column norms and the row-major copy (blocked transpose)
+        const int jb = blk * 32, je = std::min(jb + 32, n);
+        for (int j = jb; j < je; j++) acnorm[j] = enorm(n, fjac + (size_t)j * ldfjac);
         for (int ib = 0; ib < n; ib += 32)
-            for (int j = jb; j < std::min(jb + 32, n); j++)
+            for (int j = jb; j < je; j++)
                 for (int i = ib; i < std::min(ib + 32, n); i++) At[(size_t)i * ld + j] = fjac[i + (size_t)j * ldfjac];
+    });
     // qtf = Q^T fvec rides along as column n: MINPACK's qtf loop (sum = v.q; t = -sum / v_j; q += v t) is the column update
     // (sum = v.a; t = sum / v_j; a -= t v) with both signs flipped, i.e. the same bits.
     for (int i = 0; i < n; i++) At[(size_t)i * ld + n] = fvec[i];
@@ -343,6 +432,7 @@ void factor(int n, double *fjac, int ldfjac, const double *fvec, double *rdiag, 
     unsigned char skip[CB];
     const double *vp[CB];
     for (int t = 0; t < CB; t++) keep_none[t] = -1;
+    t_in = lap(tick);
     for (int j0 = 0; j0 < n; j0 += CB) {
         const int j1 = std::min(j0 + CB, n);
         for (int j = j0; j < j1; j++) {
@@ -361,9 +451,11 @@ void factor(int n, double *fjac, int ldfjac, const double *fvec, double *rdiag, 
             // the panel's own block (its later columns; in the last panel also fvec's column): right-looking, at once
             apply_reflectors(n, 1, row0 + t, keep_upto + t, skip + t, vp + t, At, ld, j0);
         }
+        t_panel += lap(tick);
         // every block to the right: through the panel's reflectors in order, blocks dealt out to threads
         const int nblk = (ld - (j0 + CB)) / CB;
-        run_tasks(nblk, threads, [&](int b) { apply_reflectors(n, j1 - j0, row0, keep_none, skip, vp, At, ld, j0 + CB * (b + 1)); });
+        pool.run(nblk, [&](int b) { apply_reflectors(n, j1 - j0, row0, keep_none, skip, vp, At, ld, j0 + CB * (b + 1)); });
+        t_trail += lap(tick);
     }
     for (int i = 0; i < n; i++) qtf[i] = At[(size_t)i * ld + n];
     for (int i = 0, l = 0; i < n; i++) {                         // R by rows: row i = [rdiag[i], A(i, i+1 .. n-1)]
@@ -373,11 +465,18 @@ void factor(int n, double *fjac, int ldfjac, const double *fvec, double *rdiag, 
     std::fill(At, At + (size_t)n * ld, 0.0);                        // Q: columns in lanes again, blocks independent of each other
     for (int j = 0; j < n; j++) At[(size_t)j * ld + j] = 1.0;
     const int qblocks = (n + CB - 1) / CB;
-    run_tasks(qblocks, threads, [&](int b) { qform_block(n, (qblocks - 1 - b) * CB, V.data(), off.data(), At, ld); });   // heaviest first
-    for (int jb = 0; jb < n; jb += 32)
+    t_out = lap(tick);
+    pool.run(qblocks, [&](int b) { qform_block(n, (qblocks - 1 - b) * CB, V.data(), off.data(), At, ld); });   // heaviest first
+    t_qform = lap(tick);
+    pool.run((n + 31) / 32, [&](int blk) {
+        const int jb = blk * 32;
         for (int ib = 0; ib < n; ib += 32)
             for (int i = ib; i < std::min(ib + 32, n); i++)
                 for (int j = jb; j < std::min(jb + 32, n); j++) fjac[i + (size_t)j * ldfjac] = At[(size_t)i * ld + j];
+    });
+    if (trace)
+        std::fprintf(stderr, "[colvec::factor n=%d threads=%d] set-up + transpose %.2f, panels (serial) %.2f, blocks to the right %.2f, qtf + R + identity %.2f, "
+                             "qform %.2f, Q back %.2f ms\n", n, threads, t_in, t_panel, t_trail, t_out, t_qform, lap(tick));
 }
 
 #undef ld8
