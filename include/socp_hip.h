@@ -59,8 +59,11 @@ extern "C" {
 #define SOCP_VARIANT_LANE_EXACT 1   /* one trajectory per lane, reference operation order, no FMA contraction: bit-identical
                                        to the CPU path for goddard / doubleIntegrator / covid19 */
 #define SOCP_VARIANT_LANE_FAST  2   /* one trajectory per lane, reciprocal/FMA-restructured arithmetic (<= 1e-8 after 1e4 steps) */
-#define SOCP_VARIANT_WAVE       3   /* one trajectory per wavefront, state staged in LDS: exists for the variational
-                                       (is_jac = 1) integration only, which always runs that way; rejected elsewhere */
+/* There is no selectable one-trajectory-per-wavefront variant for the state-only path (north_star sketches one): a wave
+ * instruction costs the same issue slots with 1 or 64 active lanes (scripts/probes/probe_lanes.hip), and spreading ONE
+ * Goddard trajectory over lanes does not shorten its instruction stream (DESIGN.md section 3 has the count), so it would be
+ * the same latency at 1/16 of the throughput.  The variational (is_jac = 1) integration, 156 values per trajectory, IS one
+ * wavefront per trajectory with its stage vectors in LDS -- always, not as a variant. */
 
 /* what socp_eval_batch computes */
 #define SOCP_EVAL_RHS         0   /* odeTools.hpp:82  Model(t, X, isJac)      -> len(X) values  */

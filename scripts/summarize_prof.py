@@ -64,6 +64,8 @@ def main():
             tj[k] = int(extra[k])
     if "variant" in extra:
         tj["variant"] = extra["variant"]
+    if "source" in extra:
+        tj["source"] = extra["source"]          # the committed summary the figure comes from (bench.py: roofline.traffic_source)
     tpath = os.path.join(root, "traffic_latest.json")      # one entry per (variant, starts, rk4_steps); bench.py looks its own up
     try:
         entries = json.load(open(tpath))

@@ -16,7 +16,7 @@ MODEL_GODDARD, MODEL_DOUBLE_INTEGRATOR, MODEL_COVID19, MODEL_INTERCEPTOR = 1, 2,
 INTERCEPTOR_PARAM_NAMES = ["c0", "hr", "d0", "eta", "propellant_mass", "empty_mass", "q", "ve", "alpha_max", "u_max",
                            "a_max", "mu_gft", "muT", "muV", "muC", "R_Earth", "mu0", "chartLimit"]
 FIXED, FREE, CONTINUOUS = 0, 1, 2
-VARIANT_AUTO, VARIANT_LANE_EXACT, VARIANT_LANE_FAST, VARIANT_WAVE = 0, 1, 2, 3
+VARIANT_AUTO, VARIANT_LANE_EXACT, VARIANT_LANE_FAST = 0, 1, 2
 EVAL_RHS, EVAL_CONTROL, EVAL_HAMILTONIAN = 0, 1, 2
 REQ_DONE, REQ_FVEC, REQ_JAC = 0, 1, 2
 INT_RK4, INT_DOPRI5 = 0, 1

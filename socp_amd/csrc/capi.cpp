@@ -111,13 +111,6 @@ const ModelLaunchers *table_of(const socp_ctx *c)
     return (c->variant == SOCP_VARIANT_LANE_FAST && c->vt_fast) ? c->vt_fast : c->vt;
 }
 
-int check_variant(socp_ctx *c)
-{
-    if (c->variant == SOCP_VARIANT_WAVE)
-        return fail(c, SOCP_ERR_UNSUPPORTED, "wave-per-trajectory variant is not available for this entry point");
-    return SOCP_OK;
-}
-
 hipError_t run_traj(socp_ctx *c, int B, const double *t0, const double *tf, const double *sw,
                     const double *X0, double *Xf)
 {
@@ -290,7 +283,7 @@ int socp_ctx_get_switching_times(const socp_ctx *c, double *sw2)
 int socp_ctx_set_variant(socp_ctx *c, int variant)
 {
     if (!c) return SOCP_ERR_ARG;
-    if (variant < SOCP_VARIANT_AUTO || variant > SOCP_VARIANT_WAVE) return fail(c, SOCP_ERR_ARG, "set_variant: unknown variant");
+    if (variant < SOCP_VARIANT_AUTO || variant > SOCP_VARIANT_LANE_FAST) return fail(c, SOCP_ERR_ARG, "set_variant: unknown variant");
     c->variant = variant;
     return SOCP_OK;
 }
@@ -356,7 +349,6 @@ int socp_integrate_batch_dev(socp_ctx *c, int B, const double *d_t0, const doubl
         HIP_TRY(c, var_traj(c->model_id, c->stream, c->P, B, d_t0, d_tf, d_X0, d_Xf));
         return SOCP_OK;
     }
-    if (int rc = check_variant(c)) return rc;
     HIP_TRY(c, run_traj(c, B, d_t0, d_tf, d_sw, d_X0, d_Xf));
     return SOCP_OK;
 }
@@ -655,7 +647,6 @@ int socp_residual_batch_dev(socp_ctx *c, int B, const double *d_Z, double *d_F)
     if (!c) return SOCP_ERR_ARG;
     if (!c->has_problem) return fail(c, SOCP_ERR_ARG, "residual_batch: no problem set");
     if (B < 0 || (B > 0 && (!d_Z || !d_F))) return fail(c, SOCP_ERR_ARG, "residual_batch: null argument");
-    if (int rc = check_variant(c)) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, run_residual(c, B, d_Z, d_F));
     return SOCP_OK;
@@ -686,7 +677,6 @@ int socp_fd_jacobian_multi_dev(socp_ctx *c, int np, const double *d_Z, const dou
     if (!c->has_problem) return fail(c, SOCP_ERR_ARG, "fd_jacobian: no problem set");
     if (np < 0 || (np > 0 && (!d_Z || !d_Fvec || !d_Fjac))) return fail(c, SOCP_ERR_ARG, "fd_jacobian: null argument");
     if (np == 0) return SOCP_OK;
-    if (int rc = check_variant(c)) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
     const double eps = fd_eps(epsfcn);
     if (dedup) {
@@ -710,7 +700,6 @@ int socp_fd_rows_dev(socp_ctx *c, int np, const double *d_Z, double epsfcn, doub
     if (!c->has_problem) return fail(c, SOCP_ERR_ARG, "fd_rows: no problem set");
     if (np < 0 || (np > 0 && (!d_Z || !d_Rows))) return fail(c, SOCP_ERR_ARG, "fd_rows: null argument");
     if (np == 0) return SOCP_OK;
-    if (int rc = check_variant(c)) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, run_fdrows(c, np, d_Z, fd_eps(epsfcn), d_Rows));
     return SOCP_OK;

@@ -1,6 +1,7 @@
 // api_conventions.cpp -- the reference's error and ownership conventions, kept by the C++ mirror:
 //   api_conventions bad_multi | bad_thread   constructor with a count < 1: message on stderr, exit(1) (shooting.cpp:62-77)
 //   api_conventions checks                   everything that returns: prints one "ok <name>" line per convention
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <stdexcept>
@@ -16,7 +17,7 @@ class hostOnly : public model
 {
 public:
     hostOnly() : model(2) {}
-    mstate Model(real const &, mstate const &X, int) const override { return mstate(X.size(), 0.0); }
+    mstate Model(real const &, mstate const &X, int) const override { return mstate(X.size(), 1.0); }
     mcontrol Control(real const &, mstate const &) const override { return mcontrol(1, 0.0); }
     mstate Hamiltonian(real const &, mstate const &, int) const override { return mstate(1, 0.0); }
 };
@@ -68,14 +69,18 @@ int main(int argc, char **argv)
     if (sh.SolveOCP(0.0, 5.0) == -1) ok("timeout_returns_minus_1");
     g.stepNbr = 10;
 
-    // a model class without device dynamics: no CPU path, loud failure
+    // a model class without device dynamics (only the reference's host virtuals): integrated on the host by the reference's
+    // own loop (odeTools.cpp:128-146), with a warning -- x' = 1 for every component here, so X(1) = X(0) + 1 up to rounding
     hostOnly h;
-    try {
-        h.ComputeTraj(0.0, model::mstate(4, 0.0), 1.0, 0, 0);
-    } catch (const std::runtime_error &e) {
-        if (std::strstr(e.what(), "no device dynamics")) ok("no_device_twin_throws");
-    }
-    // one-step host helpers are declared for source compatibility but do not run host callbacks
-    try { g.RK4(0.0, model::mstate(14, 0.0), 0.1, nullptr, nullptr); } catch (const std::logic_error &) { ok("host_rk_helpers_throw"); }
+    const model::mstate Xh = h.ComputeTraj(0.0, model::mstate(4, 0.5), 1.0, 0, 0);
+    if (Xh.size() == 4 && std::fabs(Xh[0] - 1.5) < 1e-14 && std::fabs(Xh[3] - 1.5) < 1e-14) ok("no_device_twin_runs_on_host");
+    // ... but never with the adaptive integrator, which only exists as a device kernel
+    odeTools::UseAdaptiveIntegrator(true);
+    try { h.ComputeTraj(0.0, model::mstate(4, 0.5), 1.0, 0, 0); } catch (const std::runtime_error &) { ok("no_device_twin_adaptive_throws"); }
+    odeTools::UseAdaptiveIntegrator(false);
+    // the one-step host helpers run host callbacks (odeTools.cpp:46-98; interceptor.cpp:117 uses the function-pointer form)
+    struct Cb { static odeTools::odeVector f(real const &, odeTools::odeVector const &X, void *) { return odeTools::odeVector(X.size(), 2.0); } };
+    const odeTools::odeVector Y = odeTools::RK4(0.0, odeTools::odeVector(3, 1.0), 0.25, &Cb::f, nullptr);
+    if (Y.size() == 3 && Y[0] == 1.5 && Y[2] == 1.5) ok("host_rk_helpers_run");
     return 0;
 }

@@ -44,6 +44,8 @@ def test_status_codes_and_messages():
         ctx.set_integrator(capi.INT_DOPRI5, 0.0)
     with pytest.raises(capi.SocpError):
         ctx.set_variant(17)
+    with pytest.raises(capi.SocpError):
+        ctx.set_variant(3)                               # the former "wave" value: not a variant of the state-only path
     # null pointers
     assert L.socp_integrate_batch(ctx.h, 4, None, None, None, None, None, 0) == capi.ERR_ARG
     assert L.socp_ctx_destroy(None) == capi.OK
