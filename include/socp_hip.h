@@ -81,6 +81,7 @@ const char *socp_last_error(const socp_ctx *ctx);   /* ctx may be NULL: last cre
 
 int socp_ctx_set_params(socp_ctx *ctx, const double *params, int nparams);
 int socp_ctx_get_params(const socp_ctx *ctx, double *params, int nparams);
+int socp_ctx_num_params(const socp_ctx *ctx);        /* length of the model's packed parameter block (< 0: error) */
 int socp_ctx_set_step_number(socp_ctx *ctx, int step_nbr);      /* model::stepNbr, model.hpp:367 */
 /* integrator of every later call: SOCP_INT_RK4 = the reference's default fixed-step loop
  * (odeTools.cpp:135-145); SOCP_INT_DOPRI5 = what it runs when built with -D_USE_BOOST (odeTools.cpp:129-134),

@@ -108,13 +108,9 @@ extern "C" int socp_chains_solve(socp_ctx *ctx, int P, const socp_chain_options 
     if (n <= 0) return SOCP_ERR_ARG;
     int dim = 0, S = 0;
     socp_ctx_dims(ctx, &dim, &S, nullptr);
-    int nparams = 0;
+    const int nparams = socp_ctx_num_params(ctx);
     double shared_params[SOCP_MAX_NPARAMS + 2] = {0};
-    {
-        // parameter count of the model: probe with the largest block the context accepts
-        for (int k = SOCP_MAX_NPARAMS; k >= 0; k--)
-            if (socp_ctx_get_params(ctx, shared_params, k) == SOCP_OK) { nparams = k; break; }
-    }
+    if (nparams < 0 || nparams > SOCP_MAX_NPARAMS || socp_ctx_get_params(ctx, shared_params, nparams) != SOCP_OK) return SOCP_ERR_ARG;
     const int kind = opt->kind;
     if (kind != SOCP_CHAIN_PLAIN && kind != SOCP_CHAIN_PARAM && kind != SOCP_CHAIN_DATA) return SOCP_ERR_ARG;
     if (kind == SOCP_CHAIN_PARAM && (!goal || opt->param_index < 0 || opt->param_index >= nparams)) return SOCP_ERR_ARG;
@@ -352,7 +348,6 @@ extern "C" int socp_chains_solve(socp_ctx *ctx, int P, const socp_chain_options 
             continue;
         }
         rounds++;
-        const clk::time_point tg = clk::now();
         const int kF = (int)reqF.size(), kJ = (int)reqJ.size();
         // how many of the residual requests are evaluated as whole FD batches: as many as fit the idle SIMDs
         // (one wave per SIMD keeps the round at one trajectory latency); speculate = 1 forces all of them
@@ -421,6 +416,7 @@ extern "C" int socp_chains_solve(socp_ctx *ctx, int P, const socp_chain_options 
         bool f_collected = (kF == 0);
         for (int j0 = 0; j0 < kJ || !f_collected; j0 += jchunk) {
             const int kc = j0 < kJ ? std::min(jchunk, kJ - j0) : 0;
+            const clk::time_point t_chunk = clk::now();
             if (kc) {
                 socp_problem_set_blocks_dev(ctx, pp_params ? dPJ.d() + (size_t)j0 * stride : nullptr, stride,
                                             pp_bound ? dTJ.d() + (size_t)j0 * nodes : nullptr, pp_bound ? dXJ.d() + (size_t)j0 * nodes * S : nullptr);
@@ -437,7 +433,7 @@ extern "C" int socp_chains_solve(socp_ctx *ctx, int P, const socp_chain_options 
             }
             if (kc) {
                 if (hipStreamSynchronize(main_stream) != hipSuccess) { rc = SOCP_ERR_HIP; break; }
-                t_gpu += ms_since(tg);
+                t_gpu += ms_since(t_chunk);
                 const clk::time_point tc = clk::now();
                 if (hipMemcpy(hJ.p, dJ.p, jacB * kc, hipMemcpyDeviceToHost) != hipSuccess) { rc = SOCP_ERR_HIP; break; }
                 parallel_for(kc, [&](int k) { std::memcpy(ch[reqJ[j0 + k]].xout, hJ.d() + (size_t)k * n * n, jacB); });

@@ -245,6 +245,8 @@ int socp_ctx_get_params(const socp_ctx *c, double *params, int nparams)
     return SOCP_OK;
 }
 
+int socp_ctx_num_params(const socp_ctx *c) { return c ? c->nparams : SOCP_ERR_ARG; }
+
 int socp_ctx_set_step_number(socp_ctx *c, int step_nbr)
 {
     if (!c) return SOCP_ERR_ARG;

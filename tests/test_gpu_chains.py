@@ -245,3 +245,68 @@ def test_round_limit_stops_stragglers_only():
     assert np.array_equal(cut["z"][~stopped], full["z"][~stopped]) and np.array_equal(cut["info"][~stopped], full["info"][~stopped])
     assert np.array_equal(cut["nfev"][~stopped], full["nfev"][~stopped])
     ctx.close()
+
+
+def test_covid_program_continuations_as_chains():
+    """The two continuations of the reference's tests/testCovid19.cpp -- SolveOCP(0.1) on the final target (R: 0.6 -> 0.7) and
+    SolveOCP(0.01) on the horizon (tf: 30 -> 365 days, 100 homotopy steps) -- M = 20, n = 160, as boundary-data chains
+    (shooting.cpp:598-692).  The chain that reproduces the program's own data must end on the program's unknowns bit for bit
+    (covid19 has + - * / only: the C++ mirror's solves are the CPU path's); the chains beside it (other targets / horizons)
+    must equal the sequential loop run for each of them alone."""
+    from socp_amd import capi
+    exe = os.path.join(ROOT, "socp_amd", "_build", "bin", "covid_flow")
+    out = subprocess.run([exe, "1e-8", "3"], capture_output=True, text=True, timeout=900, env=dict(os.environ, SOCP_VARIANT="exact"))
+    prog = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert [s["info"] for s in prog] == [1, 1, 1], out.stderr
+
+    M, d, s = 20, 4, 8
+    ctx = capi.Context(capi.MODEL_COVID19)
+    ctx.set_params([3.4, 14, 5, 1, 0.1, 1, -10, 20])
+    ctx.set_variant(capi.VARIANT_LANE_EXACT)
+    mode_t = [capi.FIXED] + [capi.CONTINUOUS] * (M - 1) + [capi.FIXED]
+    mode_x = np.zeros((M + 1, d), dtype=np.int32)
+    mode_x[1:M] = capi.CONTINUOUS
+    mode_x[M, :3] = capi.FREE
+    Xi = np.array([0.93, 0.003, 0.01, 0.057, -0.001, 0.001, 0.0, 0.0])
+    time30 = np.array([0.0 + i * (30.0 - 0.0) / M for i in range(M + 1)])
+    X = np.zeros((M + 1, s))
+    X[0] = Xi
+    X[1:M] = ctx.integrate_batch(np.zeros(M - 1), time30[1:M], np.repeat(Xi[None, :], M - 1, axis=0))     # InitShooting's Move
+    X[M, 3] = 0.6
+    assert ctx.problem_set(mode_t, mode_x, time30, X) == 160
+
+    def data(tf, target):
+        T = time30.copy()
+        T[M] = tf
+        Xd = X.copy()
+        Xd[M, 3] = target
+        return T, Xd.ravel()
+
+    # ---- stage 2: target continuation, step 0.1; chain 0 is the program's, the others aim elsewhere
+    z1 = np.array(prog[0]["z"])
+    targets = [0.7, 0.65, 0.72]
+    Tp, Xp = data(30.0, 0.6)
+    goal = [data(30.0, t) for t in targets]
+    P = len(targets)
+    res = ctx.chains_solve(np.tile(z1, (P, 1)), kind=2, step=0.1, time_prev=np.tile(Tp, (P, 1)), x_prev=np.tile(Xp, (P, 1)),
+                           time_goal=np.array([g[0] for g in goal]), x_goal=np.array([g[1] for g in goal]), xtol=1e-8)
+    # 11 solves, not 10: b = 0.1 + 0.1 + ... reaches 0.9999999999999999 after ten steps and the loop adds min(b + step, 1)
+    assert np.all(res["info"] == 1) and np.all(res["solves"] == 11)
+    assert np.array_equal(res["z"][0], np.array(prog[1]["z"])) and res["nfev"][0] == prog[1]["nfev"]
+    for p in (1, 2):
+        def set_b(b, p=p):
+            ctx.problem_set(mode_t, mode_x, (1 - b) * Tp + b * goal[p][0], ((1 - b) * Xp + b * goal[p][1]).reshape(M + 1, s))
+        q = sequential_chain(ctx, z1, 0.1, 1e-12, 1e-8, set_b)
+        assert q["info"] == 1 and np.array_equal(res["z"][p], q["z"]) and res["nfev_total"][p] == q["nfev_total"], p
+    # ---- stage 3: horizon continuation, step 0.01 (100 solves per chain); chain 0 is the program's
+    z2 = np.array(prog[1]["z"])
+    horizons = [365.0, 200.0]
+    Tp, Xp = data(30.0, 0.7)
+    goal = [data(h, 0.7) for h in horizons]
+    P = len(horizons)
+    ctx.problem_set(mode_t, mode_x, Tp, Xp.reshape(M + 1, s))
+    res = ctx.chains_solve(np.tile(z2, (P, 1)), kind=2, step=0.01, time_prev=np.tile(Tp, (P, 1)), x_prev=np.tile(Xp, (P, 1)),
+                           time_goal=np.array([g[0] for g in goal]), x_goal=np.array([g[1] for g in goal]), xtol=1e-8)
+    assert np.all(res["info"] == 1) and np.all(res["solves"] >= 100) and np.all(res["b_reached"] == 1.0)
+    assert np.array_equal(res["z"][0], np.array(prog[2]["z"])) and res["nfev"][0] == prog[2]["nfev"]
+    ctx.close()
