@@ -310,3 +310,57 @@ def test_covid_program_continuations_as_chains():
     assert np.all(res["info"] == 1) and np.all(res["solves"] >= 100) and np.all(res["b_reached"] == 1.0)
     assert np.array_equal(res["z"][0], np.array(prog[2]["z"])) and res["nfev"][0] == prog[2]["nfev"]
     ctx.close()
+
+
+def test_interceptor_program_continuations_as_chains():
+    """The reference's tests/testInterceptor.cpp (scenario 1): continuation on the model parameter mu_gft 0 -> 1, step 0.1
+    (shooting.cpp:695-778), then on the boundary data towards the scenario, step 0.1, with a FREE final time
+    (shooting.cpp:598-692) -- as chains.  The interceptor is a table-driven model with its own ComputeTraj and final rows: this
+    drives the per-problem instantiations of ITS kernels.  The C++ mirror's program runs the same device arithmetic through the
+    shared-parameter kernels, so the chain must end on its unknowns bit for bit."""
+    from socp_amd import capi
+    exe = os.path.join(ROOT, "socp_amd", "_build", "bin", "interceptor_flow")
+    out = subprocess.run([exe, "1e-8", "1"], capture_output=True, text=True, timeout=900, env=dict(os.environ, SOCP_VARIANT="exact"))
+    prog = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert [s["stage"] for s in prog] == ["analytical_guess", "mu_gft_continuation", "scenario_continuation"], out.stderr
+    assert [s["info"] for s in prog] == [1, 1, 1]
+
+    RE = 6378145.0
+    ctx = capi.Context(capi.MODEL_INTERCEPTOR)
+    ctx.set_variant(capi.VARIANT_LANE_EXACT)
+    names = capi.INTERCEPTOR_PARAM_NAMES
+    MU = names.index("mu_gft")
+    mode_t = [capi.FIXED, capi.FREE]
+    mode_x = np.zeros((2, 6), dtype=np.int32)
+    mode_x[1, 1] = capi.FREE
+    X = np.zeros((2, 12))
+    X[0, :6] = [1000, 1000, np.pi / 4, 0.0, 5454661 / RE, 46086 / RE]
+    X[1, :6] = [6000, 1000, 0.01 * np.pi, 0.01 * np.pi, (5454661 + 27829.0) / RE, 46086 / RE]
+    assert ctx.problem_set(mode_t, mode_x, [0.0, 10.0], X) == 13
+    # ---- stage 2: mu_gft 0 -> 1, step 0.1, from the converged mu_gft = 0 solution; a second chain aims at 0.6
+    z1 = np.array(prog[0]["z"])
+    p0 = ctx.get_params()
+    p0[MU] = 0.0
+    goals = np.array([1.0, 0.6])
+    res = ctx.chains_solve(np.tile(z1, (2, 1)), kind=1, param_index=MU, step=0.1, goal=goals, params=np.tile(p0, (2, 1)), xtol=1e-8)
+    assert np.all(res["info"] == 1) and np.all(res["param_final"] == goals)
+    assert np.array_equal(res["z"][0], np.array(prog[1]["z"])) and res["nfev"][0] == prog[1]["nfev"]
+    # ---- stage 3: boundary data towards scenario 1, FREE tf; previous data = the stage-2 solution (GetSolution: final node =
+    #      the final state of the stored trajectory)
+    z2 = res["z"][0]
+    ctx.set_param("mu_gft", 1.0)
+    t_end = z2[12]
+    X_end = ctx.integrate_batch(0.0, t_end, z2[None, :12])[0]
+    Xp = np.zeros((2, 12))
+    Xp[0], Xp[1] = z2[:12], X_end
+    Tp = np.array([0.0, t_end])
+    Xg = np.zeros((2, 12))
+    Xg[0, :6] = [3000, 1000, -np.pi / 6, 0.0, 5454661 / RE, 46086 / RE]
+    Xg[1, :6] = [12000, 1000, 0.0, np.pi / 8, 5475000 / RE, 42000 / RE]
+    Tg = np.array([0.0, 20.0])
+    ctx.problem_set(mode_t, mode_x, Tp, Xp)
+    res3 = ctx.chains_solve(z2[None, :], kind=2, step=0.1, time_prev=Tp[None, :], x_prev=Xp.ravel()[None, :], time_goal=Tg[None, :],
+                            x_goal=Xg.ravel()[None, :], xtol=1e-8)
+    assert res3["info"][0] == 1 and res3["b_reached"][0] == 1.0
+    assert np.array_equal(res3["z"][0], np.array(prog[2]["z"])) and res3["nfev"][0] == prog[2]["nfev"]
+    ctx.close()
