@@ -80,6 +80,9 @@ def parse_args(argv=None):
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo + --share-device0: rehearse the multi-rank path on a one-GPU box (collectives on CPU tensors)")
     ap.add_argument("--share-device0", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal only: initialise torch.distributed and run the barrier / all_reduce / all_gather of the N > 1 path "
+                         "even with ONE rank -- exercises the RCCL (backend nccl) code path on a one-GPU box")
     ap.add_argument("--lean", action="store_true",
                     help="N = 1: only the headline timed region, roofline and cpu_baseline (no exact / parity / "
                          "single_problem / north_star_128 legs)")
@@ -228,7 +231,7 @@ def cpu_baseline_b0(steps_rk4, target_seconds):
                          "" if steps == steps_rk4 else "; rate scaled to %d steps" % steps_rk4)}
 
 
-def timed_region(torch, dist, ctx, stream, dev, cdev, world, P, d_Z, d_rows, d_J, steps, warmup):
+def timed_region(torch, dist, ctx, stream, dev, cdev, world, P, d_Z, d_rows, d_J, steps, warmup, collective=None):
     """W untimed steps, then exactly K steps between fences (sync + barrier + sync); returns (max-over-ranks seconds,
     mean HIP-event ms of the dominant kernel on the stream it is launched on)."""
     def step(events=None):
@@ -239,9 +242,11 @@ def timed_region(torch, dist, ctx, stream, dev, cdev, world, P, d_Z, d_rows, d_J
             events[1].record(stream)
         ctx.fd_diff_dev(P, d_Z.data_ptr(), EPSFCN, d_rows.data_ptr(), d_J.data_ptr())
 
+    collective = (world > 1) if collective is None else collective
+
     def fence():
         torch.cuda.synchronize(dev)          # this rank's own launches are done ...
-        if world > 1:
+        if collective:
             dist.barrier()                   # ... and so are everybody else's
         torch.cuda.synchronize(dev)
 
@@ -255,7 +260,7 @@ def timed_region(torch, dist, ctx, stream, dev, cdev, world, P, d_Z, d_rows, d_J
     fence()
     elapsed = time.perf_counter() - t0
     t_max = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-    if world > 1:
+    if collective:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
     return float(t_max.item()), float(np.mean([a.elapsed_time(b) for a, b in evs]))
 
@@ -365,6 +370,13 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))            # nothing above has touched the GPU (torch is not even imported yet)
 
+    # stdout carries exactly ONE line, the JSON record: native libraries write there too (RCCL prints a version banner on
+    # process-group creation), so file descriptor 1 is pointed at stderr for the duration of the run and the record goes to the
+    # saved descriptor at the end
+    sys.stdout.flush()
+    record_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from socp_amd import capi
@@ -374,8 +386,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and rank == 0:
         sys.stderr.write("bench.py: --gpus %d but the launcher started %d ranks; reporting n_gpus = %d\n" % (args.gpus, world, world))
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.share_device0:
             local_rank = 0
@@ -403,7 +417,8 @@ def main():
     d_rows = torch.empty((P, ROWS, N_UNKNOWN), dtype=torch.float64, device=dev)
     d_J = torch.empty((P, N_UNKNOWN, N_UNKNOWN), dtype=torch.float64, device=dev)
 
-    elapsed_max, kernel_ms = timed_region(torch, dist, ctx, stream, dev, cdev, world, P, d_Z, d_rows, d_J, args.steps, args.warmup)
+    elapsed_max, kernel_ms = timed_region(torch, dist, ctx, stream, dev, cdev, world, P, d_Z, d_rows, d_J, args.steps, args.warmup,
+                                          collective=use_dist)
     traj_per_step_rank = P * ROWS
 
     # result record of this rank (checksum of the Jacobians, finite count): the only exchange of the
@@ -411,7 +426,7 @@ def main():
     finite = int(torch.isfinite(d_J).all(dim=(1, 2)).sum().item())
     rec = torch.tensor([float(rank), float(finite), float(torch.nan_to_num(d_J).abs().sum().item())],
                        dtype=torch.float64, device=cdev)
-    if world > 1:
+    if use_dist:
         gathered = [torch.empty_like(rec) for _ in range(world)]
         dist.all_gather(gathered, rec)
         recs = [g.tolist() for g in gathered]
@@ -507,10 +522,11 @@ def main():
             out["north_star_128"] = north_star_128(capi, local_rank, args.rk4_steps, cpu_v)
             if cpu_v:
                 out["north_star_128"]["cpu_baseline_value"] = cpu_v
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(record_fd, (json.dumps(out) + "\n").encode())
 
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     sys.exit(status)

@@ -65,3 +65,15 @@ def test_gpus_2_really_runs_two_ranks():
     assert d["config"]["trajectories_per_step_per_gpu"] == 1024 * 15
     assert abs(d["value"] - 2 * 1024 * 15 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
     assert "cpu_baseline" not in d and "exact" not in d               # N = 1 extras only
+
+
+def test_rccl_code_path_with_one_rank():
+    """The N > 1 path talks to RCCL (torch.distributed backend "nccl"): process-group creation with a device id, barrier,
+    all_reduce(MAX) of the timing and all_gather of the result records on DEVICE tensors.  A one-GPU box cannot host two RCCL
+    ranks, so this runs that exact code with a world of one (--force-dist); the two-rank plumbing is the gloo test above."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--lean", "--steps", "2", "--warmup", "1",
+                          "--starts", "1024", "--rk4-steps", "1000", "--cpu-seconds", "0"],
+                         capture_output=True, text=True, timeout=900)
+    d = _line(out)
+    assert d["n_gpus"] == 1 and d["ranks_reported"] == 1 and d["finite_jacobians"] == [1024]
+    assert abs(d["value"] - 1024 * 15 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
