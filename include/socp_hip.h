@@ -198,6 +198,9 @@ int socp_fd_diff_dev(socp_ctx *ctx, int np, const double *d_Z, double epsfcn, co
  * for models with modelOrder == 1; fjac column-major as handed to hybrj (shooting.cpp:889-893).
  * The variational state is integrated with fixed-step RK4 only: SOCP_ERR_UNSUPPORTED under SOCP_INT_DOPRI5. */
 int socp_var_jacobian(socp_ctx *ctx, const double *z, double *fjac);
+/* The same for `np` unknown vectors of one problem structure, device pointers: Z[np][n] -> Fjac[np][n*n]; one wavefront per
+ * (problem, segment); per-problem blocks (socp_problem_set_blocks_dev) apply. */
+int socp_var_jacobian_multi_dev(socp_ctx *ctx, int np, const double *d_Z, double *d_Fjac);
 
 #ifdef __cplusplus
 }

@@ -103,6 +103,10 @@ typedef struct socp_chain_options {
                                  info = SOCP_INFO_ROUND_LIMIT, like a callback returning < 0 (shooting.cpp:873): a sweep's wall
                                  time is rounds x one trajectory latency and the round count is set by its slowest chain
                                  (typically one that ends in info 4/5 anyway).  The other chains' iterates do not change. */
+    int analytic_jac;         /* 0: hybrd, forward-difference Jacobians (modelOrder 0).  1: hybrj with the variational Jacobian
+                                 (modelOrder 1, shooting.cpp:828-852,996-1130; models with variational equations only): the
+                                 Jacobian requests of a round are one batched variational integration, one wavefront per
+                                 (chain, segment); nfev / njev are accounted as hybrj does. */
 } socp_chain_options;
 #define SOCP_INFO_ROUND_LIMIT (-3)
 
@@ -128,6 +132,11 @@ int socp_chains_solve(struct socp_ctx *ctx, int P, const socp_chain_options *opt
                       const double *goal, const double *time_prev, const double *x_prev, const double *time_goal,
                       const double *x_goal, double *Zout, int *info, int *nfev_last, int *nfev_total, int *solves,
                       double *b_reached, double *param_final, double *fnorm, socp_chain_stats *stats);
+/* the same with njev_last[P] (Jacobian evaluations of the last solve: what GetCallNumber()[1] reports on the hybrj path) */
+int socp_chains_solve_ex(struct socp_ctx *ctx, int P, const socp_chain_options *opt, const double *Z0, const double *params,
+                         const double *goal, const double *time_prev, const double *x_prev, const double *time_goal,
+                         const double *x_goal, double *Zout, int *info, int *nfev_last, int *nfev_total, int *njev_last,
+                         int *solves, double *b_reached, double *param_final, double *fnorm, socp_chain_stats *stats);
 
 #ifdef __cplusplus
 }

@@ -40,7 +40,7 @@ class ChainOptions(C.Structure):
     """socp_chain_options (include/socp_solver.h)."""
     _fields_ = [("kind", C.c_int), ("param_index", C.c_int), ("step", C.c_double), ("step_min", C.c_double),
                 ("xtol", C.c_double), ("maxfev", C.c_int), ("epsfcn", C.c_double), ("factor", C.c_double),
-                ("dedup", C.c_int), ("speculate", C.c_int), ("max_rounds", C.c_int)]
+                ("dedup", C.c_int), ("speculate", C.c_int), ("max_rounds", C.c_int), ("analytic_jac", C.c_int)]
 
 
 class ChainStats(C.Structure):
@@ -116,6 +116,9 @@ def lib():
         L.socp_ctx_get_switching_times.argtypes = [_vp, _dp]
         L.socp_chains_solve.argtypes = [_vp, C.c_int, C.POINTER(ChainOptions), _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _ip,
                                         _ip, _dp, _dp, _dp, C.POINTER(ChainStats)]
+        L.socp_chains_solve_ex.argtypes = [_vp, C.c_int, C.POINTER(ChainOptions), _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _ip,
+                                           _ip, _ip, _dp, _dp, _dp, C.POINTER(ChainStats)]
+        L.socp_var_jacobian_multi_dev.argtypes = [_vp, C.c_int, _vp, _vp]
         L.socp_multistart_solve.argtypes = [_vp, C.c_int, _dp, C.c_double, C.c_int, C.c_double, C.c_double, C.c_int,
                                             _dp, _ip, _ip, _dp, C.POINTER(C.c_longlong)]
         L.hybrd.argtypes = [FCN, _vp, C.c_int, _dp, _dp, C.c_double, C.c_int, C.c_int, C.c_int, C.c_double,
@@ -381,12 +384,12 @@ class Context:
 
     def chains_solve(self, Z0, kind=CHAIN_PLAIN, param_index=0, step=1.0, step_min=1e-12, goal=None, params=None,
                      time_prev=None, x_prev=None, time_goal=None, x_goal=None, xtol=1e-8, maxfev=10000, epsfcn=1e-15,
-                     factor=1.0, dedup=True, speculate=-1, max_rounds=0):
+                     factor=1.0, dedup=True, speculate=-1, max_rounds=0, analytic_jac=False):
         """Lock-step continuation chains (socp_chains_solve).  Returns a dict of per-chain arrays + 'stats'."""
         Z0 = _f64(Z0).reshape(-1, self.n)
         P = Z0.shape[0]
         opt = ChainOptions(int(kind), int(param_index), float(step), float(step_min), float(xtol), int(maxfev), float(epsfcn),
-                           float(factor), int(bool(dedup)), int(speculate), int(max_rounds))
+                           float(factor), int(bool(dedup)), int(speculate), int(max_rounds), int(bool(analytic_jac)))
         keep = []
 
         def arr(a, width=None):
@@ -401,16 +404,17 @@ class Context:
         nfev_last = np.zeros(P, dtype=np.int32)
         nfev_total = np.zeros(P, dtype=np.int32)
         solves = np.zeros(P, dtype=np.int32)
+        njev = np.zeros(P, dtype=np.int32)
         b = np.zeros(P)
         pf = np.zeros(P)
         fn = np.zeros(P)
         st = ChainStats()
         ip = lambda a: a.ctypes.data_as(_ip)  # noqa: E731
-        self._chk(self.L.socp_chains_solve(self.h, P, C.byref(opt), _d(Z0), arr(params, len(self.get_params())), arr(goal),
-                                           arr(time_prev, nodes), arr(x_prev, nodes * self.s), arr(time_goal, nodes),
-                                           arr(x_goal, nodes * self.s), _d(Z), ip(info), ip(nfev_last), ip(nfev_total), ip(solves),
-                                           _d(b), _d(pf), _d(fn), C.byref(st)))
-        return dict(z=Z, info=info, nfev=nfev_last, nfev_total=nfev_total, solves=solves, b_reached=b, param_final=pf, fnorm=fn,
+        self._chk(self.L.socp_chains_solve_ex(self.h, P, C.byref(opt), _d(Z0), arr(params, len(self.get_params())), arr(goal),
+                                              arr(time_prev, nodes), arr(x_prev, nodes * self.s), arr(time_goal, nodes),
+                                              arr(x_goal, nodes * self.s), _d(Z), ip(info), ip(nfev_last), ip(nfev_total), ip(njev),
+                                              ip(solves), _d(b), _d(pf), _d(fn), C.byref(st)))
+        return dict(z=Z, info=info, nfev=nfev_last, nfev_total=nfev_total, njev=njev, solves=solves, b_reached=b, param_final=pf, fnorm=fn,
                     stats={k: getattr(st, k) for k, _ in ChainStats._fields_})
 
     def fd_jacobian_dev(self, d_z, d_fvec, epsfcn, d_fjac, dedup=False):

@@ -103,6 +103,15 @@ extern "C" int socp_chains_solve(socp_ctx *ctx, int P, const socp_chain_options 
                                  const double *x_goal, double *Zout, int *info, int *nfev_last, int *nfev_total, int *solves,
                                  double *b_reached, double *param_final, double *fnorm, socp_chain_stats *stats)
 {
+    return socp_chains_solve_ex(ctx, P, opt, Z0, params, goal, time_prev, x_prev, time_goal, x_goal, Zout, info, nfev_last, nfev_total,
+                                nullptr, solves, b_reached, param_final, fnorm, stats);
+}
+
+extern "C" int socp_chains_solve_ex(socp_ctx *ctx, int P, const socp_chain_options *opt, const double *Z0, const double *params,
+                                    const double *goal, const double *time_prev, const double *x_prev, const double *time_goal,
+                                    const double *x_goal, double *Zout, int *info, int *nfev_last, int *nfev_total, int *njev_last,
+                                    int *solves, double *b_reached, double *param_final, double *fnorm, socp_chain_stats *stats)
+{
     if (!ctx || !opt || P < 0 || (P > 0 && (!Z0 || !Zout || !info))) return SOCP_ERR_ARG;
     const int n = socp_problem_num_param(ctx);
     if (n <= 0) return SOCP_ERR_ARG;
@@ -170,7 +179,7 @@ extern "C" int socp_chains_solve(socp_ctx *ctx, int P, const socp_chain_options 
     bool alloc_ok = true;
     parallel_for(P, [&](int p) {
         Chain &c = ch[p];
-        c.solver = socp_hybr_create(n, opt->xtol, opt->maxfev, opt->epsfcn, 1, opt->factor, 0);
+        c.solver = socp_hybr_create(n, opt->xtol, opt->maxfev, opt->epsfcn, 1, opt->factor, opt->analytic_jac ? 1 : 0);
         c.committed.assign(Z0 + (size_t)p * n, Z0 + (size_t)(p + 1) * n);
         c.eval_x.resize(n); c.slot_x.resize(n);
         if (pp_params) {
@@ -197,6 +206,7 @@ extern "C" int socp_chains_solve(socp_ctx *ctx, int P, const socp_chain_options 
     int speculate = opt->speculate;
     if (const char *e = std::getenv("SOCP_CHAINS_SPECULATE")) speculate = std::atoi(e);
     if ((double)P * rowsB * 2 > 16e9) speculate = 0;              // slots + staging would not be "free"
+    if (opt->analytic_jac) speculate = 0;                          // no finite differences on the hybrj path
     const bool spec_on = speculate != 0;
     Pinned hX, hF, hJx, hJf, hJ, hPF, hTF, hXF, hPJ, hTJ, hXJ, hIdx;
     Dev dX, dF, dJx, dJf, dJ, dPF, dTF, dXF, dPJ, dTJ, dXJ, dStage, dSlots, dIdx;
@@ -420,7 +430,10 @@ extern "C" int socp_chains_solve(socp_ctx *ctx, int P, const socp_chain_options 
             if (kc) {
                 socp_problem_set_blocks_dev(ctx, pp_params ? dPJ.d() + (size_t)j0 * stride : nullptr, stride,
                                             pp_bound ? dTJ.d() + (size_t)j0 * nodes : nullptr, pp_bound ? dXJ.d() + (size_t)j0 * nodes * S : nullptr);
-                if ((rc = socp_fd_jacobian_multi_dev(ctx, kc, dJx.d() + (size_t)j0 * n, dJf.d() + (size_t)j0 * n, opt->epsfcn, dJ.d(), opt->dedup)) != SOCP_OK) break;
+                rc = opt->analytic_jac
+                         ? socp_var_jacobian_multi_dev(ctx, kc, dJx.d() + (size_t)j0 * n, dJ.d())
+                         : socp_fd_jacobian_multi_dev(ctx, kc, dJx.d() + (size_t)j0 * n, dJf.d() + (size_t)j0 * n, opt->epsfcn, dJ.d(), opt->dedup);
+                if (rc != SOCP_OK) break;
             }
             if (!f_collected) {
                 // F of the speculative requests is row 0 of their (n+1) x n block
@@ -452,6 +465,7 @@ extern "C" int socp_chains_solve(socp_ctx *ctx, int P, const socp_chain_options 
             info[p] = c.info;
             if (nfev_last) nfev_last[p] = c.nfev_last;
             if (nfev_total) nfev_total[p] = c.nfev_total;
+            if (njev_last) njev_last[p] = socp_hybr_njev(c.solver);
             if (solves) solves[p] = c.solves;
             if (b_reached) b_reached[p] = kind == SOCP_CHAIN_PLAIN ? 1.0 : (c.info == 1 ? c.b : c.b_prec);
             if (param_final) param_final[p] = kind == SOCP_CHAIN_PARAM ? pblock[(size_t)p * stride + opt->param_index] : 0.0;

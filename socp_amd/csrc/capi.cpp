@@ -67,7 +67,7 @@ struct socp_ctx {
     int T_full = 0, T_dedup = 0;
 
     // grow-only staging for the host-pointer entry points
-    DevBuf s_t0, s_tf, s_sw, s_in, s_out, s_aux;
+    DevBuf s_t0, s_tf, s_sw, s_in, s_out, s_aux, s_var;
 
     long long n_traj = 0, n_launch = 0;
     std::string err;
@@ -224,7 +224,7 @@ int socp_ctx_destroy(socp_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     c->d_tables.release(); c->d_pairs_full.release(); c->d_pairs_dedup.release();
-    c->s_t0.release(); c->s_tf.release(); c->s_sw.release(); c->s_in.release(); c->s_out.release(); c->s_aux.release();
+    c->s_t0.release(); c->s_tf.release(); c->s_sw.release(); c->s_in.release(); c->s_out.release(); c->s_aux.release(); c->s_var.release();
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return SOCP_OK;
@@ -778,27 +778,36 @@ int socp_plugin_load(const char *path)
     return reg();        // the handle stays open: the kernels live in it
 }
 
+int socp_var_jacobian_multi_dev(socp_ctx *c, int np, const double *d_Z, double *d_Fjac)
+{
+    if (!c) return SOCP_ERR_ARG;
+    if (!c->has_problem) return fail(c, SOCP_ERR_ARG, "var_jacobian: no problem set");
+    if (np < 0 || (np > 0 && (!d_Z || !d_Fjac))) return fail(c, SOCP_ERR_ARG, "var_jacobian: null argument");
+    if (c->model_id != SOCP_MODEL_DOUBLE_INTEGRATOR)
+        return fail(c, SOCP_ERR_UNSUPPORTED, "var_jacobian: this model has no variational equations (modelOrder 0)");
+    if (c->P.integrator != SOCP_INT_RK4)
+        return fail(c, SOCP_ERR_UNSUPPORTED, "var_jacobian: the variational state is integrated with fixed-step RK4 only");
+    if (np == 0) return SOCP_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t M = c->M, L = (size_t)(c->S + 1) * c->S, B = (size_t)np * M;
+    HIP_TRY(c, c->s_var.reserve(sizeof(double) * (2 * B * L + 2 * B)));
+    double *Xaug = c->s_var.as<double>(), *Xtf = Xaug + B * L, *t0 = Xtf + B * L, *tf = t0 + B;
+    c->n_traj += (long long)B; c->n_launch += 3;
+    HIP_TRY(c, var_jacobian(c->model_id, c->stream, c->P, c->pb, np, d_Z, Xaug, Xtf, t0, tf, d_Fjac));
+    return SOCP_OK;
+}
+
 int socp_var_jacobian(socp_ctx *c, const double *z, double *fjac)
 {
     if (!c) return SOCP_ERR_ARG;
     if (!c->has_problem) return fail(c, SOCP_ERR_ARG, "var_jacobian: no problem set");
     if (!z || !fjac) return fail(c, SOCP_ERR_ARG, "var_jacobian: null argument");
-    if (c->model_id != SOCP_MODEL_DOUBLE_INTEGRATOR)
-        return fail(c, SOCP_ERR_UNSUPPORTED, "var_jacobian: this model has no variational equations (modelOrder 0)");
-    if (c->P.integrator != SOCP_INT_RK4)
-        return fail(c, SOCP_ERR_UNSUPPORTED, "var_jacobian: the variational state is integrated with fixed-step RK4 only");
     HIP_TRY(c, hipSetDevice(c->device));
-    const size_t n = c->n, M = c->M, L = (size_t)(c->S + 1) * c->S;
+    const size_t n = c->n;
     HIP_TRY(c, c->s_in.reserve(sizeof(double) * n));
-    HIP_TRY(c, c->s_aux.reserve(sizeof(double) * 2 * M * L));
-    HIP_TRY(c, c->s_t0.reserve(sizeof(double) * M));
-    HIP_TRY(c, c->s_tf.reserve(sizeof(double) * M));
     HIP_TRY(c, c->s_out.reserve(sizeof(double) * n * n));
     HIP_TRY(c, hipMemcpyAsync(c->s_in.p, z, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
-    double *Xaug = c->s_aux.as<double>(), *Xtf = Xaug + M * L;
-    c->n_traj += (long long)M; c->n_launch += 3;
-    HIP_TRY(c, var_jacobian(c->model_id, c->stream, c->P, c->pb, c->s_in.as<double>(), Xaug, Xtf,
-                            c->s_t0.as<double>(), c->s_tf.as<double>(), c->s_out.as<double>()));
+    if (int rc = socp_var_jacobian_multi_dev(c, 1, c->s_in.as<double>(), c->s_out.as<double>())) return rc;
     HIP_TRY(c, hipMemcpyAsync(fjac, c->s_out.p, sizeof(double) * n * n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return SOCP_OK;

@@ -21,19 +21,21 @@ hipError_t var_traj(int model_id, hipStream_t st, const ModelParams &P, int B, c
 {
     if (model_id != 2) return hipErrorInvalidValue;
     if (B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(traj_var_wave_kernel<DIntVar>, dim3(B), dim3(64), 0, st, P, t0, tf, X0, Xf);
+    hipLaunchKernelGGL(traj_var_wave_kernel<DIntVar>, dim3(B), dim3(64), 0, st, P, t0, tf, X0, Xf, (const double *)nullptr, 0, 1);
     return hipGetLastError();
 }
 
-hipError_t var_jacobian(int model_id, hipStream_t st, const ModelParams &P, const ProblemDev &pb, const double *z,
+hipError_t var_jacobian(int model_id, hipStream_t st, const ModelParams &P, const ProblemDev &pb, int np, const double *z,
                         double *Xaug, double *Xtf, double *t0, double *tf, double *fjac)
 {
     if (model_id != 2) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(var_prepare_kernel<DIntVar>, dim3(pb.M), dim3(64), 0, st, pb, z, Xaug, t0, tf);
-    hipLaunchKernelGGL(traj_var_wave_kernel<DIntVar>, dim3(pb.M), dim3(64), 0, st, P, t0, tf, Xaug, Xtf);
-    hipError_t e = hipMemsetAsync(fjac, 0, sizeof(double) * (size_t)pb.n * pb.n, st);
+    if (np <= 0) return hipSuccess;
+    const unsigned B = (unsigned)((long)np * pb.M);                 // one wavefront per (problem, segment)
+    hipLaunchKernelGGL(var_prepare_kernel<DIntVar>, dim3(B), dim3(64), 0, st, pb, z, Xaug, t0, tf);
+    hipLaunchKernelGGL(traj_var_wave_kernel<DIntVar>, dim3(B), dim3(64), 0, st, P, t0, tf, Xaug, Xtf, pb.pp_params, pb.pp_stride, pb.M);
+    hipError_t e = hipMemsetAsync(fjac, 0, sizeof(double) * (size_t)np * pb.n * pb.n, st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(var_assemble_kernel<DIntVar>, dim3((pb.M + 63) / 64), dim3(64), 0, st, P, pb, z, Xtf, fjac);
+    hipLaunchKernelGGL(var_assemble_kernel<DIntVar>, dim3((B + 63) / 64), dim3(64), 0, st, P, pb, np, z, Xtf, fjac);
     return hipGetLastError();
 }
 

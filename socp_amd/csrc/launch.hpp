@@ -73,7 +73,7 @@ SOCP_DECLARE_LAUNCHERS(exact)
 // variational (hybrj) path: double integrator only; reference operation order
 hipError_t var_traj(int model_id, hipStream_t st, const ModelParams &P, int B, const double *t0, const double *tf,
                     const double *X0, double *Xf);
-hipError_t var_jacobian(int model_id, hipStream_t st, const ModelParams &P, const ProblemDev &pb, const double *z,
+hipError_t var_jacobian(int model_id, hipStream_t st, const ModelParams &P, const ProblemDev &pb, int np, const double *z,
                         double *Xaug, double *Xtf, double *t0, double *tf, double *fjac);
 hipError_t var_eval(int model_id, hipStream_t st, const ModelParams &P, int what, int B, const double *X, int len,
                     double *out);

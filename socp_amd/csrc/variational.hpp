@@ -55,18 +55,26 @@ struct DIntVar : DIntExact {
     }
 };
 
-// K_var: B augmented trajectories, one wave each.  X0, Xf: [B][L].
+// K_var: B augmented trajectories, one wave each.  X0, Xf: [B][L].  pp_params (may be null): per-problem parameter blocks
+// [B / M][pp_stride] (dev_common.hpp), trajectory b belongs to problem b / M.
 template <class Mdl>
 __global__ __launch_bounds__(64) void traj_var_wave_kernel(ModelParams P, const double *__restrict__ t0,
                                                            const double *__restrict__ tf,
                                                            const double *__restrict__ X0,
-                                                           double *__restrict__ Xf)
+                                                           double *__restrict__ Xf,
+                                                           const double *__restrict__ pp_params, int pp_stride, int M)
 {
     constexpr int L = Mdl::L;
     constexpr int K = (L + 63) / 64;
     __shared__ double Y[L];
     const int lane = threadIdx.x;
     const long b = blockIdx.x;
+    if (pp_params) {
+        const double *src = pp_params + (b / M) * pp_stride;
+#pragma unroll
+        for (int k = 0; k < kMaxParams; k++)
+            if (k < pp_stride - 2) P.p[k] = src[k];
+    }
     double X[K], F1[K], Fs[K], F[K], V[K];
 #pragma unroll
     for (int k = 0; k < K; k++) {
@@ -110,19 +118,23 @@ __global__ __launch_bounds__(64) void traj_var_wave_kernel(ModelParams P, const 
 
 // K_vprep: augmented initial states and segment bounds of one unknown vector z:
 // Xaug[i] = [z_i ; I] (shooting.cpp:1003-1005,1060-1064), t0[i], tf[i] from the timeline.
+// One block per (problem, segment): Zb[np][n] -> Xaug[np * M][L], t0 / tf[np * M]; per-problem boundary tables when set.
 template <class Mdl>
-__global__ void var_prepare_kernel(ProblemDev pb, const double *__restrict__ z, double *__restrict__ Xaug,
+__global__ void var_prepare_kernel(ProblemDev pb, const double *__restrict__ Zb, double *__restrict__ Xaug,
                                    double *__restrict__ t0, double *__restrict__ tf)
 {
     constexpr int S = Mdl::S, L = Mdl::L;
-    const int i = blockIdx.x;
+    const long prob = blockIdx.x / pb.M;
+    const int i = blockIdx.x - (int)prob * pb.M;
+    const double *z = Zb + prob * pb.n;
+    if (pb.pp_time) pb.time = pb.pp_time + prob * (pb.M + 1);
     for (int e = threadIdx.x; e < L; e += blockDim.x) {
         double v;
         if (e < S) v = z[S * i + e];
         else { const int k = (e - S) / S, c = (e - S) - k * S; v = (k == c) ? 1.0 : 0.0; }
-        Xaug[(long)i * L + e] = v;
+        Xaug[(long)blockIdx.x * L + e] = v;
     }
-    if (threadIdx.x == 0) { t0[i] = node_time(pb, z, i); tf[i] = node_time(pb, z, i + 1); }
+    if (threadIdx.x == 0) { t0[blockIdx.x] = node_time(pb, z, i); tf[blockIdx.x] = node_time(pb, z, i + 1); }
 }
 
 // K_vasm: analytic shooting Jacobian from the integrated augmented states (shooting.cpp:996-1130 with
@@ -130,17 +142,23 @@ __global__ void var_prepare_kernel(ProblemDev pb, const double *__restrict__ z, 
 // written column-major (the hand-over layout, shooting.cpp:889-893) into a zeroed n x n matrix.
 // The reference's quirks are kept: only d/dt_end terms exist, and at a FREE interior time the copy loop
 // of shooting.cpp:1070 also drops the time term one block to the right.
+// One thread per (problem, segment); Zb[np][n], Xtf_all[np * M][L] -> Fjac[np][n * n].
 template <class Mdl>
-__global__ void var_assemble_kernel(ModelParams P, ProblemDev pb, const double *__restrict__ z,
-                                    const double *__restrict__ Xtf_all, double *__restrict__ fjac)
+__global__ void var_assemble_kernel(ModelParams P, ProblemDev pb, int np, const double *__restrict__ Zb,
+                                    const double *__restrict__ Xtf_all, double *__restrict__ Fjac)
 {
     constexpr int S = Mdl::S, D = Mdl::D, L = Mdl::L;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int M = pb.M, n = pb.n;
-    if (i >= M) return;
+    if (gid >= (long)np * M) return;
+    const long prob = gid / M;
+    const int i = (int)(gid - prob * M);
+    load_problem_block(pb, prob, P, pb);                 // per-problem parameters / boundary tables when set (P, pb are by-value copies)
+    const double *z = Zb + prob * n;
+    double *fjac = Fjac + prob * (long)n * n;
     auto J = [&](int row, int col) -> double & { return fjac[row + (long)n * col]; };
     const double t1 = node_time(pb, z, i), t2 = node_time(pb, z, i + 1);
-    const double *Xtf = Xtf_all + (long)i * L;
+    const double *Xtf = Xtf_all + gid * L;
     const int index = S * (i + 1);
     auto ident = [](int k, int c) -> double { return k == c ? 1.0 : 0.0; };   // sensitivity block of [z ; I]
 

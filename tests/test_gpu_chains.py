@@ -364,3 +364,92 @@ def test_interceptor_program_continuations_as_chains():
     assert res3["info"][0] == 1 and res3["b_reached"][0] == 1.0
     assert np.array_equal(res3["z"][0], np.array(prog[2]["z"])) and res3["nfev"][0] == prog[2]["nfev"]
     ctx.close()
+
+
+@pytest.mark.parametrize("order", [1, 0])
+def test_double_integrator_program_continuations_as_chains(order):
+    """tests/testDoubleIntegrator.cpp: SolveOCP(1.0) on the boundary data (target y: 15 -> 20), then SolveOCP(1.0, muT, 0.02), with
+    the variational Jacobian (modelOrder 1, hybrj -- what the reference's test runs; `analytic_jac`) and with forward differences
+    (modelOrder 0, hybrd).  No transcendental function anywhere: the C++ mirror's program IS the CPU path, and the chain must end on
+    its unknowns, nfev and njev exactly.  A second chain with another goal runs beside it."""
+    from socp_amd import capi
+    exe = os.path.join(ROOT, "socp_amd", "_build", "bin", "dint_flow")
+    out = subprocess.run([exe, "basic", str(order), "1e-8"], capture_output=True, text=True, timeout=900)
+    prog = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert [s["stage"] for s in prog] == ["solve", "data_continuation", "muT_continuation"] and all(s["info"] == 1 for s in prog), out.stderr
+
+    ctx = capi.Context(capi.MODEL_DOUBLE_INTEGRATOR)
+    mode_t = [capi.FIXED, capi.FREE]
+    mode_x = np.zeros((2, 6), dtype=np.int32)
+    X = np.zeros((2, 12))
+    X[0, 6:] = 0.01
+    X[1, 0], X[1, 1] = 10.0, 15.0
+    T = np.array([0.0, 10.0])
+    assert ctx.problem_set(mode_t, mode_x, T, X) == 13
+    kw = dict(xtol=1e-8, analytic_jac=bool(order))
+    # the program's first solve, as a one-solve chain
+    z0 = np.concatenate([X[0], [10.0]])
+    r1 = ctx.chains_solve(z0[None, :], kind=0, **kw)
+    assert r1["info"][0] == 1 and np.array_equal(r1["z"][0], np.array(prog[0]["z"])) and r1["nfev"][0] == prog[0]["nfev"]
+    if order:
+        assert r1["njev"][0] == prog[0]["njev"]
+    # data continuation: y target 15 -> 20 (chain 0, the program's) and 15 -> 12 (chain 1)
+    Xg = np.tile(X.ravel(), (2, 1))
+    Xg[0, 12 + 1] = 20.0
+    Xg[1, 12 + 1] = 12.0
+    z1 = np.array(prog[0]["z"])
+    r2 = ctx.chains_solve(np.tile(z1, (2, 1)), kind=2, step=1.0, time_prev=np.tile(T, (2, 1)), x_prev=np.tile(X.ravel(), (2, 1)),
+                          time_goal=np.tile(T, (2, 1)), x_goal=Xg, **kw)
+    assert np.all(r2["info"] == 1)
+    assert np.array_equal(r2["z"][0], np.array(prog[1]["z"])) and r2["nfev"][0] == prog[1]["nfev"]
+    if order:
+        assert r2["njev"][0] == prog[1]["njev"]
+    assert not np.array_equal(r2["z"][1], r2["z"][0])
+    # parameter continuation muT 0.01 -> 0.02 on the new boundary data
+    ctx.problem_set(mode_t, mode_x, T, Xg[0].reshape(2, 12))
+    z2 = np.array(prog[1]["z"])
+    r3 = ctx.chains_solve(np.tile(z2, (2, 1)), kind=1, param_index=2, step=1.0, goal=np.array([0.02, 0.05]),
+                          params=np.tile(ctx.get_params(), (2, 1)), **kw)
+    assert r3["info"][0] == 1 and r3["param_final"][0] == 0.02
+    assert np.array_equal(r3["z"][0], np.array(prog[2]["z"])) and r3["nfev"][0] == prog[2]["nfev"]
+    if order:
+        assert r3["njev"][0] == prog[2]["njev"]
+    ctx.close()
+
+
+def test_batched_variational_jacobian_equals_one_problem_at_a_time():
+    """socp_var_jacobian_multi_dev through the chain engine's per-problem blocks: np problems with their own parameters and
+    boundary data in one launch == socp_var_jacobian of each problem alone, bit for bit (WP layout: FREE interior time, FIXED /
+    CONTINUOUS interior modes, M = 5)."""
+    import torch
+    from socp_amd import capi
+    ctx = capi.Context(capi.MODEL_DOUBLE_INTEGRATOR)
+    M = 5
+    mode_t = [capi.FIXED] + [capi.FREE] * M
+    mode_x = np.zeros((M + 1, 6), dtype=np.int32)
+    mode_x[1:M, 3:6] = capi.CONTINUOUS
+    X = np.zeros((M + 1, 12))
+    X[:, 0] = 20.0 * np.arange(M + 1) / M
+    X[:M, 6:] = 0.001
+    tn = 60.0 * np.arange(M + 1) / M
+    n = ctx.problem_set(mode_t, mode_x, tn, X)
+    rng = np.random.default_rng(2)
+    P = 7
+    Z = np.tile(np.concatenate([X[:M].ravel(), tn[1:]]), (P, 1)) * (1 + 1e-2 * rng.uniform(-1, 1, (P, n)))
+    params = np.tile(np.concatenate([ctx.get_params(), [0.0, 0.0]]), (P, 1))
+    params[:, 1] = 1.0 + 0.1 * np.arange(P)            # a_max per problem
+    params[:, 2] = 0.01 * (1 + np.arange(P))            # muT per problem
+    dev = torch.device("cuda", 0)
+    dZ = torch.from_numpy(Z).to(dev)
+    dP = torch.from_numpy(params).to(dev)
+    dJ = torch.empty((P, n * n), dtype=torch.float64, device=dev)
+    L = capi.lib()
+    assert L.socp_problem_set_blocks_dev(ctx.h, dP.data_ptr(), params.shape[1], None, None) == 0
+    assert L.socp_var_jacobian_multi_dev(ctx.h, P, dZ.data_ptr(), dJ.data_ptr()) == 0
+    ctx.synchronize()
+    L.socp_problem_set_blocks_dev(ctx.h, None, 0, None, None)
+    got = dJ.cpu().numpy().reshape(P, n, n).transpose(0, 2, 1)              # column-major -> J[row, col]
+    for q in range(P):
+        ctx.set_params(params[q, :3])
+        assert np.array_equal(got[q], ctx.var_jacobian(Z[q])), q
+    ctx.close()
