@@ -69,9 +69,11 @@ __global__ void copy_blocks_kernel(const double *__restrict__ src, const int *__
 
 bool copy_blocks(hipStream_t st, const double *src, const int *d_src_idx, double *dst, const int *d_dst_idx, int count, int len)
 {
-    if (count <= 0) return true;
     const unsigned gx = (unsigned)std::min(8, (len + 255) / 256);
-    hipLaunchKernelGGL(copy_blocks_kernel, dim3(gx, (unsigned)count), dim3(256), 0, st, src, d_src_idx, dst, d_dst_idx, count, len);
+    for (int k0 = 0; k0 < count; k0 += 32768) {                  // grid.y is limited to 65535
+        const int kc = std::min(32768, count - k0);
+        hipLaunchKernelGGL(copy_blocks_kernel, dim3(gx, (unsigned)kc), dim3(256), 0, st, src, d_src_idx + k0, dst, d_dst_idx + k0, kc, len);
+    }
     return hipGetLastError() == hipSuccess;
 }
 
