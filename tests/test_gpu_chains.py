@@ -453,3 +453,44 @@ def test_batched_variational_jacobian_equals_one_problem_at_a_time():
         ctx.set_params(params[q, :3])
         assert np.array_equal(got[q], ctx.var_jacobian(Z[q])), q
     ctx.close()
+
+
+@pytest.mark.parametrize("order", [1, 0])
+def test_double_integrator_waypoint_program_continuations_as_chains(order):
+    """tests/testDoubleIntegrator_WP.cpp (M = 2, FREE interior and final times, FIXED positions / CONTINUOUS velocities at the
+    way-point): its first solve does not converge and the reference ignores that (the unknowns stay at the initial guess,
+    shooting.cpp:588-592), then SolveOCP(1.0) moves the way-point data and SolveOCP(1.0, muT, 0.02) the parameter."""
+    from socp_amd import capi
+    exe = os.path.join(ROOT, "socp_amd", "_build", "bin", "dint_flow")
+    out = subprocess.run([exe, "wp", str(order), "1e-8"], capture_output=True, text=True, timeout=900)
+    prog = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert [s["stage"] for s in prog] == ["solve", "data_continuation", "muT_continuation"], out.stderr
+    assert prog[0]["info"] != 1 and prog[1]["info"] == 1 and prog[2]["info"] == 1
+
+    M = 2
+    ctx = capi.Context(capi.MODEL_DOUBLE_INTEGRATOR)
+    mode_t = [capi.FIXED, capi.FREE, capi.FREE]
+    mode_x = np.zeros((M + 1, 6), dtype=np.int32)
+    mode_x[1, 3:6] = capi.CONTINUOUS
+    vt = np.array([60.0 * i / M for i in range(M + 1)])
+    vX = np.zeros((M + 1, 12))
+    vX[:, 0] = [20.0 * i / M for i in range(M + 1)]
+    vX[:M, 6:] = 0.001
+    assert ctx.problem_set(mode_t, mode_x, vt, vX) == 26
+    z0 = np.concatenate([vX[:M].ravel(), vt[1:]])
+    kw = dict(xtol=1e-8, analytic_jac=bool(order))
+    r1 = ctx.chains_solve(z0[None, :], kind=0, **kw)
+    assert r1["info"][0] == prog[0]["info"] and r1["nfev"][0] == prog[0]["nfev"]          # the same failure, after the same work
+    # the program's unknowns are still the initial guess (GetParameters after a failed SolveOCP)
+    assert np.array_equal(np.array(prog[0]["z"]), z0)
+    Xg = vX.copy()
+    Xg[1, 1], Xg[2, 1], Xg[2, 2] = 15.0, 5.0, 10.0
+    r2 = ctx.chains_solve(z0[None, :], kind=2, step=1.0, time_prev=vt[None, :], x_prev=vX.ravel()[None, :], time_goal=vt[None, :],
+                          x_goal=Xg.ravel()[None, :], **kw)
+    assert r2["info"][0] == 1 and np.array_equal(r2["z"][0], np.array(prog[1]["z"])) and r2["nfev"][0] == prog[1]["nfev"]
+    ctx.problem_set(mode_t, mode_x, vt, Xg)
+    r3 = ctx.chains_solve(r2["z"], kind=1, param_index=2, step=1.0, goal=np.array([0.02]), params=ctx.get_params()[None, :], **kw)
+    assert r3["info"][0] == 1 and np.array_equal(r3["z"][0], np.array(prog[2]["z"])) and r3["nfev"][0] == prog[2]["nfev"]
+    if order:
+        assert r2["njev"][0] == prog[1]["njev"] and r3["njev"][0] == prog[2]["njev"]
+    ctx.close()
