@@ -202,46 +202,79 @@ extern "C" int socp_chains_solve_ex(socp_ctx *ctx, int P, const socp_chain_optio
     for (int p = 0; p < P; p++) if (!ch[p].solver) alloc_ok = false;
     if (!alloc_ok) { cleanup(); return SOCP_ERR_ARG; }
 
-    // ---- buffers ----------------------------------------------------------------------------------------------------
+    // ---- groups and buffers -------------------------------------------------------------------------------------------
+    // The chains can be split into G groups that take turns: while the launches of one group are in flight the host advances
+    // the state machines of the other and stages its requests.  Every group has its own staging buffers and streams; a chain
+    // only ever meets its own group, so no iterate depends on G (tests/test_gpu_chains.py).  What it buys is half of the host
+    // work of a round (a group's own advance still precedes its launch), which only shows where the host work is a sizeable
+    // part of a round: measured 6 % on the 4096-start n = 85 sweep, nothing at n = 14 (4096 and 65 536 starts: the rounds are
+    // kernel time).  Hence G = 2 from 2048 chains of n >= 32 up, else 1; SOCP_CHAINS_GROUPS overrides.
     const size_t rowB = sizeof(double) * n, jacB = rowB * n, rowsLen = (size_t)(n + 1) * n, rowsB = sizeof(double) * rowsLen;
-    const int jchunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)P, ((size_t)64 << 20) / jacB));
     int speculate = opt->speculate;
     if (const char *e = std::getenv("SOCP_CHAINS_SPECULATE")) speculate = std::atoi(e);
     if ((double)P * rowsB * 2 > 16e9) speculate = 0;              // slots + staging would not be "free"
     if (opt->analytic_jac) speculate = 0;                          // no finite differences on the hybrj path
     const bool spec_on = speculate != 0;
-    Pinned hX, hF, hJx, hJf, hJ, hPF, hTF, hXF, hPJ, hTJ, hXJ, hIdx;
-    Dev dX, dF, dJx, dJf, dJ, dPF, dTF, dXF, dPJ, dTJ, dXJ, dStage, dSlots, dIdx;
-    bool ok = hX.reserve(rowB * P) && hF.reserve(rowB * P) && hJx.reserve(rowB * P) && hJf.reserve(rowB * P) && hJ.reserve(jacB * jchunk) &&
-              dX.alloc(rowB * P) && dF.alloc(rowB * P) && dJx.alloc(rowB * P) && dJf.alloc(rowB * P) && dJ.alloc(jacB * jchunk) &&
-              hIdx.reserve(sizeof(int) * 2 * (size_t)P) && dIdx.alloc(sizeof(int) * 2 * (size_t)P);
-    if (ok && pp_params) ok = hPF.reserve(sizeof(double) * stride * P) && hPJ.reserve(sizeof(double) * stride * P) &&
-                              dPF.alloc(sizeof(double) * stride * P) && dPJ.alloc(sizeof(double) * stride * P);
-    if (ok && pp_bound) ok = hTF.reserve(sizeof(double) * nodes * P) && hTJ.reserve(sizeof(double) * nodes * P) &&
-                             hXF.reserve(sizeof(double) * nodes * S * P) && hXJ.reserve(sizeof(double) * nodes * S * P) &&
-                             dTF.alloc(sizeof(double) * nodes * P) && dTJ.alloc(sizeof(double) * nodes * P) &&
-                             dXF.alloc(sizeof(double) * nodes * S * P) && dXJ.alloc(sizeof(double) * nodes * S * P);
-    if (ok && spec_on) ok = dStage.alloc(rowsB * P) && dSlots.alloc(rowsB * P);
-    if (!ok) { cleanup(); return SOCP_ERR_HIP; }
+    int G = (P >= 2048 && n >= 32 && !opt->analytic_jac) ? 2 : 1;  // the batched variational Jacobian keeps one scratch area per context
+    if (const char *e = std::getenv("SOCP_CHAINS_GROUPS")) G = std::max(1, std::min(4, std::atoi(e)));
+    if (opt->analytic_jac || G > P) G = 1;
 
     static const bool trace = std::getenv("SOCP_MULTISTART_TRACE") != nullptr;
     static const bool overlap = [] { const char *e = std::getenv("SOCP_MULTISTART_OVERLAP"); return !(e && e[0] == '0'); }();
     void *main_stream_v = nullptr;
-    hipStream_t aux = nullptr;
-    if (socp_ctx_synchronize(ctx) != SOCP_OK || socp_ctx_get_stream(ctx, &main_stream_v) != SOCP_OK ||
-        hipStreamCreateWithFlags(&aux, hipStreamNonBlocking) != hipSuccess) {
-        cleanup();
-        return SOCP_ERR_HIP;
-    }
+    if (socp_ctx_synchronize(ctx) != SOCP_OK || socp_ctx_get_stream(ctx, &main_stream_v) != SOCP_OK) { cleanup(); return SOCP_ERR_HIP; }
     hipStream_t main_stream = static_cast<hipStream_t>(main_stream_v);
-    hipStream_t fstream = overlap ? aux : main_stream;      // residual-type work (and everything speculative) goes here
+
+    struct Group {
+        int lo = 0, hi = 0;                      // chains [lo, hi)
+        int jchunk = 1;
+        Pinned hX, hF, hJx, hJf, hJ, hPF, hTF, hXF, hPJ, hTJ, hXJ, hIdx;
+        Dev dX, dF, dJx, dJf, dJ, dPF, dTF, dXF, dPJ, dTJ, dXJ, dStage, dIdx;
+        hipStream_t fs = nullptr, js = nullptr;  // residual-type work (and everything speculative) / launched Jacobians
+        bool own_fs = false, own_js = false;
+        std::vector<int> reqF, reqJ, reqJc, accepted;
+        int kS = 0, j_next = 0;                  // speculative prefix of reqF; next Jacobian chunk to launch
+        bool pending = false;                    // launches in flight, results not yet handed to the solvers
+        long long rounds = 0;
+    };
+    std::vector<Group> grp(G);
+    Dev dSlots;
+    bool ok = !spec_on || dSlots.alloc(rowsB * P);
+    for (int g = 0; g < G && ok; g++) {
+        Group &q = grp[g];
+        q.lo = (int)((long)P * g / G); q.hi = (int)((long)P * (g + 1) / G);
+        const size_t C = (size_t)(q.hi - q.lo);
+        q.jchunk = (int)std::max<size_t>(1, std::min<size_t>(C, ((size_t)64 << 20) / jacB / G));
+        ok = q.hX.reserve(rowB * C) && q.hF.reserve(rowB * C) && q.hJx.reserve(rowB * C) && q.hJf.reserve(rowB * C) && q.hJ.reserve(jacB * q.jchunk) &&
+             q.dX.alloc(rowB * C) && q.dF.alloc(rowB * C) && q.dJx.alloc(rowB * C) && q.dJf.alloc(rowB * C) && q.dJ.alloc(jacB * q.jchunk) &&
+             q.hIdx.reserve(sizeof(int) * 2 * C) && q.dIdx.alloc(sizeof(int) * 2 * C);
+        if (ok && pp_params) ok = q.hPF.reserve(sizeof(double) * stride * C) && q.hPJ.reserve(sizeof(double) * stride * C) &&
+                                  q.dPF.alloc(sizeof(double) * stride * C) && q.dPJ.alloc(sizeof(double) * stride * C);
+        if (ok && pp_bound) ok = q.hTF.reserve(sizeof(double) * nodes * C) && q.hTJ.reserve(sizeof(double) * nodes * C) &&
+                                 q.hXF.reserve(sizeof(double) * nodes * S * C) && q.hXJ.reserve(sizeof(double) * nodes * S * C) &&
+                                 q.dTF.alloc(sizeof(double) * nodes * C) && q.dTJ.alloc(sizeof(double) * nodes * C) &&
+                                 q.dXF.alloc(sizeof(double) * nodes * S * C) && q.dXJ.alloc(sizeof(double) * nodes * S * C);
+        if (ok && spec_on) ok = q.dStage.alloc(rowsB * C);
+        // group 0 launches its Jacobians on the context's stream (as the engine always did); residual-type work on a second one
+        if (ok && g == 0) q.js = main_stream;
+        else if (ok) { ok = hipStreamCreateWithFlags(&q.js, hipStreamNonBlocking) == hipSuccess; q.own_js = ok; }
+        if (ok && overlap) { ok = hipStreamCreateWithFlags(&q.fs, hipStreamNonBlocking) == hipSuccess; q.own_fs = ok; }
+        else if (ok) q.fs = q.js;
+    }
+    auto release_streams = [&]() {
+        for (Group &q : grp) {
+            if (q.own_fs && q.fs) { (void)hipStreamSynchronize(q.fs); (void)hipStreamDestroy(q.fs); }
+            if (q.own_js && q.js) { (void)hipStreamSynchronize(q.js); (void)hipStreamDestroy(q.js); }
+            q.fs = q.js = nullptr;
+        }
+    };
+    if (!ok) { release_streams(); cleanup(); return SOCP_ERR_HIP; }
 
     bool round_limit_hit = false;
-    long long rounds = 0, spec_rows_rounds = 0, jac_from_cache = 0, jac_launched = 0, restarts = 0;
-    double t_adv = 0, t_gpu = 0, t_copy = 0;
+    long long spec_rows_rounds = 0, jac_from_cache = 0, jac_launched = 0, restarts = 0;
+    double t_adv = 0, t_wait = 0, t_copy = 0;
     const double t_setup = ms_since(t_begin);
     int rc = SOCP_OK;
-    std::vector<int> reqF, reqJ, reqJc, accepted;
 
     // chain logic at the end of one Newton solve: the bisection rules of shooting.cpp:627-660 / 724-760
     auto solve_finished = [&](int p) {
@@ -281,13 +314,16 @@ extern "C" int socp_chains_solve_ex(socp_ctx *ctx, int P, const socp_chain_optio
         c.need_advance = true;
     };
 
-    for (;;) {
+    // ---- phase 1 of a group's turn: advance its chains, serve cached Jacobians, stage and enqueue its requests ------------
+    auto advance_and_launch = [&](Group &q) -> int {
         const clk::time_point ta = clk::now();
-        // (1) advance every chain that received what it asked for; chains whose solve ended restart (or retire) and advance
-        //     again, so that after this loop every live chain has exactly one pending request.  Jacobian requests whose
-        //     point is cached are served here, without a round of trajectories.
+        const int C = q.hi - q.lo;
+        // advance every chain that received what it asked for; chains whose solve ended restart (or retire) and advance again,
+        // so that afterwards every live chain has exactly one pending request.  Jacobian requests whose point is cached are
+        // served here, without a round of trajectories.
         for (;;) {
-            parallel_for(P, [&](int p) {
+            parallel_for(C, [&](int k) {
+                const int p = q.lo + k;
                 Chain &c = ch[p];
                 while (!c.finished && c.need_advance) {
                     c.req = socp_hybr_advance(c.solver, c.flag, &c.xin, &c.xout);
@@ -297,168 +333,211 @@ extern "C" int socp_chains_solve_ex(socp_ctx *ctx, int P, const socp_chain_optio
                 }
             });
             if (!spec_on) break;
-            // the rows evaluated last round belong to the chain's slot if that point is now the solver's x
-            accepted.clear(); reqJc.clear();
-            for (int p = 0; p < P; p++) {
+            // the rows evaluated in the group's last round belong to a chain's slot if that point is now its solver's x
+            q.accepted.clear(); q.reqJc.clear();
+            for (int p = q.lo; p < q.hi; p++) {
                 Chain &c = ch[p];
                 if (c.finished || c.stage_idx < 0) continue;
-                if (std::memcmp(socp_hybr_x(c.solver), c.eval_x.data(), rowB) == 0) accepted.push_back(p);
+                if (std::memcmp(socp_hybr_x(c.solver), c.eval_x.data(), rowB) == 0) q.accepted.push_back(p);
             }
-            if (!accepted.empty()) {
-                int *idx = hIdx.i();
-                for (size_t k = 0; k < accepted.size(); k++) { idx[k] = ch[accepted[k]].stage_idx; idx[P + k] = accepted[k]; }
-                if (hipMemcpyAsync(dIdx.p, idx, sizeof(int) * 2 * (size_t)P, hipMemcpyHostToDevice, fstream) != hipSuccess ||
-                    !copy_blocks(fstream, dStage.d(), dIdx.i(), dSlots.d(), dIdx.i() + P, (int)accepted.size(), (int)rowsLen) ||
-                    hipStreamSynchronize(fstream) != hipSuccess) { rc = SOCP_ERR_HIP; break; }
-                for (int p : accepted) { ch[p].slot_x = ch[p].eval_x; ch[p].slot_valid = true; }
+            if (!q.accepted.empty()) {
+                int *idx = q.hIdx.i();
+                for (size_t k = 0; k < q.accepted.size(); k++) { idx[k] = ch[q.accepted[k]].stage_idx; idx[C + k] = q.accepted[k]; }
+                if (hipMemcpyAsync(q.dIdx.p, idx, sizeof(int) * 2 * (size_t)C, hipMemcpyHostToDevice, q.fs) != hipSuccess ||
+                    !copy_blocks(q.fs, q.dStage.d(), q.dIdx.i(), dSlots.d(), q.dIdx.i() + C, (int)q.accepted.size(), (int)rowsLen) ||
+                    hipStreamSynchronize(q.fs) != hipSuccess) return SOCP_ERR_HIP;
+                for (int p : q.accepted) { ch[p].slot_x = ch[p].eval_x; ch[p].slot_valid = true; }
             }
-            for (int p = 0; p < P; p++) ch[p].stage_idx = -1;      // the staging area is about to be reused
-            for (int p = 0; p < P; p++) {
+            for (int p = q.lo; p < q.hi; p++) ch[p].stage_idx = -1;      // the staging area is about to be reused
+            for (int p = q.lo; p < q.hi; p++) {
                 Chain &c = ch[p];
-                if (!c.finished && c.req == SOCP_REQ_JAC && c.slot_valid && std::memcmp(c.xin, c.slot_x.data(), rowB) == 0) reqJc.push_back(p);
+                if (!c.finished && c.req == SOCP_REQ_JAC && c.slot_valid && std::memcmp(c.xin, c.slot_x.data(), rowB) == 0) q.reqJc.push_back(p);
             }
-            if (reqJc.empty()) break;
+            if (q.reqJc.empty()) break;
             // Jacobians from cached rows: slot -> staging (gather), fd_diff, read back, scatter; then those chains advance again
-            for (size_t j0 = 0; j0 < reqJc.size() && rc == SOCP_OK; j0 += jchunk) {
-                const int kc = (int)std::min<size_t>(jchunk, reqJc.size() - j0);
-                int *idx = hIdx.i();
+            for (size_t j0 = 0; j0 < q.reqJc.size(); j0 += q.jchunk) {
+                const int kc = (int)std::min<size_t>(q.jchunk, q.reqJc.size() - j0);
+                int *idx = q.hIdx.i();
                 for (int k = 0; k < kc; k++) {
-                    idx[k] = reqJc[j0 + k]; idx[P + k] = k;
-                    std::memcpy(hJx.d() + (size_t)k * n, ch[reqJc[j0 + k]].xin, rowB);
+                    idx[k] = q.reqJc[j0 + k]; idx[C + k] = k;
+                    std::memcpy(q.hJx.d() + (size_t)k * n, ch[q.reqJc[j0 + k]].xin, rowB);
                 }
-                if (hipMemcpyAsync(dIdx.p, idx, sizeof(int) * 2 * (size_t)P, hipMemcpyHostToDevice, fstream) != hipSuccess ||
-                    hipMemcpyAsync(dJx.p, hJx.p, rowB * kc, hipMemcpyHostToDevice, fstream) != hipSuccess ||
-                    !copy_blocks(fstream, dSlots.d(), dIdx.i(), dStage.d(), dIdx.i() + P, kc, (int)rowsLen)) { rc = SOCP_ERR_HIP; break; }
-                socp_ctx_set_stream(ctx, fstream, 0);
-                rc = socp_fd_diff_dev(ctx, kc, dJx.d(), opt->epsfcn, dStage.d(), dJ.d());
+                if (hipMemcpyAsync(q.dIdx.p, idx, sizeof(int) * 2 * (size_t)C, hipMemcpyHostToDevice, q.fs) != hipSuccess ||
+                    hipMemcpyAsync(q.dJx.p, q.hJx.p, rowB * kc, hipMemcpyHostToDevice, q.fs) != hipSuccess ||
+                    !copy_blocks(q.fs, dSlots.d(), q.dIdx.i(), q.dStage.d(), q.dIdx.i() + C, kc, (int)rowsLen)) return SOCP_ERR_HIP;
+                socp_ctx_set_stream(ctx, q.fs, 0);
+                const int r = socp_fd_diff_dev(ctx, kc, q.dJx.d(), opt->epsfcn, q.dStage.d(), q.dJ.d());
                 socp_ctx_set_stream(ctx, main_stream, 0);
-                if (rc != SOCP_OK) break;
-                if (hipMemcpyAsync(hJ.p, dJ.p, jacB * kc, hipMemcpyDeviceToHost, fstream) != hipSuccess ||
-                    hipStreamSynchronize(fstream) != hipSuccess) { rc = SOCP_ERR_HIP; break; }
-                parallel_for(kc, [&](int k) { std::memcpy(ch[reqJc[j0 + k]].xout, hJ.d() + (size_t)k * n * n, jacB); });
-                for (int k = 0; k < kc; k++) ch[reqJc[j0 + k]].need_advance = true;
+                if (r != SOCP_OK) return r;
+                if (hipMemcpyAsync(q.hJ.p, q.dJ.p, jacB * kc, hipMemcpyDeviceToHost, q.fs) != hipSuccess ||
+                    hipStreamSynchronize(q.fs) != hipSuccess) return SOCP_ERR_HIP;
+                parallel_for(kc, [&](int k) { std::memcpy(ch[q.reqJc[j0 + k]].xout, q.hJ.d() + (size_t)k * n * n, jacB); });
+                for (int k = 0; k < kc; k++) ch[q.reqJc[j0 + k]].need_advance = true;
                 jac_from_cache += kc;
             }
-            if (rc != SOCP_OK) break;
         }
-        if (rc != SOCP_OK) break;
-        // (2) gather the requests in chain order (keeps the batches deterministic)
-        reqF.clear(); reqJ.clear();
-        for (int p = 0; p < P; p++) {
+        // gather the requests in chain order (keeps the batches deterministic)
+        q.reqF.clear(); q.reqJ.clear();
+        for (int p = q.lo; p < q.hi; p++) {
             Chain &c = ch[p];
             if (c.finished) continue;
-            if (c.req == SOCP_REQ_FVEC) reqF.push_back(p);
-            else if (c.req == SOCP_REQ_JAC) reqJ.push_back(p);
+            if (c.req == SOCP_REQ_FVEC) q.reqF.push_back(p);
+            else if (c.req == SOCP_REQ_JAC) q.reqJ.push_back(p);
         }
-        t_adv += ms_since(ta);
-        if (reqF.empty() && reqJ.empty()) break;
-        if (opt->max_rounds > 0 && rounds >= opt->max_rounds) {
+        q.pending = false;
+        if (q.reqF.empty() && q.reqJ.empty()) { t_adv += ms_since(ta); return SOCP_OK; }
+        if (opt->max_rounds > 0 && q.rounds >= opt->max_rounds) {
             // round budget spent: the chains still solving stop the way a negative callback return stops hybrd
-            for (int p : reqF) { ch[p].flag = SOCP_INFO_ROUND_LIMIT; ch[p].need_advance = true; }
-            for (int p : reqJ) { ch[p].flag = SOCP_INFO_ROUND_LIMIT; ch[p].need_advance = true; }
+            for (int p : q.reqF) { ch[p].flag = SOCP_INFO_ROUND_LIMIT; ch[p].need_advance = true; }
+            for (int p : q.reqJ) { ch[p].flag = SOCP_INFO_ROUND_LIMIT; ch[p].need_advance = true; }
             round_limit_hit = true;
-            continue;
+            parallel_for(C, [&](int k) {
+                Chain &c = ch[q.lo + k];
+                if (!c.finished && c.need_advance) { c.req = socp_hybr_advance(c.solver, c.flag, &c.xin, &c.xout); c.need_advance = false; if (c.req == SOCP_REQ_DONE) solve_finished(q.lo + k); }
+            });
+            q.reqF.clear(); q.reqJ.clear();
+            t_adv += ms_since(ta);
+            return SOCP_OK;
         }
-        rounds++;
-        const int kF = (int)reqF.size(), kJ = (int)reqJ.size();
-        // how many of the residual requests are evaluated as whole FD batches: as many as fit the idle SIMDs
-        // (one wave per SIMD keeps the round at one trajectory latency); speculate = 1 forces all of them
+        q.rounds++;
+        const int kF = (int)q.reqF.size(), kJ = (int)q.reqJ.size();
+        // how many of the residual requests are evaluated as whole FD batches: all of them when they fit the group's share of
+        // the idle SIMDs (one wave per SIMD keeps the round at one trajectory latency), else none -- a round that is part FD
+        // batches, part plain residuals would be two launches on one stream, i.e. two latencies.  speculate = 1 forces all.
         int kS = 0;
         if (spec_on && kF) {
             if (speculate > 0) kS = kF;
             else {
-                // all or nothing: a round that is part FD batches, part plain residuals is two launches on one stream, i.e. two
-                // trajectory latencies.  All of them fit when kF (n+1) segs lanes + the Jacobian launch <= 1024 waves x 64.
-                const long lanes = (1024 - ((long)kJ * n * segs + 63) / 64) * 64;
+                const long lanes = (1024 / G - ((long)kJ * n * segs + 63) / 64) * 64;
                 kS = ((long)kF * (n + 1) * segs <= lanes) ? kF : 0;
             }
         }
-        if (trace) std::fprintf(stderr, "[socp_chains] round %lld: %d residual requests (%d as FD batches), %d Jacobian requests\n", rounds, kF, kS, kJ);
-        // stage the requests' inputs and per-problem blocks: the first kS residual requests are the speculative ones
+        q.kS = kS;
+        if (trace) std::fprintf(stderr, "[socp_chains] group %d round %lld: %d residual requests (%d as FD batches), %d Jacobian requests\n",
+                                (int)(&q - grp.data()), q.rounds, kF, kS, kJ);
         for (int k = 0; k < kF; k++) {
-            const int p = reqF[k];
-            std::memcpy(hX.d() + (size_t)k * n, ch[p].xin, rowB);
-            if (pp_params) std::memcpy(hPF.d() + (size_t)k * stride, &pblock[(size_t)p * stride], sizeof(double) * stride);
+            const int p = q.reqF[k];
+            std::memcpy(q.hX.d() + (size_t)k * n, ch[p].xin, rowB);
+            if (pp_params) std::memcpy(q.hPF.d() + (size_t)k * stride, &pblock[(size_t)p * stride], sizeof(double) * stride);
             if (pp_bound) {
-                std::memcpy(hTF.d() + (size_t)k * nodes, &tblock[(size_t)p * nodes], sizeof(double) * nodes);
-                std::memcpy(hXF.d() + (size_t)k * nodes * S, &xblock[(size_t)p * nodes * S], sizeof(double) * nodes * S);
+                std::memcpy(q.hTF.d() + (size_t)k * nodes, &tblock[(size_t)p * nodes], sizeof(double) * nodes);
+                std::memcpy(q.hXF.d() + (size_t)k * nodes * S, &xblock[(size_t)p * nodes * S], sizeof(double) * nodes * S);
             }
             if (k < kS) { std::memcpy(ch[p].eval_x.data(), ch[p].xin, rowB); ch[p].stage_idx = k; }
         }
         for (int k = 0; k < kJ; k++) {
-            const int p = reqJ[k];
-            std::memcpy(hJx.d() + (size_t)k * n, ch[p].xin, rowB);
-            std::memcpy(hJf.d() + (size_t)k * n, socp_hybr_fvec(ch[p].solver), rowB);
-            if (pp_params) std::memcpy(hPJ.d() + (size_t)k * stride, &pblock[(size_t)p * stride], sizeof(double) * stride);
+            const int p = q.reqJ[k];
+            std::memcpy(q.hJx.d() + (size_t)k * n, ch[p].xin, rowB);
+            std::memcpy(q.hJf.d() + (size_t)k * n, socp_hybr_fvec(ch[p].solver), rowB);
+            if (pp_params) std::memcpy(q.hPJ.d() + (size_t)k * stride, &pblock[(size_t)p * stride], sizeof(double) * stride);
             if (pp_bound) {
-                std::memcpy(hTJ.d() + (size_t)k * nodes, &tblock[(size_t)p * nodes], sizeof(double) * nodes);
-                std::memcpy(hXJ.d() + (size_t)k * nodes * S, &xblock[(size_t)p * nodes * S], sizeof(double) * nodes * S);
+                std::memcpy(q.hTJ.d() + (size_t)k * nodes, &tblock[(size_t)p * nodes], sizeof(double) * nodes);
+                std::memcpy(q.hXJ.d() + (size_t)k * nodes * S, &xblock[(size_t)p * nodes * S], sizeof(double) * nodes * S);
             }
         }
-        // residual-type launches (stream F): the speculative prefix through the fdrows kernel, the rest through the residual kernel
+        t_adv += ms_since(ta);
+        int r = SOCP_OK;
+        // residual-type launches (stream fs): all requests through the FD-row kernel, or all through the residual kernel
         if (kF) {
-            bool h2d = hipMemcpyAsync(dX.p, hX.p, rowB * kF, hipMemcpyHostToDevice, fstream) == hipSuccess;
-            if (h2d && pp_params) h2d = hipMemcpyAsync(dPF.p, hPF.p, sizeof(double) * stride * kF, hipMemcpyHostToDevice, fstream) == hipSuccess;
-            if (h2d && pp_bound) h2d = hipMemcpyAsync(dTF.p, hTF.p, sizeof(double) * nodes * kF, hipMemcpyHostToDevice, fstream) == hipSuccess &&
-                                       hipMemcpyAsync(dXF.p, hXF.p, sizeof(double) * nodes * S * kF, hipMemcpyHostToDevice, fstream) == hipSuccess;
-            if (!h2d) { rc = SOCP_ERR_HIP; break; }
-            socp_ctx_set_stream(ctx, fstream, 0);
+            bool h2d = hipMemcpyAsync(q.dX.p, q.hX.p, rowB * kF, hipMemcpyHostToDevice, q.fs) == hipSuccess;
+            if (h2d && pp_params) h2d = hipMemcpyAsync(q.dPF.p, q.hPF.p, sizeof(double) * stride * kF, hipMemcpyHostToDevice, q.fs) == hipSuccess;
+            if (h2d && pp_bound) h2d = hipMemcpyAsync(q.dTF.p, q.hTF.p, sizeof(double) * nodes * kF, hipMemcpyHostToDevice, q.fs) == hipSuccess &&
+                                       hipMemcpyAsync(q.dXF.p, q.hXF.p, sizeof(double) * nodes * S * kF, hipMemcpyHostToDevice, q.fs) == hipSuccess;
+            if (!h2d) return SOCP_ERR_HIP;
+            socp_ctx_set_stream(ctx, q.fs, 0);
             if (kS) {
-                socp_problem_set_blocks_dev(ctx, pp_params ? dPF.d() : nullptr, stride, pp_bound ? dTF.d() : nullptr, pp_bound ? dXF.d() : nullptr);
-                rc = socp_fd_rows_dev(ctx, kS, dX.d(), opt->epsfcn, dStage.d());
+                socp_problem_set_blocks_dev(ctx, pp_params ? q.dPF.d() : nullptr, stride, pp_bound ? q.dTF.d() : nullptr, pp_bound ? q.dXF.d() : nullptr);
+                r = socp_fd_rows_dev(ctx, kS, q.dX.d(), opt->epsfcn, q.dStage.d());
                 spec_rows_rounds++;
             }
-            if (rc == SOCP_OK && kF > kS) {
-                socp_problem_set_blocks_dev(ctx, pp_params ? dPF.d() + (size_t)kS * stride : nullptr, stride,
-                                            pp_bound ? dTF.d() + (size_t)kS * nodes : nullptr, pp_bound ? dXF.d() + (size_t)kS * nodes * S : nullptr);
-                rc = socp_residual_batch_dev(ctx, kF - kS, dX.d() + (size_t)kS * n, dF.d() + (size_t)kS * n);
+            if (r == SOCP_OK && kF > kS) {
+                socp_problem_set_blocks_dev(ctx, pp_params ? q.dPF.d() + (size_t)kS * stride : nullptr, stride,
+                                            pp_bound ? q.dTF.d() + (size_t)kS * nodes : nullptr, pp_bound ? q.dXF.d() + (size_t)kS * nodes * S : nullptr);
+                r = socp_residual_batch_dev(ctx, kF - kS, q.dX.d() + (size_t)kS * n, q.dF.d() + (size_t)kS * n);
             }
+            // F of the speculative requests is row 0 of their (n+1) x n block
+            bool d2h = r == SOCP_OK;
+            if (d2h && kS) d2h = hipMemcpy2DAsync(q.hF.p, rowB, q.dStage.p, rowsB, rowB, (size_t)kS, hipMemcpyDeviceToHost, q.fs) == hipSuccess;
+            if (d2h && kF > kS) d2h = hipMemcpyAsync(q.hF.d() + (size_t)kS * n, q.dF.d() + (size_t)kS * n, rowB * (kF - kS), hipMemcpyDeviceToHost, q.fs) == hipSuccess;
             socp_ctx_set_stream(ctx, main_stream, 0);
-            if (rc != SOCP_OK) break;
+            if (r != SOCP_OK) return r;
+            if (!d2h) return SOCP_ERR_HIP;
         }
+        q.j_next = 0;
         if (kJ) {
-            bool h2d = hipMemcpyAsync(dJx.p, hJx.p, rowB * kJ, hipMemcpyHostToDevice, main_stream) == hipSuccess &&
-                       hipMemcpyAsync(dJf.p, hJf.p, rowB * kJ, hipMemcpyHostToDevice, main_stream) == hipSuccess;
-            if (h2d && pp_params) h2d = hipMemcpyAsync(dPJ.p, hPJ.p, sizeof(double) * stride * kJ, hipMemcpyHostToDevice, main_stream) == hipSuccess;
-            if (h2d && pp_bound) h2d = hipMemcpyAsync(dTJ.p, hTJ.p, sizeof(double) * nodes * kJ, hipMemcpyHostToDevice, main_stream) == hipSuccess &&
-                                       hipMemcpyAsync(dXJ.p, hXJ.p, sizeof(double) * nodes * S * kJ, hipMemcpyHostToDevice, main_stream) == hipSuccess;
-            if (!h2d) { rc = SOCP_ERR_HIP; break; }
+            bool h2d = hipMemcpyAsync(q.dJx.p, q.hJx.p, rowB * kJ, hipMemcpyHostToDevice, q.js) == hipSuccess &&
+                       hipMemcpyAsync(q.dJf.p, q.hJf.p, rowB * kJ, hipMemcpyHostToDevice, q.js) == hipSuccess;
+            if (h2d && pp_params) h2d = hipMemcpyAsync(q.dPJ.p, q.hPJ.p, sizeof(double) * stride * kJ, hipMemcpyHostToDevice, q.js) == hipSuccess;
+            if (h2d && pp_bound) h2d = hipMemcpyAsync(q.dTJ.p, q.hTJ.p, sizeof(double) * nodes * kJ, hipMemcpyHostToDevice, q.js) == hipSuccess &&
+                                       hipMemcpyAsync(q.dXJ.p, q.hXJ.p, sizeof(double) * nodes * S * kJ, hipMemcpyHostToDevice, q.js) == hipSuccess;
+            if (!h2d) return SOCP_ERR_HIP;
             jac_launched += kJ;
         }
-        bool f_collected = (kF == 0);
-        for (int j0 = 0; j0 < kJ || !f_collected; j0 += jchunk) {
-            const int kc = j0 < kJ ? std::min(jchunk, kJ - j0) : 0;
-            const clk::time_point t_chunk = clk::now();
-            if (kc) {
-                socp_problem_set_blocks_dev(ctx, pp_params ? dPJ.d() + (size_t)j0 * stride : nullptr, stride,
-                                            pp_bound ? dTJ.d() + (size_t)j0 * nodes : nullptr, pp_bound ? dXJ.d() + (size_t)j0 * nodes * S : nullptr);
-                rc = opt->analytic_jac
-                         ? socp_var_jacobian_multi_dev(ctx, kc, dJx.d() + (size_t)j0 * n, dJ.d())
-                         : socp_fd_jacobian_multi_dev(ctx, kc, dJx.d() + (size_t)j0 * n, dJf.d() + (size_t)j0 * n, opt->epsfcn, dJ.d(), opt->dedup);
-                if (rc != SOCP_OK) break;
-            }
-            if (!f_collected) {
-                // F of the speculative requests is row 0 of their (n+1) x n block
-                bool d2h = true;
-                if (kS) d2h = hipMemcpy2DAsync(hF.p, rowB, dStage.p, rowsB, rowB, (size_t)kS, hipMemcpyDeviceToHost, fstream) == hipSuccess;
-                if (d2h && kF > kS) d2h = hipMemcpyAsync(hF.d() + (size_t)kS * n, dF.d() + (size_t)kS * n, rowB * (kF - kS), hipMemcpyDeviceToHost, fstream) == hipSuccess;
-                if (!d2h || hipStreamSynchronize(fstream) != hipSuccess) { rc = SOCP_ERR_HIP; break; }
-                for (int k = 0; k < kF; k++) std::memcpy(ch[reqF[k]].xout, hF.d() + (size_t)k * n, rowB);
-                f_collected = true;
-            }
-            if (kc) {
-                if (hipStreamSynchronize(main_stream) != hipSuccess) { rc = SOCP_ERR_HIP; break; }
-                t_gpu += ms_since(t_chunk);
-                const clk::time_point tc = clk::now();
-                if (hipMemcpy(hJ.p, dJ.p, jacB * kc, hipMemcpyDeviceToHost) != hipSuccess) { rc = SOCP_ERR_HIP; break; }
-                parallel_for(kc, [&](int k) { std::memcpy(ch[reqJ[j0 + k]].xout, hJ.d() + (size_t)k * n * n, jacB); });
-                t_copy += ms_since(tc);
-            }
+        q.pending = true;
+        return SOCP_OK;
+    };
+
+    // one chunk of a group's launched Jacobians: enqueue on its Jacobian stream (the copy back included)
+    auto launch_jac_chunk = [&](Group &q) -> int {
+        const int kJ = (int)q.reqJ.size(), j0 = q.j_next;
+        if (j0 >= kJ) return SOCP_OK;
+        const int kc = std::min(q.jchunk, kJ - j0);
+        socp_ctx_set_stream(ctx, q.js, 0);
+        socp_problem_set_blocks_dev(ctx, pp_params ? q.dPJ.d() + (size_t)j0 * stride : nullptr, stride,
+                                    pp_bound ? q.dTJ.d() + (size_t)j0 * nodes : nullptr, pp_bound ? q.dXJ.d() + (size_t)j0 * nodes * S : nullptr);
+        const int r = opt->analytic_jac
+                          ? socp_var_jacobian_multi_dev(ctx, kc, q.dJx.d() + (size_t)j0 * n, q.dJ.d())
+                          : socp_fd_jacobian_multi_dev(ctx, kc, q.dJx.d() + (size_t)j0 * n, q.dJf.d() + (size_t)j0 * n, opt->epsfcn, q.dJ.d(), opt->dedup);
+        socp_ctx_set_stream(ctx, main_stream, 0);
+        if (r != SOCP_OK) return r;
+        return hipMemcpyAsync(q.hJ.p, q.dJ.p, jacB * kc, hipMemcpyDeviceToHost, q.js) == hipSuccess ? SOCP_OK : SOCP_ERR_HIP;
+    };
+
+    // ---- phase 2 of a group's turn: wait for its launches and hand the results to the solvers -------------------------------
+    auto collect = [&](Group &q) -> int {
+        if (!q.pending) return SOCP_OK;
+        const clk::time_point tw = clk::now();
+        const int kF = (int)q.reqF.size(), kJ = (int)q.reqJ.size();
+        if (kF) {
+            if (hipStreamSynchronize(q.fs) != hipSuccess) return SOCP_ERR_HIP;
+            for (int k = 0; k < kF; k++) std::memcpy(ch[q.reqF[k]].xout, q.hF.d() + (size_t)k * n, rowB);
         }
-        if (rc != SOCP_OK) break;
-        for (int p : reqF) ch[p].need_advance = true;
-        for (int p : reqJ) ch[p].need_advance = true;
+        while (q.j_next < kJ) {
+            const int j0 = q.j_next, kc = std::min(q.jchunk, kJ - j0);
+            if (hipStreamSynchronize(q.js) != hipSuccess) return SOCP_ERR_HIP;
+            t_wait += ms_since(tw);
+            const clk::time_point tc = clk::now();
+            // hundreds of MB per round at n ~ 100: spread the copies into the solvers' own buffers over the host threads
+            parallel_for(kc, [&](int k) { std::memcpy(ch[q.reqJ[j0 + k]].xout, q.hJ.d() + (size_t)k * n * n, jacB); });
+            t_copy += ms_since(tc);
+            q.j_next += kc;
+            if (q.j_next < kJ) { const int r = launch_jac_chunk(q); if (r != SOCP_OK) return r; }
+        }
+        if (!kJ) t_wait += ms_since(tw);
+        for (int p : q.reqF) ch[p].need_advance = true;
+        for (int p : q.reqJ) ch[p].need_advance = true;
+        q.pending = false;
+        return SOCP_OK;
+    };
+
+    // ---- the turns: a group's results are collected only after the other groups have been advanced and launched --------------
+    for (Group &q : grp) {
+        if ((rc = advance_and_launch(q)) != SOCP_OK) break;
+        if (q.pending && (rc = launch_jac_chunk(q)) != SOCP_OK) break;
     }
+    while (rc == SOCP_OK) {
+        bool any = false;
+        for (Group &q : grp) {
+            if (!q.pending) continue;
+            any = true;
+            if ((rc = collect(q)) != SOCP_OK) break;
+            if ((rc = advance_and_launch(q)) != SOCP_OK) break;
+            if (q.pending && (rc = launch_jac_chunk(q)) != SOCP_OK) break;
+        }
+        if (!any) break;
+    }
+    long long rounds = 0;
+    for (const Group &q : grp) rounds = std::max(rounds, q.rounds);
     socp_problem_set_blocks_dev(ctx, nullptr, 0, nullptr, nullptr);
     if (rc == SOCP_OK) {
         for (int p = 0; p < P; p++) {
@@ -482,15 +561,14 @@ extern "C" int socp_chains_solve_ex(socp_ctx *ctx, int P, const socp_chain_optio
     for (int p = 0; p < P; p++) restarts += std::max(0, ch[p].solves - 1);
     if (trace && round_limit_hit) std::fprintf(stderr, "[socp_chains] round limit %d reached: the chains still solving were stopped\n", opt->max_rounds);
     if (trace)
-        std::fprintf(stderr, "[socp_chains] set-up %.1f ms, host advance %.1f ms, launches + wait (Jacobian rounds) %.1f ms, Jacobian read-back + scatter %.1f ms, "
-                             "total %.1f ms; %lld rounds, %lld Jacobians launched, %lld from cached rows, %lld solver restarts\n",
-                     t_setup, t_adv, t_gpu, t_copy, ms_since(t_begin), rounds, jac_launched, jac_from_cache, restarts);
+        std::fprintf(stderr, "[socp_chains] set-up %.1f ms, host advance + staging %.1f ms, waiting for launches %.1f ms, Jacobian scatter %.1f ms, "
+                             "total %.1f ms; %d group(s), %lld rounds, %lld Jacobians launched, %lld from cached rows, %lld solver restarts\n",
+                     t_setup, t_adv, t_wait, t_copy, ms_since(t_begin), G, rounds, jac_launched, jac_from_cache, restarts);
     if (stats) {
         stats->rounds = rounds; stats->jacobians_launched = jac_launched; stats->jacobians_from_cache = jac_from_cache;
         stats->speculative_rounds = spec_rows_rounds; stats->restarts = restarts; stats->wall_ms = ms_since(t_begin);
     }
-    (void)hipStreamSynchronize(aux);
-    (void)hipStreamDestroy(aux);
+    release_streams();
     cleanup();
     return rc;
 }

@@ -494,3 +494,38 @@ def test_double_integrator_waypoint_program_continuations_as_chains(order):
     if order:
         assert r2["njev"][0] == prog[1]["njev"] and r3["njev"][0] == prog[2]["njev"]
     ctx.close()
+
+
+def test_groups_take_turns_without_changing_an_iterate(monkeypatch):
+    """The engine splits the chains into groups whose launches and host work overlap (SOCP_CHAINS_GROUPS; 2 from 2048 chains
+    up): a chain only ever meets its own group, so solutions, counts and the continuation bookkeeping do not depend on G."""
+    from socp_amd import sweep
+    ctx = make_ctx("exact", steps=100)
+    goddard_m6(ctx)
+    P = 11
+    rng = np.random.default_rng(9)
+    Z0 = np.tile(STAGE2_INIT, (P, 1))
+    Z0[:, 7:14] *= 1 + 1e-3 * rng.uniform(-1, 1, (P, 7))
+    goals = np.linspace(150.0, 900.0, P)
+    runs = {}
+    for G in ("1", "2", "3"):
+        monkeypatch.setenv("SOCP_CHAINS_GROUPS", G)
+        runs[G] = ctx.chains_solve(Z0, kind=1, param_index=KD, step=0.5, goal=goals, params=np.tile(PARAMS0, (P, 1)), xtol=1e-6)
+    for G in ("2", "3"):
+        for key in ("z", "info", "nfev", "nfev_total", "solves", "b_reached", "param_final", "fnorm"):
+            assert np.array_equal(runs["1"][key], runs[G][key]), (G, key)
+    assert np.all(runs["1"]["info"] == 1) and np.all(runs["1"]["solves"] >= 2)          # step 0.5: two solves, more where a step was bisected
+    # single shooting with speculative Jacobians, groups on: same again
+    ctx.set_params(sweep.GODDARD_PARAMS)
+    sweep.goddard_single_shooting_problem(ctx)
+    Zs = sweep.goddard_starts(50, 1e-3)
+    ref = None
+    for G in ("1", "2"):
+        monkeypatch.setenv("SOCP_CHAINS_GROUPS", G)
+        r = ctx.chains_solve(Zs, kind=0, xtol=1e-8, speculate=1)
+        assert r["stats"]["jacobians_launched"] == 0
+        if ref is None:
+            ref = r
+        else:
+            assert np.array_equal(ref["z"], r["z"]) and np.array_equal(ref["nfev"], r["nfev"]) and np.array_equal(ref["info"], r["info"])
+    ctx.close()
