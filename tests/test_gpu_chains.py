@@ -529,3 +529,22 @@ def test_groups_take_turns_without_changing_an_iterate(monkeypatch):
         else:
             assert np.array_equal(ref["z"], r["z"]) and np.array_equal(ref["nfev"], r["nfev"]) and np.array_equal(ref["info"], r["info"])
     ctx.close()
+
+
+def test_throughput_flavour_chains_within_north_star_tolerance():
+    """north_star: converged results within 1e-8 relative of the reference path.  The KD continuation chains in the throughput
+    flavour (restructured arithmetic, per-problem general-law kernels) against the reference-order flavour, at a solver tolerance
+    where the root is defined that sharply (xtol = 1e-12, as tests/test_host_flow.py does for single solves)."""
+    goals = np.array([310.0, 200.0, 450.0, 800.0])
+    P = len(goals)
+    Z0 = np.tile(STAGE2_INIT, (P, 1))
+    out = {}
+    for variant in ("exact", "fast"):
+        ctx = make_ctx(variant)
+        goddard_m6(ctx)
+        out[variant] = ctx.chains_solve(Z0, kind=1, param_index=KD, step=0.5, goal=goals, params=np.tile(PARAMS0, (P, 1)), xtol=1e-12)
+        ctx.close()
+    assert np.all(out["exact"]["info"] == 1) and np.all(out["fast"]["info"] == 1)
+    rel = np.max(np.abs(out["fast"]["z"] - out["exact"]["z"]), axis=1) / np.max(np.abs(out["exact"]["z"]), axis=1)
+    assert np.all(rel <= 1e-8), rel
+    assert np.array_equal(out["fast"]["solves"], out["exact"]["solves"])
