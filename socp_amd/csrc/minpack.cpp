@@ -211,7 +211,11 @@ namespace colvec {
 typedef double v8 __attribute__((vector_size(64)));
 typedef long long m8 __attribute__((vector_size(64)));
 constexpr int W = 8;                 // columns per vector
-constexpr int G = 4;                 // vectors per block: 32 columns advance together (four independent add chains)
+#ifndef SOCP_COLVEC_G
+#define SOCP_COLVEC_G 2
+#endif
+constexpr int G = SOCP_COLVEC_G;     // vectors per block: 16 columns advance together.  Measured on the EPYC 9575F at n = 832: one thread 43 ms for
+                                     // G = 2, 4 alike (48 for 8); 16 threads 8.7 ms (G = 2), 12-20 (4), 16 (8): smaller blocks balance better
 constexpr int CB = W * G;            // columns per block = reflectors per panel: a panel's columns are exactly one block
 constexpr int kMinN = 24;            // below this the scalar code is as fast
 
