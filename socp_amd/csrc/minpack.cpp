@@ -219,7 +219,9 @@ constexpr int G = SOCP_COLVEC_G;     // vectors per block: 16 columns advance to
 constexpr int CB = W * G;            // columns per block = reflectors per panel: a panel's columns are exactly one block
 constexpr int kMinN = 24;            // below this the scalar code is as fast
 
+#ifndef SOCP_ISA_CLONES          // tests build single-ISA variants (-DSOCP_ISA_CLONES= with or without -mavx2) to compare them all
 #define SOCP_ISA_CLONES __attribute__((target_clones("avx512f", "avx2", "default")))
+#endif
 
 typedef double v8u __attribute__((vector_size(64), aligned(8)));      // the same eight lanes at any address
 // macros, not functions: a helper that returns a 64-byte vector would be compiled for the baseline ISA

@@ -196,7 +196,21 @@ def test_simd_column_factor_work_is_bit_identical_to_the_scalar_column_algorithm
     cxx = "/opt/rocm/lib/llvm/bin/clang++" if os.path.exists("/opt/rocm/lib/llvm/bin/clang++") else "g++"
     subprocess.check_call([cxx, "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-psabi", "-I" + os.path.join(root, "include"), "-o", exe,
                            os.path.join(root, "tests", "tools", "qr_bench.cpp"), "-lpthread"])
-    for n, threads in ((5, 1), (24, 1), (31, 1), (32, 1), (33, 1), (64, 2), (85, 1), (97, 3), (127, 1), (260, 4)):
+    for n, threads in ((5, 1), (15, 1), (16, 1), (17, 1), (24, 1), (31, 1), (32, 1), (33, 1), (64, 2), (85, 1), (97, 3), (127, 1), (260, 4)):
         out = subprocess.run([exe, str(n), str(threads), "1"], capture_output=True, text=True, timeout=600)
         rec = json.loads(out.stdout.strip().splitlines()[-1])
         assert out.returncode == 0 and rec["bit_identical"] is True, (n, threads, out.stdout, out.stderr)
+    # the ISA picked at load time changes the vector width, never a rounding: the baseline (SSE2) build and an AVX2-only build
+    # of the same kernels are bit-identical to the scalar algorithm too
+    import platform
+    if platform.machine() == "x86_64":
+        for tag, flags in (("sse2", ["-DSOCP_ISA_CLONES="]), ("avx2", ["-DSOCP_ISA_CLONES=", "-mavx2"])):
+            if tag == "avx2" and "avx2" not in open("/proc/cpuinfo").read():
+                continue
+            exe2 = str(tmp_path / ("qr_bench_" + tag))
+            subprocess.check_call([cxx, "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-psabi"] + flags +
+                                  ["-I" + os.path.join(root, "include"), "-o", exe2, os.path.join(root, "tests", "tools", "qr_bench.cpp"), "-lpthread"])
+            for n, threads in ((33, 1), (97, 2), (260, 3)):
+                out = subprocess.run([exe2, str(n), str(threads), "1"], capture_output=True, text=True, timeout=600)
+                rec = json.loads(out.stdout.strip().splitlines()[-1])
+                assert out.returncode == 0 and rec["bit_identical"] is True, (tag, n, threads, out.stdout, out.stderr)
