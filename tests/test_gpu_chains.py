@@ -548,3 +548,26 @@ def test_throughput_flavour_chains_within_north_star_tolerance():
     rel = np.max(np.abs(out["fast"]["z"] - out["exact"]["z"]), axis=1) / np.max(np.abs(out["exact"]["z"]), axis=1)
     assert np.all(rel <= 1e-8), rel
     assert np.array_equal(out["fast"]["solves"], out["exact"]["solves"])
+
+
+def test_chain_engine_edge_cases():
+    """Empty batch, one chain, bad options, and a chain whose goal equals its start (b = 1 at once: a single solve)."""
+    import ctypes as C
+    from socp_amd import capi
+    ctx = make_ctx("exact")
+    goddard_m6(ctx)
+    r = ctx.chains_solve(np.zeros((0, 85)), kind=1, param_index=KD, step=1.0, goal=np.zeros(0), params=np.zeros((0, 8)), xtol=1e-6)
+    assert r["z"].shape == (0, 85) and r["stats"]["rounds"] == 0
+    one = ctx.chains_solve(STAGE2_INIT[None, :], kind=1, param_index=KD, step=1.0, goal=[0.0], params=np.array(PARAMS0)[None, :], xtol=1e-6)
+    assert one["info"][0] == 1 and one["solves"][0] == 1 and one["param_final"][0] == 0.0 and one["b_reached"][0] == 1.0
+    with pytest.raises(capi.SocpError):
+        ctx.chains_solve(STAGE2_INIT[None, :], kind=1, param_index=99, step=1.0, goal=[1.0], xtol=1e-6)          # no such parameter
+    with pytest.raises(capi.SocpError):
+        ctx.chains_solve(STAGE2_INIT[None, :], kind=1, param_index=KD, step=0.0, goal=[1.0], xtol=1e-6)          # step must be > 0
+    with pytest.raises(capi.SocpError):
+        ctx.chains_solve(STAGE2_INIT[None, :], kind=2, step=1.0, xtol=1e-6)                                      # data homotopy without data
+    with pytest.raises(capi.SocpError):
+        ctx.chains_solve(STAGE2_INIT[None, :], kind=0, xtol=1e-6, analytic_jac=True)                             # goddard has no variational equations
+    # the context is still usable after the refusals
+    assert np.all(np.isfinite(ctx.residual(STAGE2_INIT)))
+    ctx.close()
