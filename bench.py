@@ -285,7 +285,7 @@ def recorded_traffic(P, variant, rk4_steps):
     return None, None
 
 
-def parity_leg(torch, ctxs, dev, Z_host, rows_by_variant, rk4_steps, K):
+def parity_leg(Z_host, rows_by_variant, rk4_steps, K):
     """FD-batch rows of the first K starts against the CPU oracle (the checker; never inside a timed region)."""
     from oracle import oracle as orc
     o = orc.Oracle(orc.MODEL_GODDARD, step_nbr=rk4_steps, params=GODDARD_PARAMS)
@@ -491,7 +491,7 @@ def main():
             rows_by_variant[other] = d_rows2
             # ---- in-run parity of both flavours against the oracle -------------------------------------------------
             try:
-                out["parity"] = parity_leg(torch, None, dev, Z_host, rows_by_variant, args.rk4_steps, K=min(P, 16))
+                out["parity"] = parity_leg(Z_host, rows_by_variant, args.rk4_steps, K=min(P, 16))
                 if not out["parity"]["pass"]:
                     status = 1
             except Exception as exc:       # the checker is absent: say so, do not guess
