@@ -154,6 +154,12 @@ def main():
     ap.add_argument("--speculate", type=int, default=-1, help="socp_chain_options.speculate: -1 auto, 0 never, 1 always")
     args = ap.parse_args()
 
+    # stdout carries only the JSON record: RCCL prints a version banner to file descriptor 1 when a process group is created
+    import sys
+    sys.stdout.flush()
+    record_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from . import capi
@@ -227,7 +233,7 @@ def main():
         info = table[:, -2].astype(int)
         conv = table[info == 1, :n_unknown]
         spread = float(np.max(np.abs(conv - np.median(conv, axis=0))) / np.max(np.abs(conv))) if len(conv) else None
-        print(json.dumps({"solution_spread_rel": spread, "max_fnorm_converged": float(np.max(table[info == 1, -3])) if len(conv) else None,
+        record = json.dumps({"solution_spread_rel": spread, "max_fnorm_converged": float(np.max(table[info == 1, -3])) if len(conv) else None,
                           "sweep": ("goddard_kd_continuation_chains_M6_n85" if chain_kw is not None else
                                     "goddard_single_shooting_n14" if args.segments == 1 else "goddard_multiple_shooting_M%d_n%d" % (args.segments, n_unknown)),
                           "chains_per_s": (args.starts / wall) if chain_kw is not None else None,
@@ -238,7 +244,8 @@ def main():
                           "converged": int(np.sum(info == 1)), "info_histogram": {str(k): int(np.sum(info == k)) for k in np.unique(info)},
                           "trajectories": int(traj.item()), "trajectories_per_s": traj.item() / wall,
                           "solves_per_s": args.starts / wall, "rounds_rank0": int(local["rounds"]),
-                          "mean_nfev": float(np.mean(table[:, -1]))}), flush=True)
+                          "mean_nfev": float(np.mean(table[:, -1]))})
+        os.write(record_fd, (record + "\n").encode())
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
