@@ -517,6 +517,15 @@ def main():
             b0 = cpu_baseline_b0(args.rk4_steps, args.cpu_seconds)
             if b0:
                 out["cpu_baseline"]["b0"] = b0
+            # the GPU figures as multiples of both CPU baselines (reported, not the target: the roofline fraction is)
+            ratios = {"headline_over_b1": value / out["cpu_baseline"]["value"]}
+            if "exact" in out:
+                ratios["exact_over_b1"] = out["exact"]["value"] / out["cpu_baseline"]["value"]
+            if b0:
+                ratios["headline_over_b0"] = value / b0["value"]
+                if "exact" in out:
+                    ratios["exact_over_b0"] = out["exact"]["value"] / b0["value"]
+            out["cpu_baseline"]["gpu_ratios"] = ratios
         if world == 1 and not args.lean:
             cpu_v = out.get("cpu_baseline", {}).get("value")
             out["north_star_128"] = north_star_128(capi, local_rank, args.rk4_steps, cpu_v)
