@@ -102,6 +102,7 @@ int socp_ctx_synchronize(socp_ctx *ctx);
 int socp_ctx_dims(const socp_ctx *ctx, int *dim, int *state_len, int *state_len_jac);
 int socp_ctx_control_dim(const socp_ctx *ctx);
 int socp_ctx_device(const socp_ctx *ctx);            /* HIP device index the context lives on (< 0: error) */
+int socp_ctx_model_id(const socp_ctx *ctx);          /* SOCP_MODEL_* / plugin id the context was created with */
 
 /* counters since creation: trajectories integrated, kernel launches */
 int socp_ctx_counters(const socp_ctx *ctx, long long *trajectories, long long *launches);

@@ -91,6 +91,7 @@ def lib():
         L.socp_ctx_control_dim.argtypes = [_vp]
         L.socp_ctx_device.argtypes = [_vp]
         L.socp_ctx_num_params.argtypes = [_vp]
+        L.socp_ctx_model_id.argtypes = [_vp]
         L.socp_ctx_counters.argtypes = [_vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
         L.socp_integrate_batch.argtypes = [_vp, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_int]
         L.socp_integrate_batch_dev.argtypes = [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int]

@@ -127,6 +127,8 @@ extern "C" int socp_chains_solve_ex(socp_ctx *ctx, int P, const socp_chain_optio
     if (kind == SOCP_CHAIN_PARAM && (!goal || opt->param_index < 0 || opt->param_index >= nparams)) return SOCP_ERR_ARG;
     if (kind == SOCP_CHAIN_DATA && (!time_prev || !x_prev || !time_goal || !x_goal)) return SOCP_ERR_ARG;
     if (kind != SOCP_CHAIN_PLAIN && !(opt->step > 0)) return SOCP_ERR_ARG;
+    // the variational Jacobian exists for models with variational equations only (modelOrder 1: the double integrator)
+    if (opt->analytic_jac && socp_ctx_model_id(ctx) != SOCP_MODEL_DOUBLE_INTEGRATOR) return SOCP_ERR_UNSUPPORTED;
     if (P == 0) return SOCP_OK;
 
     // every allocation, copy and stream below lives on the context's device, whatever the calling thread's current device
