@@ -571,3 +571,19 @@ def test_chain_engine_edge_cases():
     # the context is still usable after the refusals
     assert np.all(np.isfinite(ctx.residual(STAGE2_INIT)))
     ctx.close()
+
+
+def test_a_nan_start_ends_its_own_chain_and_nothing_else():
+    """NaNs propagate silently in the reference: a chain that starts on NaN must come to an end by MINPACK's own
+    rules (info 4 / 5 after the slow-progress counters run out) without touching its neighbours' iterates."""
+    ctx = make_ctx("exact")
+    goddard_m6(ctx)
+    Z0 = np.tile(STAGE2_INIT, (3, 1))
+    Z0[1, 20] = np.nan
+    goals = np.array([310.0, 310.0, 310.0])
+    r = ctx.chains_solve(Z0, kind=1, param_index=KD, step=1.0, step_min=1e-3, goal=goals, params=np.tile(PARAMS0, (3, 1)), xtol=1e-6, max_rounds=400)
+    assert r["info"][0] == 1 and r["info"][2] == 1 and r["info"][1] != 1
+    assert np.array_equal(r["z"][0], r["z"][2])
+    alone = ctx.chains_solve(Z0[:1], kind=1, param_index=KD, step=1.0, goal=goals[:1], params=np.array(PARAMS0)[None, :], xtol=1e-6)
+    assert np.array_equal(alone["z"][0], r["z"][0]) and alone["nfev_total"][0] == r["nfev_total"][0]
+    ctx.close()
