@@ -131,6 +131,75 @@ def run_sweep(Z0, solve_local, dist=None, device=None):
     return table, local
 
 
+def interceptor_config5_problem(ctx, M=21):
+    """BASELINE config 5 class: the interceptor's scenario 1 (tests/testInterceptor.cpp) as an M-segment multiple-shooting problem,
+    final time and final velocity free: n = 12 M + 1 (253 at M = 21).  Node states along the CONVERGED trajectory of the test program
+    (tests/golden/interceptor_flow.json), integrated on the device with the reference's fixed-step scheme.  Returns the unknown vector."""
+    from . import capi
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gold = json.load(open(os.path.join(root, "tests", "golden", "interceptor_flow.json")))["scenario1_xtol1e-12"][-1]["z"]
+    RE = 6378145.0
+    X0, tf = np.array(gold[:12]), gold[12]
+    Xf = np.zeros(12)
+    Xf[:6] = [12000, 1000, 0.0, np.pi / 8, 5475000 / RE, 42000 / RE]
+    mode_t = [capi.FIXED] + [capi.CONTINUOUS] * (M - 1) + [capi.FREE]
+    mode_x = np.zeros((M + 1, 6), dtype=np.int32)
+    mode_x[1:M] = capi.CONTINUOUS
+    mode_x[M, 1] = capi.FREE
+    time = np.array([tf * i / M for i in range(M + 1)])
+    X = np.zeros((M + 1, 12))
+    X[0], X[M] = X0, Xf
+    ctx.set_integrator(capi.INT_RK4)
+    X[1:M] = ctx.integrate_batch(np.zeros(M - 1), time[1:M], np.repeat(X0[None, :], M - 1, axis=0))
+    n = ctx.problem_set(mode_t, mode_x, time, X)
+    return n, np.concatenate([X[:M].ravel(), [tf]])
+
+
+def interceptor_sweep(args, torch, dist, capi, world, rank, local_rank, dev, record_fd):
+    ctx = capi.Context(capi.MODEL_INTERCEPTOR, device=local_rank)
+    ctx.set_variant(capi.VARIANT_LANE_FAST if args.variant == "fast" else capi.VARIANT_LANE_EXACT)
+    n, z = interceptor_config5_problem(ctx)
+    if not args.fixed_step:
+        ctx.set_integrator(capi.INT_DOPRI5, args.ode_tol)
+    eps = args.eps if args.eps is not None else 1e-3
+    raw = mt19937_64(20250905, 6 * args.starts)
+    xi = ((raw >> np.uint64(11)).astype(np.float64) * 2.0 ** -53 * 2.0 - 1.0).reshape(args.starts, 6)
+    Z0 = np.tile(z, (args.starts, 1))
+    Z0[:, 6:12] *= 1.0 + eps * xi
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    stats = {}
+
+    def solve_block(Zb):
+        r = ctx.chains_solve(Zb, kind=capi.CHAIN_PLAIN, xtol=args.xtol, speculate=args.speculate, max_rounds=args.max_rounds)
+        stats.update(r["stats"])
+        r["rounds"] = r["stats"]["rounds"]
+        return r
+    t0 = time.perf_counter()
+    table, local = run_sweep(Z0, solve_block, dist if world > 1 else None, dev)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    traj = torch.tensor([float(ctx.counters()[0])], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(traj)
+    if rank == 0:
+        info = table[:, -2].astype(int)
+        conv = table[info == 1, :n]
+        record = json.dumps({"sweep": "interceptor_config5_M21_n%d_%s" % (n, "rk4" if args.fixed_step else "dopri5_tol%g" % args.ode_tol),
+                             "starts": args.starts, "eps": eps, "n_gpus": world, "variant": args.variant, "xtol": args.xtol, "wall_s": wall,
+                             "converged": int(np.sum(info == 1)), "info_histogram": {str(k): int(np.sum(info == k)) for k in np.unique(info)},
+                             "solution_spread_rel": float(np.max(np.abs(conv - np.median(conv, axis=0))) / np.max(np.abs(conv))) if len(conv) else None,
+                             "solves_per_s": args.starts / wall, "trajectories": int(traj.item()), "trajectories_per_s": traj.item() / wall,
+                             "rounds_rank0": int(local["rounds"]), "mean_nfev": float(np.mean(table[:, -1])), "engine_rank0": stats})
+        os.write(record_fd, (record + "\n").encode())
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--starts", type=int, default=4096)
@@ -146,6 +215,12 @@ def main():
                     help="kd: every start is a CHAIN of testGoddard's drag continuation, SolveOCP(step, \"KD\", goal) "
                          "(shooting.cpp:695-778), started from the no-drag solution of the test (tests/golden) with node-0 "
                          "costates perturbed by --eps; all chains advance in lock-step (socp_chains_solve)")
+    ap.add_argument("--model", choices=["goddard", "interceptor"], default="goddard",
+                    help="interceptor: BASELINE config 5 class -- M = 21 segments, n = 253 unknowns, nodes along the converged "
+                         "scenario-1 trajectory of the reference's test program (tests/golden), node-0 costates perturbed by --eps "
+                         "(default 1e-3), adaptive Dormand-Prince unless --fixed-step; every start is a full Newton solve")
+    ap.add_argument("--fixed-step", action="store_true", help="interceptor: the reference's 50 fixed RK4 steps per stage instead of Dormand-Prince")
+    ap.add_argument("--ode-tol", type=float, default=1e-8, help="interceptor: tolerance of the adaptive integrator")
     ap.add_argument("--kd-goal", type=float, default=310.0)
     ap.add_argument("--kd-spread", type=float, default=0.0, help="chain p's goal = kd-goal * (1 + spread * xi_p), xi uniform(-1, 1)")
     ap.add_argument("--step", type=float, default=1.0, help="continuationStep of the chains")
@@ -174,6 +249,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
+    if args.model == "interceptor":
+        return interceptor_sweep(args, torch, dist, capi, world, rank, local_rank, dev, record_fd)
     ctx = capi.Context(capi.MODEL_GODDARD, device=local_rank)
     ctx.set_params(GODDARD_PARAMS)
     ctx.set_step_number(args.rk4_steps)

@@ -587,3 +587,29 @@ def test_a_nan_start_ends_its_own_chain_and_nothing_else():
     alone = ctx.chains_solve(Z0[:1], kind=1, param_index=KD, step=1.0, goal=goals[:1], params=np.array(PARAMS0)[None, :], xtol=1e-6)
     assert np.array_equal(alone["z"][0], r["z"][0]) and alone["nfev_total"][0] == r["nfev_total"][0]
     ctx.close()
+
+
+def test_config5_interceptor_solve_sweep():
+    """BASELINE config 5 as a SOLVE sweep (python -m socp_amd.sweep --model interceptor): interceptor, adaptive Dormand-Prince,
+    M = 21, n = 253 -- a handful of starts around the converged scenario-1 trajectory, full Newton solves in lock-step, all on
+    the same root; the throughput flavour agrees with the reference-order flavour within north_star's 1e-8."""
+    from socp_amd import capi, sweep
+    roots = {}
+    for variant in ("exact", "fast"):
+        ctx = capi.Context(capi.MODEL_INTERCEPTOR)
+        ctx.set_variant(capi.VARIANT_LANE_EXACT if variant == "exact" else capi.VARIANT_LANE_FAST)
+        n, z = sweep.interceptor_config5_problem(ctx)
+        assert n == 253
+        # the adaptive integrator's step-size decisions put noise of the order of its tolerance into the FD Jacobian: the solver
+        # tolerance has to stay above it (xtol 1e-9 over an ODE tolerance of 1e-11)
+        ctx.set_integrator(capi.INT_DOPRI5, 1e-11)
+        rng = np.random.default_rng(4)
+        Z0 = np.tile(z, (6, 1))
+        Z0[:, 6:12] *= 1 + 1e-3 * rng.uniform(-1, 1, (6, 6))
+        r = ctx.chains_solve(Z0, kind=0, xtol=1e-9)
+        assert np.all(r["info"] == 1), r["info"]
+        spread = np.max(np.abs(r["z"] - r["z"][0])) / np.max(np.abs(r["z"][0]))
+        assert spread < 1e-8, spread
+        roots[variant] = r["z"][0]
+        ctx.close()
+    assert np.max(np.abs(roots["fast"] - roots["exact"])) / np.max(np.abs(roots["exact"])) <= 1e-8
