@@ -47,6 +47,13 @@ typedef struct socp_hybr socp_hybr;
 socp_hybr *socp_hybr_create(int n, double xtol, int maxfev, double epsfcn, int mode, double factor,
                             int analytic_jac);
 void socp_hybr_destroy(socp_hybr *s);
+/* `count` solvers of one size in one arena (huge pages where the system grants them): what the lock-step engine uses.  The
+ * solvers belong to the pool: never pass them to socp_hybr_destroy. */
+typedef struct socp_hybr_pool socp_hybr_pool;
+socp_hybr_pool *socp_hybr_pool_create(int count, int n, double xtol, int maxfev, double epsfcn, int mode, double factor,
+                                      int analytic_jac);
+socp_hybr *socp_hybr_pool_get(socp_hybr_pool *pool, int i);
+void socp_hybr_pool_destroy(socp_hybr_pool *pool);
 /* (re)start from x0; diag may be NULL (mode 1) */
 int socp_hybr_start(socp_hybr *s, const double *x0, const double *diag);
 /* user_flag: value the caller's evaluation returned for the PREVIOUS request (< 0 aborts). */

@@ -181,9 +181,11 @@ extern "C" int socp_chains_solve_ex(socp_ctx *ctx, int P, const socp_chain_optio
         }
     };
     bool alloc_ok = true;
+    socp_hybr_pool *pool = socp_hybr_pool_create(P, n, opt->xtol, opt->maxfev, opt->epsfcn, 1, opt->factor, opt->analytic_jac ? 1 : 0);
+    if (!pool) return SOCP_ERR_ARG;
     parallel_for(P, [&](int p) {
         Chain &c = ch[p];
-        c.solver = socp_hybr_create(n, opt->xtol, opt->maxfev, opt->epsfcn, 1, opt->factor, opt->analytic_jac ? 1 : 0);
+        c.solver = socp_hybr_pool_get(pool, p);
         c.committed.assign(Z0 + (size_t)p * n, Z0 + (size_t)(p + 1) * n);
         c.eval_x.resize(n); c.slot_x.resize(n);
         if (pp_params) {
@@ -200,7 +202,7 @@ extern "C" int socp_chains_solve_ex(socp_ctx *ctx, int P, const socp_chain_optio
         set_blocks(p);
         if (c.solver) socp_hybr_start(c.solver, c.committed.data(), nullptr);
     });
-    auto cleanup = [&]() { parallel_for(P, [&](int p) { socp_hybr_destroy(ch[p].solver); ch[p].solver = nullptr; }); };
+    auto cleanup = [&]() { for (Chain &c : ch) c.solver = nullptr; socp_hybr_pool_destroy(pool); pool = nullptr; };
     for (int p = 0; p < P; p++) if (!ch[p].solver) alloc_ok = false;
     if (!alloc_ok) { cleanup(); return SOCP_ERR_ARG; }
 
