@@ -329,20 +329,7 @@ def north_star_128(capi, device, rk4_steps, cpu_traj_per_s):
         ctx.set_params(GODDARD_PARAMS)
         ctx.set_step_number(rk4_steps)
         ctx.set_variant(variant)
-        M, d, s = 9, 7, 14
-        mode_t = [capi.FIXED] + [capi.CONTINUOUS] * (M - 1) + [capi.FREE]
-        mode_t[M // 2] = capi.FREE
-        mode_x = np.full((M + 1, d), capi.CONTINUOUS, dtype=np.int32)
-        mode_x[0] = capi.FIXED
-        mode_x[M] = capi.FIXED
-        mode_x[M, 3:7] = capi.FREE
-        tn = np.linspace(0.0, sweep.TF, M + 1)
-        X = np.zeros((M + 1, s))
-        X[0] = np.concatenate([sweep.X0_STATE, sweep.PSTAR])
-        X[M, 0] = 1.01
-        X[1:M] = ctx.integrate_batch(np.zeros(M - 1), tn[1:M], np.repeat(X[0][None, :], M - 1, axis=0))
-        n = ctx.problem_set(mode_t, mode_x, tn, X)
-        z = np.concatenate([X[:M].ravel(), [tn[j] for j in range(M + 1) if mode_t[j] == capi.FREE]])
+        n, z, _mt, _mx, _tn, _X = sweep.goddard_north_star_128_problem(ctx)
         assert n == 128 and len(z) == n
         F0 = ctx.residual(z)
         res = {}

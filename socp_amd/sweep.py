@@ -108,6 +108,30 @@ def goddard_multiple_shooting_starts(ctx, Z14, M, tf=TF):
     return Z
 
 
+def goddard_north_star_128_problem(ctx, M=9):
+    """north_star's "128-unknown" Goddard layout: M = 9 segments, FREE final time plus ONE FREE interior time (node
+    M // 2) -> n = 14 * 9 + 2 = 128.  Node states along the p* trajectory, integrated on the device.  The interior free time adds
+    the row H(X-) = 0 (goddard.cpp:343-370, shooting.cpp:961-973) and spaces the CONTINUOUS nodes on either side of it uniformly
+    (shooting.cpp:1592-1609); under the smooth law (mu2 > 0) that row is redundant with the free-tf row, so this layout is for
+    Jacobian batches at a fixed z, not for solves.  Returns (n, z, mode_t, mode_x, time, X)."""
+    from . import capi
+    d, s = 7, 14
+    mode_t = [capi.FIXED] + [capi.CONTINUOUS] * (M - 1) + [capi.FREE]
+    mode_t[M // 2] = capi.FREE
+    mode_x = np.full((M + 1, d), capi.CONTINUOUS, dtype=np.int32)
+    mode_x[0] = capi.FIXED
+    mode_x[M] = capi.FIXED
+    mode_x[M, 3:7] = capi.FREE
+    tn = np.linspace(0.0, TF, M + 1)
+    X = np.zeros((M + 1, s))
+    X[0] = np.concatenate([X0_STATE, PSTAR])
+    X[M, 0] = 1.01
+    X[1:M] = ctx.integrate_batch(np.zeros(M - 1), tn[1:M], np.repeat(X[0][None, :], M - 1, axis=0))
+    n = ctx.problem_set(mode_t, mode_x, tn, X)
+    z = np.concatenate([X[:M].ravel(), [tn[j] for j in range(M + 1) if mode_t[j] == capi.FREE]])
+    return n, z, mode_t, mode_x, tn, X
+
+
 def run_sweep(Z0, solve_local, dist=None, device=None):
     """Shard the rows of Z0 over the ranks, solve, gather.  `solve_local(Zblock)` returns a dict with
     z [k][n], info [k], nfev [k], fnorm [k].  Returns (table [P][n+3] in start order, local dict)."""
