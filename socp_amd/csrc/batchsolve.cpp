@@ -29,6 +29,8 @@
 #include <thread>
 #include <vector>
 
+#include "host_pool.hpp"
+
 namespace {
 
 struct Pinned {
@@ -49,8 +51,9 @@ struct Pinned {
 };
 struct Dev {
     void *p = nullptr;
-    bool alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8) == hipSuccess; }
-    ~Dev() { if (p) (void)hipFree(p); }
+    bool alloc(size_t bytes) { release(); return hipMalloc(&p, bytes ? bytes : 8) == hipSuccess; }
+    void release() { if (p) (void)hipFree(p); p = nullptr; }
+    ~Dev() { release(); }
     double *d() const { return static_cast<double *>(p); }
     int *i() const { return static_cast<int *>(p); }
 };
@@ -127,6 +130,9 @@ extern "C" int socp_chains_solve_ex(socp_ctx *ctx, int P, const socp_chain_optio
     if (kind == SOCP_CHAIN_PARAM && (!goal || opt->param_index < 0 || opt->param_index >= nparams)) return SOCP_ERR_ARG;
     if (kind == SOCP_CHAIN_DATA && (!time_prev || !x_prev || !time_goal || !x_goal)) return SOCP_ERR_ARG;
     if (kind != SOCP_CHAIN_PLAIN && !(opt->step > 0)) return SOCP_ERR_ARG;
+    // continuationStepMin: a negative or NaN value can never end the bisection of a chain whose solves keep failing (0 can: the
+    // halving stops moving b after ~55 steps, see solve_finished)
+    if (kind != SOCP_CHAIN_PLAIN && !(opt->step_min >= 0)) return SOCP_ERR_ARG;
     // the variational Jacobian exists for models with variational equations only (modelOrder 1: the double integrator)
     if (opt->analytic_jac && socp_ctx_model_id(ctx) != SOCP_MODEL_DOUBLE_INTEGRATOR) return SOCP_ERR_UNSUPPORTED;
     if (P == 0) return SOCP_OK;
@@ -154,13 +160,14 @@ extern "C" int socp_chains_solve_ex(socp_ctx *ctx, int P, const socp_chain_optio
     auto ms_since = [](clk::time_point t) { return std::chrono::duration<double, std::milli>(clk::now() - t).count(); };
     const unsigned hw = std::thread::hardware_concurrency();
     const int nthreads = ((long)P * n * n < 200000) ? 1 : (int)std::max(1u, std::min(16u, hw ? hw : 1u));
+    // one pool of host workers for the whole call (the reference starts and joins its threads on every residual call,
+    // shooting.cpp:1152-1157; an engine round calls this several times): chains are dealt out in blocks, results never depend on
+    // which thread advances a chain
+    socp::Pool workers(nthreads);
     auto parallel_for = [&](int count, auto &&body) {
         if (nthreads <= 1 || count < 2 * nthreads) { for (int k = 0; k < count; k++) body(k); return; }
-        std::vector<std::thread> pool;
-        pool.reserve(nthreads);
-        for (int t = 0; t < nthreads; t++)
-            pool.emplace_back([&, t]() { for (int k = t; k < count; k += nthreads) body(k); });
-        for (std::thread &th : pool) th.join();
+        const int blocks = std::min(count, 8 * nthreads), per = (count + blocks - 1) / blocks;
+        workers.run(blocks, [&](int b) { for (int k = b * per, e = std::min(count, (b + 1) * per); k < e; k++) body(k); });
     };
 
     // ---- per-chain state --------------------------------------------------------------------------------------------
@@ -218,11 +225,16 @@ extern "C" int socp_chains_solve_ex(socp_ctx *ctx, int P, const socp_chain_optio
     if (const char *e = std::getenv("SOCP_CHAINS_SPECULATE")) speculate = std::atoi(e);
     if ((double)P * rowsB * 2 > 16e9) speculate = 0;              // slots + staging would not be "free"
     if (opt->analytic_jac) speculate = 0;                          // no finite differences on the hybrj path
-    const bool spec_on = speculate != 0;
+    bool spec_on = speculate != 0;
     int G = (P >= 2048 && n >= 32 && !opt->analytic_jac) ? 2 : 1;  // the batched variational Jacobian keeps one scratch area per context
     if (const char *e = std::getenv("SOCP_CHAINS_GROUPS")) G = std::max(1, std::min(4, std::atoi(e)));
     if (opt->analytic_jac || G > P) G = 1;
 
+    int num_simd = 1024;                                            // MI355X: 256 CUs x 4 SIMDs; read from the device the context lives on
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, socp_ctx_device(ctx)) == hipSuccess && prop.multiProcessorCount > 0) num_simd = 4 * prop.multiProcessorCount;
+    }
     static const bool trace = std::getenv("SOCP_MULTISTART_TRACE") != nullptr;
     static const bool overlap = [] { const char *e = std::getenv("SOCP_MULTISTART_OVERLAP"); return !(e && e[0] == '0'); }();
     void *main_stream_v = nullptr;
@@ -244,29 +256,47 @@ extern "C" int socp_chains_solve_ex(socp_ctx *ctx, int P, const socp_chain_optio
     };
     std::vector<Group> grp(G);
     Dev dSlots;
-    bool ok = !spec_on || dSlots.alloc(rowsB * P);
+    // device and pinned buffers of every group.  full = false: the Jacobians of a round are launched in passes of the pinned
+    // staging size instead of all at once (what is left to try when the device buffers do not fit)
+    auto allocate = [&](bool full) {
+        bool ok = !spec_on || dSlots.alloc(rowsB * P);
+        for (int g = 0; g < G && ok; g++) {
+            Group &q = grp[g];
+            q.lo = (int)((long)P * g / G); q.hi = (int)((long)P * (g + 1) / G);
+            const size_t C = (size_t)(q.hi - q.lo);
+            q.jchunk = (int)std::max<size_t>(1, std::min<size_t>(C, ((size_t)64 << 20) / jacB / G));
+            // The launch is not cut to the staging size: a chunk of a few hundred problems leaves the chip half empty (measured: 93 k
+            // trajectories per chunk ran at 3.7 M traj/s against 6.3 M for the whole round in one launch).  HBM is plentiful: up to
+            // 8 GiB of Jacobians per group stay on the device and come back through the pinned buffer in passes.
+            q.jlaunch = full ? (int)std::max<size_t>((size_t)q.jchunk, std::min<size_t>(C, ((size_t)8 << 30) / jacB / G)) : q.jchunk;
+            ok = q.hX.reserve(rowB * C) && q.hF.reserve(rowB * C) && q.hJx.reserve(rowB * C) && q.hJf.reserve(rowB * C) && q.hJ.reserve(jacB * q.jchunk) &&
+                 q.dX.alloc(rowB * C) && q.dF.alloc(rowB * C) && q.dJx.alloc(rowB * C) && q.dJf.alloc(rowB * C) && q.dJ.alloc(jacB * q.jlaunch) &&
+                 q.hIdx.reserve(sizeof(int) * 2 * C) && q.dIdx.alloc(sizeof(int) * 2 * C);
+            if (ok && pp_params) ok = q.hPF.reserve(sizeof(double) * stride * C) && q.hPJ.reserve(sizeof(double) * stride * C) &&
+                                      q.dPF.alloc(sizeof(double) * stride * C) && q.dPJ.alloc(sizeof(double) * stride * C);
+            if (ok && pp_bound) ok = q.hTF.reserve(sizeof(double) * nodes * C) && q.hTJ.reserve(sizeof(double) * nodes * C) &&
+                                     q.hXF.reserve(sizeof(double) * nodes * S * C) && q.hXJ.reserve(sizeof(double) * nodes * S * C) &&
+                                     q.dTF.alloc(sizeof(double) * nodes * C) && q.dTJ.alloc(sizeof(double) * nodes * C) &&
+                                     q.dXF.alloc(sizeof(double) * nodes * S * C) && q.dXJ.alloc(sizeof(double) * nodes * S * C);
+            if (ok && spec_on) ok = q.dStage.alloc(rowsB * C);
+        }
+        if (!ok) (void)hipGetLastError();                          // an out-of-memory hipMalloc leaves a sticky error behind
+        return ok;
+    };
+    bool ok = allocate(true);
+    if (!ok) {
+        // not enough HBM for the comfortable set-up: drop what is optional -- the speculation cache (2 x P x (n+1) x n doubles)
+        // and the whole-round Jacobian buffer -- and try once more before giving up.  No iterate depends on either.
+        dSlots.release();
+        for (Group &q : grp) { q.dStage.release(); q.dJ.release(); }
+        spec_on = false; speculate = 0;
+        ok = allocate(false);
+    }
     for (int g = 0; g < G && ok; g++) {
         Group &q = grp[g];
-        q.lo = (int)((long)P * g / G); q.hi = (int)((long)P * (g + 1) / G);
-        const size_t C = (size_t)(q.hi - q.lo);
-        q.jchunk = (int)std::max<size_t>(1, std::min<size_t>(C, ((size_t)64 << 20) / jacB / G));
-        // The launch is not cut to the staging size: a chunk of a few hundred problems leaves the chip half empty (measured: 93 k
-        // trajectories per chunk ran at 3.7 M traj/s against 6.3 M for the whole round in one launch).  HBM is plentiful: up to
-        // 8 GiB of Jacobians per group stay on the device and come back through the pinned buffer in passes.
-        q.jlaunch = (int)std::max<size_t>((size_t)q.jchunk, std::min<size_t>(C, ((size_t)8 << 30) / jacB / G));
-        ok = q.hX.reserve(rowB * C) && q.hF.reserve(rowB * C) && q.hJx.reserve(rowB * C) && q.hJf.reserve(rowB * C) && q.hJ.reserve(jacB * q.jchunk) &&
-             q.dX.alloc(rowB * C) && q.dF.alloc(rowB * C) && q.dJx.alloc(rowB * C) && q.dJf.alloc(rowB * C) && q.dJ.alloc(jacB * q.jlaunch) &&
-             q.hIdx.reserve(sizeof(int) * 2 * C) && q.dIdx.alloc(sizeof(int) * 2 * C);
-        if (ok && pp_params) ok = q.hPF.reserve(sizeof(double) * stride * C) && q.hPJ.reserve(sizeof(double) * stride * C) &&
-                                  q.dPF.alloc(sizeof(double) * stride * C) && q.dPJ.alloc(sizeof(double) * stride * C);
-        if (ok && pp_bound) ok = q.hTF.reserve(sizeof(double) * nodes * C) && q.hTJ.reserve(sizeof(double) * nodes * C) &&
-                                 q.hXF.reserve(sizeof(double) * nodes * S * C) && q.hXJ.reserve(sizeof(double) * nodes * S * C) &&
-                                 q.dTF.alloc(sizeof(double) * nodes * C) && q.dTJ.alloc(sizeof(double) * nodes * C) &&
-                                 q.dXF.alloc(sizeof(double) * nodes * S * C) && q.dXJ.alloc(sizeof(double) * nodes * S * C);
-        if (ok && spec_on) ok = q.dStage.alloc(rowsB * C);
         // group 0 launches its Jacobians on the context's stream (as the engine always did); residual-type work on a second one
-        if (ok && g == 0) q.js = main_stream;
-        else if (ok) { ok = hipStreamCreateWithFlags(&q.js, hipStreamNonBlocking) == hipSuccess; q.own_js = ok; }
+        if (g == 0) q.js = main_stream;
+        else { ok = hipStreamCreateWithFlags(&q.js, hipStreamNonBlocking) == hipSuccess; q.own_js = ok; }
         if (ok && overlap) { ok = hipStreamCreateWithFlags(&q.fs, hipStreamNonBlocking) == hipSuccess; q.own_fs = ok; }
         else if (ok) q.fs = q.js;
     }
@@ -303,6 +333,8 @@ extern "C" int socp_chains_solve_ex(socp_ctx *ctx, int P, const socp_chain_optio
         std::vector<double> next;                                  // tab_param_temp for the next solve
         if (c.info != 1) {
             if (std::fabs(c.b - c.b_prec) < opt->step_min) running = false;
+            // the halving has stopped moving b (only reachable with step_min = 0, where the reference's loop never ends)
+            if (c.b == c.b_prec) running = false;
             c.b = c.b_prec + (c.b - c.b_prec) / 2;
             next = c.committed;
         } else if (c.b == 1) {
@@ -417,7 +449,7 @@ extern "C" int socp_chains_solve_ex(socp_ctx *ctx, int P, const socp_chain_optio
         if (spec_on && kF) {
             if (speculate > 0) kS = kF;
             else {
-                const long lanes = (1024 / G - ((long)kJ * n * segs + 63) / 64) * 64;
+                const long lanes = (num_simd / G - ((long)kJ * n * segs + 63) / 64) * 64;
                 kS = ((long)kF * (n + 1) * segs <= lanes) ? kF : 0;
             }
         }

@@ -23,7 +23,8 @@ using namespace socp;
 
 namespace {
 
-std::string g_create_error;
+// socp_last_error(NULL) reports the calling thread's last creation failure: concurrent socp_ctx_create calls may fail at once
+thread_local std::string g_create_error;
 
 struct DevBuf {
     void *p = nullptr;
@@ -308,6 +309,7 @@ int socp_ctx_get_stream(const socp_ctx *c, void **hip_stream)
 int socp_ctx_synchronize(socp_ctx *c)
 {
     if (!c) return SOCP_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return SOCP_OK;
 }
@@ -607,6 +609,9 @@ int socp_residual_batch_blocks(socp_ctx *c, int B, const double *Z, const double
     if (!c) return SOCP_ERR_ARG;
     if (!c->has_problem) return fail(c, SOCP_ERR_ARG, "residual_batch_blocks: no problem set");
     if (B < 0 || (B > 0 && (!Z || !F))) return fail(c, SOCP_ERR_ARG, "residual_batch_blocks: null argument");
+    // before anything is sized or copied from it: a wrong stride would read past the caller's array
+    if (params && stride != c->nparams + 2)
+        return fail(c, SOCP_ERR_ARG, "residual_batch_blocks: stride must be nparams + 2 (parameters, then two switching times)");
     if (B == 0) return SOCP_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t nodes = (size_t)c->M + 1;

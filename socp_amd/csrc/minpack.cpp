@@ -24,13 +24,18 @@
 #include <condition_variable>
 #include <cstring>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
 
 #include <sys/mman.h>
 
+#include "host_pool.hpp"
+
 namespace {
+
+using socp::Pool;      // host_pool.hpp: a solve's worker threads, handed a batch of tasks per panel / per sweep
 
 constexpr double kEpsMch = DBL_EPSILON;      // dpmpar(1)
 constexpr double kGiant = DBL_MAX;           // dpmpar(3)
@@ -321,102 +326,16 @@ void qform_block(int n, int j0, const double *V, const size_t *off, double *Qt, 
     }
 }
 
-// Worker threads for ONE factorisation: started once, handed a batch of tasks per panel (an atomic counter deals them out, so
-// a thread that finishes early takes the next block).  Between batches a worker waits actively for at most ~40 us and then
-// parks on a condition variable (the process may run under a CPU quota: no unbounded spinning).  Starting and joining 15
-// threads at each of the 26 panels of n = 832 cost as much as the arithmetic.
-class Pool {
-public:
-    explicit Pool(int threads) : n_(std::max(1, threads))
-    {
-        for (int w = 1; w < n_; w++) th_.emplace_back([this]() { worker(); });
-    }
-    ~Pool()
-    {
-        { std::lock_guard<std::mutex> lk(m_); stop_.store(true); }
-        cv_start_.notify_all();
-        for (std::thread &t : th_) t.join();
-    }
-    template <class Body>
-    void run(int tasks, Body &&body)
-    {
-        if (tasks <= 0) return;
-        if (n_ == 1 || tasks == 1) { for (int t = 0; t < tasks; t++) body(t); return; }
-        std::function<void(int)> fn = body;
-        {
-            std::lock_guard<std::mutex> lk(m_);
-            job_ = &fn; tasks_ = tasks; next_.store(0); busy_.store(n_ - 1); gen_.fetch_add(1);
-        }
-        cv_start_.notify_all();
-        for (int t; (t = next_.fetch_add(1)) < tasks;) fn(t);
-        if (!spin_until([this]() { return busy_.load() == 0; })) {
-            std::unique_lock<std::mutex> lk(m_);
-            cv_done_.wait(lk, [this]() { return busy_.load() == 0; });
-        }
-        std::lock_guard<std::mutex> lk(m_);     // the last worker has left its critical section
-        job_ = nullptr;
-    }
-
-private:
-    // A batch is tens of microseconds of work per thread and the next one follows at once, while waking a parked thread
-    // costs 50-100 us: wait actively for a SHORT, bounded time (about 40 us), then park on the condition variable.
-    template <class Pred>
-    static bool spin_until(Pred &&done)
-    {
-        const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-        for (int it = 0;; it++) {
-            if (done()) return true;
-#if defined(__x86_64__)
-            __builtin_ia32_pause();
-#endif
-            if ((it & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(40)) return false;
-        }
-    }
-    void worker()
-    {
-        int seen = 0;
-        for (;;) {
-            if (!spin_until([&]() { return stop_.load() || gen_.load() != seen; })) {
-                std::unique_lock<std::mutex> lk(m_);
-                cv_start_.wait(lk, [&]() { return stop_.load() || gen_.load() != seen; });
-            }
-            if (stop_.load()) return;
-            const std::function<void(int)> *fn;
-            int tasks;
-            {
-                std::lock_guard<std::mutex> lk(m_);
-                seen = gen_.load(); fn = job_; tasks = tasks_;
-            }
-            if (fn)
-                for (int t; (t = next_.fetch_add(1)) < tasks;) (*fn)(t);
-            bool last;
-            {
-                std::lock_guard<std::mutex> lk(m_);
-                last = busy_.fetch_sub(1) == 1;
-            }
-            if (last) cv_done_.notify_one();
-        }
-    }
-    int n_;
-    std::vector<std::thread> th_;
-    std::mutex m_;
-    std::condition_variable cv_start_, cv_done_;
-    const std::function<void(int)> *job_ = nullptr;
-    int tasks_ = 0;
-    std::atomic<int> next_{0}, busy_{0}, gen_{0};
-    std::atomic<bool> stop_{false};
-};
-
 // fjac (column-major, ld ldfjac): in = Jacobian, out = Q.  rdiag / acnorm as qrfac, qtf = Q^T fvec, r = R packed by rows.
-void factor(int n, double *fjac, int ldfjac, const double *fvec, double *rdiag, double *acnorm, double *qtf, double *r, int threads)
+void factor(int n, double *fjac, int ldfjac, const double *fvec, double *rdiag, double *acnorm, double *qtf, double *r, Pool &pool)
 {
+    const int threads = pool.size();
     static const bool trace = std::getenv("SOCP_LINALG_TRACE") != nullptr;      // phase times of every call, to stderr
     using clk = std::chrono::steady_clock;
     auto lap = [&](clk::time_point &t) { const clk::time_point now = clk::now(); const double ms = std::chrono::duration<double, std::milli>(now - t).count(); t = now; return ms; };
     clk::time_point tick = clk::now();
     double t_in = 0, t_panel = 0, t_trail = 0, t_out = 0, t_qform = 0;
     const int ld = ((n + 1 + CB - 1) / CB) * CB;                 // columns 0..n-1, column n = fvec -> qtf, zero padding
-    Pool pool(std::min(threads, std::max(1, n / CB)));
     // 64-byte aligned: a block's row segment is exactly four cache lines (no split loads, no line shared by two threads)
     std::vector<double> At_store((size_t)n * ld + 8, 0.0);
     double *const At = At_store.data() + ((64 - (reinterpret_cast<uintptr_t>(At_store.data()) & 63)) & 63) / sizeof(double);
@@ -634,7 +553,7 @@ inline void decode_rotation(double t, double &cs, double &sn)
 }
 
 // a (m x n, column-major) <- a * Q1 with Q1 replayed from the encodings left in v and w by r1updt
-void r1mpyq(int m, int n, double *a, int lda, const double *v, const double *w, int threads = 1)
+void r1mpyq(int m, int n, double *a, int lda, const double *v, const double *w, Pool *pool = nullptr)
 {
     // every row of a goes through the same 2(n-1) rotations and no rotation mixes rows: large matrices are split
     // by ROW RANGE over host threads (same operations per element, bit-identical for any count)
@@ -662,12 +581,9 @@ void r1mpyq(int m, int n, double *a, int lda, const double *v, const double *w, 
             }
         }
     };
-    if (threads <= 1 || m < 256) { rows(0, m); return; }
-    const int T = std::min(threads, m / 64);
-    std::vector<std::thread> pool;
-    for (int t = 1; t < T; t++) pool.emplace_back(rows, (int)((long)m * t / T), (int)((long)m * (t + 1) / T));
-    rows(0, (int)((long)m / T));
-    for (std::thread &th : pool) th.join();
+    if (!pool || pool->size() <= 1 || m < 256) { rows(0, m); return; }
+    const int T = std::min(pool->size(), m / 64);
+    pool->run(T, [&](int t) { rows((int)((long)m * t / T), (int)((long)m * (t + 1) / T)); });
 }
 
 enum Phase { PH_INIT, PH_F0, PH_JAC, PH_TRIAL, PH_DONE };
@@ -678,6 +594,12 @@ struct Core {
     double xtol = 0, epsfcn = 0, factor = 0;
     bool analytic = false, bad_input = false;
     int lin_threads = 1;            // host threads for qrfac / qform (bit-identical for any count; see qrfac_nopivot)
+    std::shared_ptr<Pool> pool;     // the solve's worker threads: started at its first factorisation, kept until the solver goes
+    Pool &workers()
+    {
+        if (!pool || pool->size() != std::max(1, lin_threads)) pool = std::make_shared<Pool>(lin_threads);
+        return *pool;
+    }
     // caller-visible arrays
     double *x = nullptr, *fvec = nullptr, *diag = nullptr, *fjac = nullptr, *r = nullptr, *qtf = nullptr;
     double *wa1 = nullptr, *wa2 = nullptr, *wa3 = nullptr, *wa4 = nullptr;
@@ -722,7 +644,7 @@ struct Core {
     {
         if (analytic) njev += 1; else nfev += msum;
         const bool vec = colvec_enabled() && n >= colvec::kMinN;
-        if (vec) colvec::factor(n, fjac, ldfjac, fvec, wa1, wa2, qtf, r, lin_threads);     // qrfac + qtf + R + qform, columns in SIMD lanes
+        if (vec) colvec::factor(n, fjac, ldfjac, fvec, wa1, wa2, qtf, r, workers());     // qrfac + qtf + R + qform, columns in SIMD lanes
         else qrfac_nopivot(n, fjac, ldfjac, wa1, wa2, lin_threads);      // wa1 = diag(R), wa2 = column norms
         if (iter == 1) {
             if (mode != 2)
@@ -819,7 +741,7 @@ struct Core {
             if (ratio >= p0001) qtf[j] = sum;
         }
         r1updt(n, r, wa1, wa2, wa3, sing);
-        r1mpyq(n, n, fjac, ldfjac, wa2, wa3, lin_threads);
+        r1mpyq(n, n, fjac, ldfjac, wa2, wa3, (lin_threads > 1 && n >= 256) ? &workers() : nullptr);
         r1mpyq(1, n, qtf, 1, wa2, wa3);
         jeval = false;
         return request_trial(xe, out);

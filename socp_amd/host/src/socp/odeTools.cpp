@@ -87,8 +87,11 @@ odeTools::odeVector step_fn(int order, real t, odeTools::odeVector const &X, rea
 }
 void step_ode(int order, real t, odeTools::odeVector &X, real step, odeTools::modelStruct const &ode)
 {
-    X = rk_step(order, t, X, step, [&](real tt, odeTools::odeVector const &Y) {
-        odeTools::odeVector F(Y);
+    // every stage's output vector starts as a copy of the step's INPUT state, as in the reference (odeTools.cpp:51,68,89:
+    // F1 = X, F2 = X, ...): a user operator() that leaves components unwritten then sees the same numbers in stages 2-4
+    const odeTools::odeVector X0(X);
+    X = rk_step(order, t, X0, step, [&](real tt, odeTools::odeVector const &Y) {
+        odeTools::odeVector F(X0);
         ode(Y, F, tt);
         return F;
     });

@@ -12,12 +12,16 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <functional>
 #include <future>
+#include <memory>
 #include <stdexcept>
+#include <string>
 #include <thread>
 
 #include "socp_hip.h"
 #include "socp_solver.h"
+#include "host_pool.hpp"     // socp_amd/csrc: the persistent worker pool the solver library uses too
 
 struct shooting::data_struct {
     // node tables: desired / current (continuation-blended) / last converged (shooting.cpp:22-27)
@@ -36,6 +40,7 @@ struct shooting::data_struct {
     bool dedup = true;
     socp_ctx *ctx = nullptr;      // the model's device context, valid during a solve
     long long hostTrajectories = 0;   // segments integrated on the host (models without device dynamics)
+    std::unique_ptr<socp::Pool> pool;  // numThread > 1 on the host path: segment workers, started once (not per call)
 };
 
 namespace {
@@ -49,6 +54,26 @@ void check_counts(int numMulti, int numThread)
     if (numMulti < 1) die("ERROR : numMulti should be superior or equal to 1");
     if (numThread < 1) die("ERROR : numThread should be superior or equal to 1");
 }
+// free-time rows of the host residual / Jacobian (models without device dynamics)
+struct HostLayout {
+    std::vector<int> free_row;     // residual row (= column of the time unknown) of node k's free-time equation, -1: none
+    bool ok = false;
+};
+HostLayout host_layout(int M, int s, std::vector<int> const &mode_t, int numParam)
+{
+    // extra rows in the reference's nbrParam order (shooting.cpp:947-986): the boundary nodes take one whenever their time mode
+    // is not FIXED (the predicate that also selects the H variants), interior nodes when FREE
+    HostLayout L;
+    L.free_row.assign(M + 1, -1);
+    int row_next = s * M;
+    for (int k = 0; k <= M; k++) {
+        const bool boundary_node = (k == 0 || k == M);
+        if (boundary_node ? mode_t[k] != model::FIXED : mode_t[k] == model::FREE) L.free_row[k] = row_next++;
+    }
+    L.ok = row_next == numParam;
+    return L;
+}
+
 void device_check(int rc, socp_ctx *ctx, const char *where)
 {
     if (rc != SOCP_OK) throw std::runtime_error(std::string(where) + ": " + socp_last_error(ctx));
@@ -439,12 +464,22 @@ int shooting::SolveShootingFunction(int const &numParam, std::vector<real> &para
     if (myModel.DeviceModelId() == 0) {
         // A user class with the reference's host virtuals only: the reference's own scheme -- hybrd with n sequential
         // residual callbacks per forward-difference Jacobian (shooting.cpp:801-827), every trajectory on the host.
-        if (myModel.modelOrder != 0)
-            throw std::runtime_error("shooting: modelOrder 1 (variational Jacobian, hybrj) needs a model with device dynamics");
         data->ctx = nullptr;
-        data->info = hybrd(StaticHostShootingFunction, (void *)this, n, param.data(), fvec.data(), data->xtol, data->maxfev,
-                           n - 1, n - 1, data->epsfcn, xscal.data(), data->scalingMode, data->factor, data->nprint, &data->nfev,
-                           fjac.data(), n, r.data(), (int)r.size(), qtf.data(), wa1.data(), wa2.data(), wa3.data(), wa4.data());
+        if (!host_layout(data->numMulti, 2 * data->dim, data->mode_t, n).ok) {
+            std::cerr << std::endl << "ERROR : the first and the last time must be FIXED or FREE" << std::endl;
+            return data->info = 0;                     // MINPACK's "improper input parameters"; the reference never throws here
+        }
+        if (myModel.modelOrder == 0) {
+            data->info = hybrd(StaticHostShootingFunction, (void *)this, n, param.data(), fvec.data(), data->xtol, data->maxfev,
+                               n - 1, n - 1, data->epsfcn, xscal.data(), data->scalingMode, data->factor, data->nprint, &data->nfev,
+                               fjac.data(), n, r.data(), (int)r.size(), qtf.data(), wa1.data(), wa2.data(), wa3.data(), wa4.data());
+        } else {
+            // modelOrder 1: the class integrates its variational equations in Model(t, X, 1) (shooting.cpp:828-852)
+            data->info = hybrj(StaticHostShootingFunctionJacobian, (void *)this, n, param.data(), fvec.data(), fjac.data(), n,
+                               data->xtol, data->maxfev, xscal.data(), data->scalingMode, data->factor, data->nprint,
+                               &data->nfev, &data->njev, r.data(), (int)r.size(), qtf.data(),
+                               wa1.data(), wa2.data(), wa3.data(), wa4.data());
+        }
         return data->info;
     }
     data->ctx = myModel.DeviceContext();           // re-packs parameters / step number (continuation mutates them)
@@ -465,16 +500,38 @@ int shooting::SolveShootingFunction(int const &numParam, std::vector<real> &para
 }
 
 // ---- models without device dynamics ------------------------------------------------------------------------------
-// shooting.cpp:918-993 with the rows of SURVEY Appendix B: node k's free-time equation sits at 2 d M + (number of FREE times
-// before node k); segment i ends at node i + 1, whose continuity rows are [2d(i+1), 2d(i+2)).
+// shooting.cpp:918-993 with the rows of SURVEY Appendix B: node k's free-time equation sits at 2 d M + (number of free-time
+// rows before node k); segment i ends at node i + 1, whose continuity rows are [2d(i+1), 2d(i+2)).  Segments only share
+// read-only inputs (param, the timeline) and write disjoint rows, so with numThread > 1 they are dealt out in the reference's
+// contiguous blocks (shooting.cpp:1223-1231) to a pool of workers that lives as long as the shooting object -- the
+// reference creates and joins numThread std::threads on every call (shooting.cpp:1152-1157).  Like there, the workers call
+// ComputeTraj on ONE model object concurrently: the class must be re-entrant.
+// the segments of one residual / Jacobian evaluation, serial or over the pool
+void shooting::HostForEachSegment(std::function<void(int)> const &segment) const
+{
+    const int M = data->numMulti, T = std::min(data->numThread, M);
+    if (T <= 1) { for (int i = 0; i < M; i++) segment(i); return; }
+    if (!data->pool || data->pool->size() != T) data->pool.reset(new socp::Pool(T));
+    const int base = M / T, rem = M % T;
+    data->pool->run(T, [&](int t) {
+        const int count = base + (t < rem ? 1 : 0), start = t * base + std::min(t, rem);     // shooting.cpp:1223-1231
+        for (int i = start; i < start + count; i++) segment(i);
+    });
+}
+
 void shooting::HostShootingFunction(std::vector<real> const &param, std::vector<real> &fvec) const
 {
     const int M = data->numMulti, d = data->dim, s = 2 * d;
     std::vector<real> timeLine(M + 1);
     ComputeTimeLine(param, timeLine);
-    std::vector<int> free_row(M + 1, -1);
-    for (int k = 0, row = s * M; k <= M; k++)
-        if (data->mode_t[k] == model::FREE) free_row[k] = row++;
+    const HostLayout L = host_layout(M, s, data->mode_t, data->numParam);
+    if (!L.ok) {
+        // a boundary time that is neither FIXED nor FREE: the reference would write past its rows here.  No solver path throws
+        // (SolveShootingFunction refuses such a layout with info = 0 before the first callback); a direct caller gets NaN rows.
+        std::fill(fvec.begin(), fvec.end(), std::nan(""));
+        return;
+    }
+    const std::vector<int> &free_row = L.free_row;
 
     auto boundary = [&](int node, real t, model::mstate const &Xt, int first_row) {
         // Initial[H]Function at node 0, Final[H]Function at node M (model.hpp:90-290); the H variants add the free-time row
@@ -491,13 +548,12 @@ void shooting::HostShootingFunction(std::vector<real> const &param, std::vector<
         if (with_h) fvec[free_row[node]] = rows[d];
     };
 
-    model::mstate Xstart = data->X[0];
-    Xstart.resize(s);
-    for (int k = 0; k < s; k++) Xstart[k] = param[k];
-    for (int i = 0; i < M; i++) {
+    HostForEachSegment([&](int i) {
         const real ta = timeLine[i], tb = timeLine[i + 1];
+        model::mstate Xstart = data->X[0];
+        Xstart.resize(s);
+        for (int k = 0; k < s; k++) Xstart[k] = param[s * i + k];
         const model::mstate Xend = Move(ta, Xstart, tb, 0);
-        data->hostTrajectories++;
         if (i == 0) boundary(0, ta, Xstart, 0);
         if (i < M - 1) {
             model::mstate Xnext(s);
@@ -522,9 +578,113 @@ void shooting::HostShootingFunction(std::vector<real> const &param, std::vector<
                     fvec[row + d] = Xend[j + d] - Xnext[j + d];
                 }
             }
-            Xstart = Xnext;
         } else {
             boundary(M, tb, Xend, d);
+        }
+    });
+    data->hostTrajectories += M;
+}
+
+// The analytic shooting Jacobian of a model WITHOUT device dynamics whose Model(t, X, 1) integrates the variational equations
+// (modelOrder 1: shooting.cpp:996-1130 assembled from the Jacobian forms of the model's virtuals, model.hpp:104-120,149-183,
+// 305-326, and of MultipleShootingFunction, shooting.cpp:1511-1576).  fjac: n x n, COLUMN-major as hybrj wants it (the
+// reference fills a row-major copy and transposes, :889-893).  Kept as upstream: a segment's start time does not enter, and
+// the time term of a FREE interior node is first written one column beyond its block (:1070) before it lands in its own.
+void shooting::HostShootingFunctionJacobian(std::vector<real> const &param, std::vector<real> &fjac) const
+{
+    const int M = data->numMulti, d = data->dim, s = 2 * d, n = data->numParam, w = s + 1, wide = 2 * s + 1;
+    std::fill(fjac.begin(), fjac.end(), 0.0);
+    std::vector<real> timeLine(M + 1);
+    ComputeTimeLine(param, timeLine);
+    const HostLayout L = host_layout(M, s, data->mode_t, n);
+    if (!L.ok) { std::fill(fjac.begin(), fjac.end(), std::nan("")); return; }
+    const std::vector<int> &free_row = L.free_row;
+    auto J = [&](int row, int col) -> real & { return fjac[(size_t)row + (size_t)n * col]; };
+    // [X ; identity]: the augmented state a segment starts from (shooting.cpp:1003-1005, 1062-1064)
+    auto augmented = [&](int node) {
+        model::mstate Xa((size_t)w * s, 0.0);
+        for (int k = 0; k < s; k++) { Xa[k] = param[s * node + k]; Xa[(size_t)s * (k + 1) + k] = 1; }
+        return Xa;
+    };
+    // rows of a boundary block (value rows, then the H row of a free boundary time) against the unknowns of node `node`
+    auto boundary = [&](bool initial, real t, model::mstate const &Xt, model::mstate const &Xother, int first_row, int node) {
+        const int bnode = initial ? 0 : M;
+        const bool with_h = data->mode_t[bnode] != model::FIXED;
+        const int width = with_h ? w : s;
+        std::vector<real> blk((size_t)(d + (with_h ? 1 : 0)) * width, 0.0);
+        if (initial) {
+            if (with_h) myModel.InitialHFunction(t, Xt, Xother, data->mode_X[0], blk, 1);
+            else myModel.InitialFunction(t, Xt, Xother, data->mode_X[0], blk, 1);
+        } else {
+            if (with_h) myModel.FinalHFunction(t, Xt, Xother, data->mode_X[M], blk, 1);
+            else myModel.FinalFunction(t, Xt, Xother, data->mode_X[M], blk, 1);
+        }
+        for (int k = 0; k < d; k++)
+            for (int j = 0; j < s; j++) J(first_row + k, s * node + j) = blk[(size_t)width * k + j];
+        if (with_h) {
+            const int fr = free_row[bnode];
+            for (int k = 0; k < d; k++) J(first_row + k, fr) = blk[(size_t)w * k + s];
+            for (int j = 0; j < s; j++) J(fr, s * node + j) = blk[(size_t)w * d + j];
+            J(fr, fr) = blk[(size_t)w * d + s];
+        }
+    };
+
+    HostForEachSegment([&](int i) {
+        const real ta = timeLine[i], tb = timeLine[i + 1];
+        const model::mstate Xa = augmented(i);
+        const model::mstate Xend = Move(ta, Xa, tb, 1);
+        if (i == 0) boundary(true, ta, Xa, data->mode_t[0] == model::FIXED ? Xa : data->X[0], 0, 0);
+        if (i < M - 1) {
+            const int index = s * (i + 1), tmode = data->mode_t[i + 1];
+            const model::mstate Xp = augmented(i + 1);
+            std::vector<real> ms((size_t)s * wide, 0.0);
+            HostMultipleShootingJacobian(tb, Xend, Xp, data->X[i + 1], data->mode_X[i + 1], tmode, ms);
+            const int cols = tmode == model::FREE ? wide : 2 * s;
+            for (int k = 0; k < s; k++)
+                for (int j = 0; j < cols; j++) J(index + k, index - s + j) = ms[(size_t)wide * k + j];
+            if (tmode == model::FREE) {
+                const int fr = free_row[i + 1];
+                for (int k = 0; k < s; k++) J(index + k, fr) = ms[(size_t)wide * k + 2 * s];
+                const model::mstate sw = myModel.SwitchingTimesFunction(tb, Xend, Xp, 1);
+                for (int j = 0; j < 2 * s; j++) J(fr, index - s + j) = sw[j];
+                J(fr, fr) = sw[2 * s];
+            }
+        } else {
+            boundary(false, tb, Xend, data->X[M], d, i);
+        }
+    });
+    data->hostTrajectories += M;
+}
+
+// shooting::MultipleShootingFunction, Jacobian form (shooting.cpp:1524-1555): rows of stride 4d + 1 = [d/dX(t-) | d/dX+ | d/dt]
+void shooting::HostMultipleShootingJacobian(real const &t, model::mstate const &X, model::mstate const &Xp, model::mstate const &Xd,
+                                            std::vector<int> const &mode_X, int mode_t, std::vector<real> &rows) const
+{
+    const int d = data->dim, s = 2 * d, wide = 2 * s + 1;
+    model::mstate fxt, fxp;
+    if (mode_t == model::FREE) {
+        fxt = myModel.Model(t, model::mstate(X.begin(), X.begin() + s), 0);
+        fxp = myModel.Model(t, model::mstate(Xp.begin(), Xp.begin() + s), 0);
+    }
+    for (int j = 0; j < d; j++) {
+        real *rs = &rows[(size_t)wide * j], *rc = &rows[(size_t)wide * (j + d)];     // state row, costate (or second) row
+        switch (mode_X[j]) {
+        case model::FIXED:                       // X_j(t-) = Xd_j and X+_j = Xd_j: both sides pinned
+            for (int i = 0; i < s; i++) { rs[i] = X[(size_t)s * (j + 1) + i]; rc[s + i] = Xp[(size_t)s * (j + 1) + i]; }
+            if (mode_t == model::FREE) { rs[2 * s] = fxt[j]; rc[2 * s] = fxp[j]; }
+            break;
+        case model::FREE: {
+            model::mstate all(rows.begin(), rows.end());
+            myModel.SwitchingStateFunction(t, j, X, Xp, Xd, all, 1);
+            std::copy(all.begin(), all.end(), rows.begin());
+            break;
+        }
+        default:                                 // CONTINUOUS: state and costate jumps vanish
+            for (int i = 0; i < s; i++) {
+                rs[i] = X[(size_t)s * (j + 1) + i];          rs[s + i] = -Xp[(size_t)s * (j + 1) + i];
+                rc[i] = X[(size_t)s * (j + d + 1) + i];      rc[s + i] = -Xp[(size_t)s * (j + d + 1) + i];
+            }
+            if (mode_t == model::FREE) { rs[2 * s] = fxt[j] - fxp[j]; rc[2 * s] = fxt[j + d] - fxp[j + d]; }
         }
     }
 }
@@ -554,6 +714,24 @@ int shooting::StaticHostShootingFunction(void *userdata, int n, const real *para
     std::vector<real> z(param, param + n), f(n, 0.0);
     self->HostShootingFunction(z, f);
     std::copy(f.begin(), f.end(), fvec);
+    return self->data->stopFlag;
+}
+
+// shooting.cpp:877-915 for a model without device dynamics: iflag 1 -> residual, 2 -> analytic Jacobian
+int shooting::StaticHostShootingFunctionJacobian(void *userdata, int n, const real *param, real *fvec, real *fjac, int ldfjac, int iflag)
+{
+    const shooting *self = static_cast<const shooting *>(userdata);
+    std::vector<real> z(param, param + n);
+    if (iflag == 1) {
+        std::vector<real> f(n, 0.0);
+        self->HostShootingFunction(z, f);
+        std::copy(f.begin(), f.end(), fvec);
+    } else {
+        if (ldfjac != n) return -2;
+        std::vector<real> jac((size_t)n * n);
+        self->HostShootingFunctionJacobian(z, jac);
+        std::copy(jac.begin(), jac.end(), fjac);
+    }
     return self->data->stopFlag;
 }
 

@@ -10,6 +10,7 @@
 #ifndef SOCP_AMD_SHOOTING_HPP_
 #define SOCP_AMD_SHOOTING_HPP_
 
+#include <functional>
 #include <iostream>
 #include <string>
 #include <unordered_map>
@@ -21,9 +22,9 @@
 class shooting
 {
 public:
-    // numMulti >= 1 shooting segments; numThread >= 1 is accepted for compatibility (the reference
-    // splits segments over that many std::threads, shooting.cpp:1142-1157; here every segment of
-    // every residual row is one GPU trajectory, whatever numThread says)
+    // numMulti >= 1 shooting segments; numThread >= 1: the reference splits the segments of a residual over that many
+    // std::threads (shooting.cpp:1142-1157).  For a model with device dynamics every segment of every residual row is one GPU
+    // trajectory whatever numThread says; for a class without, numThread segment workers run on the host (a persistent pool)
     shooting(model &model, int numMulti = int(1), int numThread = int(1));
     ~shooting();
 
@@ -91,6 +92,14 @@ private:
     // (ComputeTraj, Initial[H]Function, Final[H]Function, SwitchingTimesFunction), shooting.cpp:918-993, 1511-1576
     void HostShootingFunction(std::vector<real> const &param, std::vector<real> &fvec) const;
     static int StaticHostShootingFunction(void *userdata, int n, const real *param, real *fvec, int iflag);
+    // the same for modelOrder == 1: analytic Jacobian from the class's own variational equations, solved with hybrj
+    // (shooting.cpp:828-852, 877-915, 996-1130)
+    void HostShootingFunctionJacobian(std::vector<real> const &param, std::vector<real> &fjac) const;
+    void HostMultipleShootingJacobian(real const &t, model::mstate const &X, model::mstate const &Xp, model::mstate const &Xd,
+                                      std::vector<int> const &mode_X, int mode_t, std::vector<real> &rows) const;
+    static int StaticHostShootingFunctionJacobian(void *userdata, int n, const real *param, real *fvec, real *fjac, int ldfjac, int iflag);
+    // segments of one host evaluation: serial, or numThread contiguous blocks (shooting.cpp:1223-1231) over a persistent pool
+    void HostForEachSegment(std::function<void(int)> const &segment) const;
     static int StaticShootingFunction(void *userdata, int n, const real *param, real *fvec, int iflag);
     static int StaticShootingFdJacobian(void *userdata, int n, const real *param, const real *fvec, real epsfcn, real *fjac, int ldfjac);
     static int StaticShootingFunctionJacobian(void *userdata, int n, const real *param, real *fvec, real *fjac, int ldfjac, int iflag);

@@ -2,7 +2,7 @@
 // Model / Control / Hamiltonian (odeTools.hpp:82, model.hpp:375,384) and knows nothing of a device (DeviceModelId() == 0).
 // It must still solve through shooting::SolveOCP -- on the host, with a warning -- and the reference-style one-step calls
 // RK4(t, X, dt, function, context) (interceptor.cpp:117) and RK1/RK2/RK4(t, X, dt, modelStruct) must work.
-//   hostmodel_flow <numMulti>                    (no GPU needed)
+//   hostmodel_flow <numMulti> [numThread]        (no GPU needed; numThread > 1: segment workers on the host)
 //   hostmodel_flow residual                      prints the residual of a 3-segment layout with FREE times (H rows, switching
 //                                                row) and mixed state modes at its initial guess (shooting::ResidualAt)
 // Problem: minimum-energy rest-to-rest transfer of a 1-D double integrator, x' = v, v' = u, cost = int u^2/2 dt;
@@ -77,6 +77,7 @@ int main(int argc, char **argv)
         return 0;
     }
     const int M = std::atoi(argv[1]);
+    const int threads = argc > 2 ? std::atoi(argv[2]) : 1;
     const bool free_tf = false;
 
     // ---- one-step helpers, function-pointer form (odeTools.cpp:46-87) against the formulas written out by hand
@@ -107,7 +108,7 @@ int main(int argc, char **argv)
     const bool struct_ok = std::fabs(Y4[3] - 0.0) < 1e-14 && std::fabs(Y4[1] - 1.5) < 1e-14 && std::fabs(Y4[0] - 0.5) < 1e-14 && Y4[2] == -12.0;
 
     // ---- the whole solve through shooting, host virtuals only
-    shooting sh(m, M, 1);
+    shooting sh(m, M, threads);
     sh.SetPrecision(1e-12);
     std::vector<int> mode_Xf(2, model::FIXED);
     sh.SetMode(free_tf ? model::FREE : model::FIXED, mode_Xf);
@@ -120,8 +121,10 @@ int main(int argc, char **argv)
     sh.GetParameters(z);
     const model::mstate u0 = m.Control(0.0, model::mstate(z.begin(), z.begin() + 4));
     std::printf("{\"info\": %d, \"nfev\": %d, \"p_x\": %.17g, \"p_v\": %.17g, \"u0\": %.17g, \"n\": %d, \"steps_ok\": %d, \"struct_ok\": %d, "
-                "\"trajectories\": %lld, \"tf\": %.17g}\n",
+                "\"trajectories\": %lld, \"tf\": %.17g, \"z\": [",
                 info, sh.GetCallNumber()[0], z[2], z[3], u0[0], (int)z.size(), (int)steps_ok, (int)struct_ok, sh.GetTrajectoryCount(),
                 free_tf ? z.back() : 1.0);
+    for (size_t k = 0; k < z.size(); k++) std::printf("%s%.17g", k ? ", " : "", z[k]);
+    std::printf("]}\n");
     return (info == 1 && steps_ok && struct_ok) ? 0 : 2;
 }
