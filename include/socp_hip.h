@@ -103,6 +103,10 @@ int socp_ctx_dims(const socp_ctx *ctx, int *dim, int *state_len, int *state_len_
 int socp_ctx_control_dim(const socp_ctx *ctx);
 int socp_ctx_device(const socp_ctx *ctx);            /* HIP device index the context lives on (< 0: error) */
 int socp_ctx_model_id(const socp_ctx *ctx);          /* SOCP_MODEL_* / plugin id the context was created with */
+/* 1 when the model integrates its variational equations on the device (modelOrder 1: is_jac = 1 trajectories,
+ * socp_var_jacobian, hybrj chains) -- the in-tree double integrator, or a plugin with the aug_rhs / dhamiltonian trait
+ * (socp_amd/csrc/plugin_impl.hpp); 0 otherwise (model.hpp:104-120,149-183 need Model(t, X, 1) and Hamiltonian(t, X, 1)) */
+int socp_ctx_has_variational(const socp_ctx *ctx);
 
 /* counters since creation: trajectories integrated, kernel launches */
 int socp_ctx_counters(const socp_ctx *ctx, long long *trajectories, long long *launches);
@@ -196,7 +200,7 @@ int socp_fd_diff_dev(socp_ctx *ctx, int np, const double *d_Z, double epsfcn, co
                      double *d_Fjac);
 
 /* replaces: shooting::ShootingFunctionJacobian (shooting.cpp:996-1130), variational Jacobian
- * for models with modelOrder == 1; fjac column-major as handed to hybrj (shooting.cpp:889-893).
+ * for models with modelOrder == 1 (socp_ctx_has_variational); fjac column-major as handed to hybrj (shooting.cpp:889-893).
  * The variational state is integrated with fixed-step RK4 only: SOCP_ERR_UNSUPPORTED under SOCP_INT_DOPRI5. */
 int socp_var_jacobian(socp_ctx *ctx, const double *z, double *fjac);
 /* The same for `np` unknown vectors of one problem structure, device pointers: Z[np][n] -> Fjac[np][n*n]; one wavefront per

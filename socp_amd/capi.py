@@ -92,6 +92,7 @@ def lib():
         L.socp_ctx_device.argtypes = [_vp]
         L.socp_ctx_num_params.argtypes = [_vp]
         L.socp_ctx_model_id.argtypes = [_vp]
+        L.socp_ctx_has_variational.argtypes = [_vp]
         L.socp_ctx_counters.argtypes = [_vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
         L.socp_integrate_batch.argtypes = [_vp, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_int]
         L.socp_integrate_batch_dev.argtypes = [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int]
@@ -191,6 +192,9 @@ class Context:
             raise SocpError(rc, self.L.socp_last_error(self.h).decode())
 
     # -- configuration
+    def has_variational(self):
+        return self.L.socp_ctx_has_variational(self.h) == 1
+
     def set_params(self, params):
         p = _f64(params)
         self._chk(self.L.socp_ctx_set_params(self.h, _d(p), len(p)))

@@ -133,8 +133,8 @@ extern "C" int socp_chains_solve_ex(socp_ctx *ctx, int P, const socp_chain_optio
     // continuationStepMin: a negative or NaN value can never end the bisection of a chain whose solves keep failing (0 can: the
     // halving stops moving b after ~55 steps, see solve_finished)
     if (kind != SOCP_CHAIN_PLAIN && !(opt->step_min >= 0)) return SOCP_ERR_ARG;
-    // the variational Jacobian exists for models with variational equations only (modelOrder 1: the double integrator)
-    if (opt->analytic_jac && socp_ctx_model_id(ctx) != SOCP_MODEL_DOUBLE_INTEGRATOR) return SOCP_ERR_UNSUPPORTED;
+    // the variational Jacobian exists for models with variational equations only (modelOrder 1: the double integrator, plugins with the trait)
+    if (opt->analytic_jac && socp_ctx_has_variational(ctx) != 1) return SOCP_ERR_UNSUPPORTED;
     if (P == 0) return SOCP_OK;
 
     // every allocation, copy and stream below lives on the context's device, whatever the calling thread's current device

@@ -146,6 +146,12 @@ hipError_t run_fdrows(socp_ctx *c, int np, const double *z, double eps, double *
                        : fdrows_exact(c->model_id, c->stream, c->P, c->pb, np, z, eps, rows);
 }
 
+// variational equations on the device: the in-tree double integrator, or a table-driven model whose table carries them
+bool has_var(const socp_ctx *c)
+{
+    return c->vt ? (c->vt->var_traj && c->vt->var_jacobian && c->vt->var_eval) : c->model_id == SOCP_MODEL_DOUBLE_INTEGRATOR;
+}
+
 double fd_eps(double epsfcn) { return std::sqrt(epsfcn > DBL_EPSILON ? epsfcn : DBL_EPSILON); }
 
 }  // namespace
@@ -326,6 +332,7 @@ int socp_ctx_dims(const socp_ctx *c, int *dim, int *state_len, int *state_len_ja
 int socp_ctx_control_dim(const socp_ctx *c) { return c ? c->nu : SOCP_ERR_ARG; }
 int socp_ctx_device(const socp_ctx *c) { return c ? c->device : SOCP_ERR_ARG; }
 int socp_ctx_model_id(const socp_ctx *c) { return c ? c->model_id : SOCP_ERR_ARG; }
+int socp_ctx_has_variational(const socp_ctx *c) { return c ? (has_var(c) ? 1 : 0) : SOCP_ERR_ARG; }
 
 int socp_ctx_counters(const socp_ctx *c, long long *trajectories, long long *launches)
 {
@@ -347,11 +354,12 @@ int socp_integrate_batch_dev(socp_ctx *c, int B, const double *d_t0, const doubl
         return fail(c, SOCP_ERR_UNSUPPORTED, "integrate_batch: the variational state is integrated with fixed-step RK4 only");
     if (is_jac) {
         // variational state: one wavefront per trajectory (doubleIntegrator; goddard has modelOrder 0 only)
-        if (c->model_id != SOCP_MODEL_DOUBLE_INTEGRATOR)
+        if (!has_var(c))
             return fail(c, SOCP_ERR_UNSUPPORTED, "integrate_batch: this model has no variational equations (modelOrder 0)");
         if (d_Xf == d_X0) return fail(c, SOCP_ERR_ARG, "integrate_batch: is_jac=1 needs distinct input and output");
         c->n_traj += B; c->n_launch += 1;
-        HIP_TRY(c, var_traj(c->model_id, c->stream, c->P, B, d_t0, d_tf, d_X0, d_Xf));
+        HIP_TRY(c, c->vt ? c->vt->var_traj(c->stream, c->P, B, d_t0, d_tf, d_X0, d_Xf)
+                         : var_traj(c->model_id, c->stream, c->P, B, d_t0, d_tf, d_X0, d_Xf));
         return SOCP_OK;
     }
     HIP_TRY(c, run_traj(c, B, d_t0, d_tf, d_sw, d_X0, d_Xf));
@@ -435,7 +443,7 @@ int socp_eval_batch(socp_ctx *c, int what, int B, const double *t, const double 
     if (what < SOCP_EVAL_RHS || what > SOCP_EVAL_HAMILTONIAN) return fail(c, SOCP_ERR_ARG, "eval_batch: unknown quantity");
     const int L = (c->S + 1) * c->S;
     const bool var = is_jac && what != SOCP_EVAL_CONTROL;
-    if (var && c->model_id != SOCP_MODEL_DOUBLE_INTEGRATOR)
+    if (var && !has_var(c))
         return fail(c, SOCP_ERR_UNSUPPORTED, "eval_batch: this model has no variational equations (modelOrder 0)");
     if (var && what == SOCP_EVAL_RHS && len != L) return fail(c, SOCP_ERR_ARG, "eval_batch: augmented state length must be (2*dim+1)*2*dim");
     if (!(var && what == SOCP_EVAL_RHS) && len < c->S) return fail(c, SOCP_ERR_ARG, "eval_batch: state length must be at least 2*dim");
@@ -460,7 +468,8 @@ int socp_eval_batch(socp_ctx *c, int what, int B, const double *t, const double 
     }
     c->n_launch += 1;
     hipError_t e = var
-        ? var_eval(c->model_id, c->stream, c->P, what == SOCP_EVAL_RHS ? 0 : 1, B, c->s_in.as<double>(), len, c->s_out.as<double>())
+        ? (c->vt ? c->vt->var_eval(c->stream, c->P, what == SOCP_EVAL_RHS ? 0 : 1, B, c->s_t0.as<double>(), c->s_in.as<double>(), len, c->s_out.as<double>())
+                 : var_eval(c->model_id, c->stream, c->P, what == SOCP_EVAL_RHS ? 0 : 1, B, c->s_t0.as<double>(), c->s_in.as<double>(), len, c->s_out.as<double>()))
         : c->vt
         ? table_of(c)->eval(c->stream, c->P, what, B, c->s_t0.as<double>(), dsw, c->s_in.as<double>(), c->s_out.as<double>())
         : use_fast(c)
@@ -789,7 +798,7 @@ int socp_var_jacobian_multi_dev(socp_ctx *c, int np, const double *d_Z, double *
     if (!c) return SOCP_ERR_ARG;
     if (!c->has_problem) return fail(c, SOCP_ERR_ARG, "var_jacobian: no problem set");
     if (np < 0 || (np > 0 && (!d_Z || !d_Fjac))) return fail(c, SOCP_ERR_ARG, "var_jacobian: null argument");
-    if (c->model_id != SOCP_MODEL_DOUBLE_INTEGRATOR)
+    if (!has_var(c))
         return fail(c, SOCP_ERR_UNSUPPORTED, "var_jacobian: this model has no variational equations (modelOrder 0)");
     if (c->P.integrator != SOCP_INT_RK4)
         return fail(c, SOCP_ERR_UNSUPPORTED, "var_jacobian: the variational state is integrated with fixed-step RK4 only");
@@ -799,7 +808,8 @@ int socp_var_jacobian_multi_dev(socp_ctx *c, int np, const double *d_Z, double *
     HIP_TRY(c, c->s_var.reserve(sizeof(double) * (2 * B * L + 2 * B)));
     double *Xaug = c->s_var.as<double>(), *Xtf = Xaug + B * L, *t0 = Xtf + B * L, *tf = t0 + B;
     c->n_traj += (long long)B; c->n_launch += 3;
-    HIP_TRY(c, var_jacobian(c->model_id, c->stream, c->P, c->pb, np, d_Z, Xaug, Xtf, t0, tf, d_Fjac));
+    HIP_TRY(c, c->vt ? c->vt->var_jacobian(c->stream, c->P, c->pb, np, d_Z, Xaug, Xtf, t0, tf, d_Fjac)
+                     : var_jacobian(c->model_id, c->stream, c->P, c->pb, np, d_Z, Xaug, Xtf, t0, tf, d_Fjac));
     return SOCP_OK;
 }
 

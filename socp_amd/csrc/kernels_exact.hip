@@ -12,40 +12,29 @@
 #include "launch_impl.hpp"
 
 // ---- variational path (compiled here: no contraction) -------------------------------------------
-#include "variational.hpp"
+#include "models_variational.hpp"
 
 namespace socp {
 
 hipError_t var_traj(int model_id, hipStream_t st, const ModelParams &P, int B, const double *t0, const double *tf,
                     const double *X0, double *Xf)
 {
-    if (model_id != 2) return hipErrorInvalidValue;
-    if (B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(traj_var_wave_kernel<DIntVar>, dim3(B), dim3(64), 0, st, P, t0, tf, X0, Xf, (const double *)nullptr, 0, 1);
-    return hipGetLastError();
+    if (model_id != 2) return hipErrorInvalidValue;      // in-tree: the double integrator; table-driven models bring their own (launch.hpp)
+    return varimpl::traj<DIntVar>(st, P, B, t0, tf, X0, Xf);
 }
 
 hipError_t var_jacobian(int model_id, hipStream_t st, const ModelParams &P, const ProblemDev &pb, int np, const double *z,
                         double *Xaug, double *Xtf, double *t0, double *tf, double *fjac)
 {
     if (model_id != 2) return hipErrorInvalidValue;
-    if (np <= 0) return hipSuccess;
-    const unsigned B = (unsigned)((long)np * pb.M);                 // one wavefront per (problem, segment)
-    hipLaunchKernelGGL(var_prepare_kernel<DIntVar>, dim3(B), dim3(64), 0, st, pb, z, Xaug, t0, tf);
-    hipLaunchKernelGGL(traj_var_wave_kernel<DIntVar>, dim3(B), dim3(64), 0, st, P, t0, tf, Xaug, Xtf, pb.pp_params, pb.pp_stride, pb.M);
-    hipError_t e = hipMemsetAsync(fjac, 0, sizeof(double) * (size_t)np * pb.n * pb.n, st);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(var_assemble_kernel<DIntVar>, dim3((B + 63) / 64), dim3(64), 0, st, P, pb, np, z, Xtf, fjac);
-    return hipGetLastError();
+    return varimpl::jacobian<DIntVar>(st, P, pb, np, z, Xaug, Xtf, t0, tf, fjac);
 }
 
-hipError_t var_eval(int model_id, hipStream_t st, const ModelParams &P, int what, int B, const double *X, int len,
+hipError_t var_eval(int model_id, hipStream_t st, const ModelParams &P, int what, int B, const double *t, const double *X, int len,
                     double *out)
 {
     if (model_id != 2) return hipErrorInvalidValue;
-    if (B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(var_eval_kernel<DIntVar>, dim3((B + 63) / 64), dim3(64), 0, st, P, what, B, X, len, out);
-    return hipGetLastError();
+    return varimpl::eval<DIntVar>(st, P, what, B, t, X, len, out);
 }
 
 }  // namespace socp

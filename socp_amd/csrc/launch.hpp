@@ -56,7 +56,7 @@ inline int rows_per_block(int M, int n)
 
 // Launch table of an out-of-tree model (include/socp_plugin.h, plugin_impl.hpp): what the C-ABI layer calls
 // instead of the built-in flavour launchers when a context is created with a registered model id.
-constexpr int kPluginAbi = 3;      // 3: ProblemDev carries per-problem blocks
+constexpr int kPluginAbi = 4;      // 3: ProblemDev carries per-problem blocks; 4: optional variational launchers
 struct ModelLaunchers {
     int abi, dim, control_dim, nparams, default_step_nbr;
     double default_params[kMaxParams];
@@ -66,6 +66,10 @@ struct ModelLaunchers {
     hipError_t (*fdrows)(hipStream_t, const ModelParams &, const ProblemDev &, int, const double *, double, double *);
     hipError_t (*dense)(hipStream_t, const ModelParams &, double, double, double, double, const double *, double *, double *, int, int *, double *);
     hipError_t (*eval)(hipStream_t, const ModelParams &, int, int, const double *, const double *, const double *, double *);
+    // variational equations (modelOrder 1, hybrj path): all three null when the model has none
+    hipError_t (*var_traj)(hipStream_t, const ModelParams &, int, const double *, const double *, const double *, double *);
+    hipError_t (*var_jacobian)(hipStream_t, const ModelParams &, const ProblemDev &, int, const double *, double *, double *, double *, double *, double *);
+    hipError_t (*var_eval)(hipStream_t, const ModelParams &, int, int, const double *, const double *, int, double *);
 };
 
 SOCP_DECLARE_LAUNCHERS(exact)
@@ -75,7 +79,7 @@ hipError_t var_traj(int model_id, hipStream_t st, const ModelParams &P, int B, c
                     const double *X0, double *Xf);
 hipError_t var_jacobian(int model_id, hipStream_t st, const ModelParams &P, const ProblemDev &pb, int np, const double *z,
                         double *Xaug, double *Xtf, double *t0, double *tf, double *fjac);
-hipError_t var_eval(int model_id, hipStream_t st, const ModelParams &P, int what, int B, const double *X, int len,
+hipError_t var_eval(int model_id, hipStream_t st, const ModelParams &P, int what, int B, const double *t, const double *X, int len,
                     double *out);
 hipError_t fd_diff(hipStream_t st, int n, int np, const double *z, double eps, const double *rows, double *fjac);
 

@@ -15,6 +15,11 @@
 //                                            const double (&X)[S]);                     // model::Hamiltonian
 //       __device__ static double switching_fn(const socp::ModelParams &P, double sw0, double sw1, double t,
 //                                             const double (&X)[S], const double (&Xp)[S]);  // SwitchingTimesFunction
+//       // OPTIONAL -- variational equations, for classes with modelOrder = 1 (hybrj; model.hpp:104-120,149-183):
+//       __device__ static double aug_rhs(const socp::ModelParams &P, double t, int e, const double *Y);
+//                 // element e of Model(t, Y, isJac = 1), Y = [X(S) ; R(S x S)], R[k][i] at Y[S (k+1) + i]  
+//       __device__ static void dhamiltonian(const socp::ModelParams &P, double t, const double *X, double (&dH)[S + 1]);
+//                 // Hamiltonian(t, X, isJac = 1): dH/dX (S entries), then dH/dt
 //   };
 //   SOCP_DEFINE_MODEL_PLUGIN(1001, MyModel, 3 /*nparams*/, 30 /*stepNbr*/, {1.0, 2.0, 3.0})
 //
@@ -26,6 +31,7 @@
 #pragma once
 #include "integrator.hpp"
 #include "launch.hpp"
+#include "variational.hpp"
 #include "../../include/socp_plugin.h"
 
 namespace socp {
@@ -108,6 +114,13 @@ hipError_t eval(hipStream_t st, const ModelParams &P, int what, int B, const dou
     return hipGetLastError();
 }
 
+// optional trait: the model integrates its variational equations (aug_rhs + dhamiltonian) -> the hybrj path works for it
+template <class M, class = void> struct has_variational : std::false_type {};
+template <class M>
+struct has_variational<M, std::void_t<decltype(M::aug_rhs(std::declval<const ModelParams &>(), 0.0, 0, (const double *)nullptr)),
+                                      decltype(M::dhamiltonian(std::declval<const ModelParams &>(), 0.0, (const double *)nullptr,
+                                                               std::declval<double (&)[M::S + 1]>()))>> : std::true_type {};
+
 template <class Mdl>
 ModelLaunchers table(int nparams, int step_nbr, std::initializer_list<double> defaults)
 {
@@ -119,6 +132,9 @@ ModelLaunchers table(int nparams, int step_nbr, std::initializer_list<double> de
     for (double v : defaults) if (i < kMaxParams) t.default_params[i++] = v;
     t.traj = &traj<Mdl>; t.residual = &residual<Mdl>; t.fdjac = &fdjac<Mdl>; t.fdrows = &fdrows<Mdl>;
     t.dense = &dense<Mdl>; t.eval = &eval<Mdl>;
+    if constexpr (has_variational<Mdl>::value) {
+        t.var_traj = &varimpl::traj<Mdl>; t.var_jacobian = &varimpl::jacobian<Mdl>; t.var_eval = &varimpl::eval<Mdl>;
+    }
     return t;
 }
 

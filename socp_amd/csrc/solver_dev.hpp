@@ -1,0 +1,572 @@
+// solver_dev.hpp -- the Powell hybrid iteration (MINPACK hybrd / hybrj as minpack.cpp states it) for MANY small problems
+// on the device: one workgroup per problem, one thread per column / row / vector element.
+//
+// Why: a lock-step sweep of thousands of n = 85 .. 253 problems is host-bound (75-90 % of the wall time in
+// host qrfac / dogleg / r1updt, and P n^2 doubles of Jacobians over PCIe per refresh).  With the state machines in HBM the
+// Jacobians never leave the device and the factor work of all problems runs at once.
+//
+// What is kept: every number is produced by the same IEEE operations in the same order as in minpack.cpp (which equals
+// SciPy's MINPACK bit for bit, tests/test_minpack.py), so a chain follows the same iterates whichever side advances it:
+//   * MINPACK's algorithms are column / row / element recurrences that never mix (qrfac: reflector j applied to column k is
+//     one dot product, one division, one axpy; qform likewise; r1updt / r1mpyq: one Givens rotation per step applied to
+//     independent elements; dogleg / prered: one serial sum per row).  A thread owns a column (row, element) and runs ITS
+//     recurrence in the serial order; only genuinely serial chains (enorm, back substitution, the rotation scalars) are
+//     left serial -- they are computed redundantly by every thread from broadcast loads, which costs no wall time.
+//   * no FMA contraction (the translation unit is compiled -ffp-contract=off), IEEE division and square root,
+//     std::max / std::min written out as the comparisons they are (NaN behaviour included).
+//
+// The same source compiles for the host with ONE thread per problem (SOCP_SOLVER_HOST: tests/tools/solver_sim.cpp), which
+// is how the arithmetic is checked against minpack.cpp without a GPU; races cannot show there -- the -m gpu tests compare
+// the real kernels with the host solvers (tests/test_gpu_devsolver.py).
+//
+// Storage per problem (doubles): A[n][ld] ROW-major with ld >= n + 1 (thread = column => coalesced; column n carries fvec
+// through the reflectors and comes out as Q^T fvec, as colvec::factor does in minpack.cpp), r[n (n+1) / 2] = R by rows,
+// fourteen vectors of n.  After a factorisation A holds Q (row-major).
+#pragma once
+#include <cfloat>
+#include <cmath>
+
+#if defined(__HIPCC__)
+#define SOCP_HD __host__ __device__ __forceinline__
+#else
+#define SOCP_HD inline
+#endif
+
+namespace socp {
+namespace devsolver {
+
+enum Phase { PH_INIT = 0, PH_F0 = 1, PH_JAC = 2, PH_TRIAL = 3, PH_DONE = 4 };
+enum Request { RQ_DONE = 0, RQ_FVEC = 1, RQ_JAC = 2 };
+
+// configuration shared by every problem of a pool (socp_hybr_create's arguments)
+struct Config {
+    int n, ld, maxfev, mode, analytic;
+    double xtol, epsfcn, factor;
+};
+
+// per-problem iteration state (Core of minpack.cpp)
+struct State {
+    int phase, iter, ncsuc, ncfail, nslow1, nslow2, nfev, njev, info, jeval, sing;
+    int req;           // Request left pending by the last advance
+    int eval_sel;      // RQ_FVEC: 0 -> evaluate at x, result to fvec; 1 -> evaluate at wa2 (trial point), result to wa4
+    int pad;
+    double delta, xnorm, fnorm, pnorm;
+};
+
+constexpr int kVectors = 14;
+SOCP_HD long ws_doubles(int n, int ld) { return (((long)n * ld + (long)n * (n + 1) / 2 + (long)kVectors * n) + 7) / 8 * 8; }
+SOCP_HD int ld_for(int n) { return (n + 1 + 7) / 8 * 8; }
+
+// views into one problem's workspace
+struct Work {
+    double *A, *r, *x, *fvec, *diag, *qtf, *wa1, *wa2, *wa3, *wa4, *rot, *c1, *s1, *c2, *s2, *vb;
+    SOCP_HD Work(double *base, int n, int ld)
+    {
+        A = base; r = A + (long)n * ld;
+        double *v = r + (long)n * (n + 1) / 2;
+        x = v; fvec = v + n; diag = v + 2 * n; qtf = v + 3 * n; wa1 = v + 4 * n; wa2 = v + 5 * n; wa3 = v + 6 * n; wa4 = v + 7 * n;
+        rot = v + 8 * n; c1 = v + 9 * n; s1 = v + 10 * n; c2 = v + 11 * n; s2 = v + 12 * n; vb = v + 13 * n;
+    }
+};
+
+// executors: one thread of a workgroup (device) or the whole problem on one host thread (simulation)
+#if defined(__HIPCC__)
+struct BlockExec {
+    int tid, nt;
+    __device__ BlockExec() : tid((int)threadIdx.x), nt((int)blockDim.x) {}
+    __device__ void sync() const { __syncthreads(); }
+};
+#endif
+struct SerialExec {
+    int tid = 0, nt = 1;
+    SOCP_HD void sync() const {}
+};
+
+#define SOCP_PAR_FOR(i, lo, hi) for (int i = (lo) + ex.tid; i < (hi); i += ex.nt)
+
+constexpr double kEpsMch = DBL_EPSILON;
+constexpr double kGiant = DBL_MAX;
+
+// minpack.cpp: enorm, over x[0], x[stride], ... (n entries).  Serial by definition (three scaled accumulators).
+SOCP_HD double enorm(int n, const double *x, long stride = 1)
+{
+    const double rdwarf = 3.834e-20, rgiant = 1.304e19;
+    double s1 = 0, s2 = 0, s3 = 0, x1max = 0, x3max = 0;
+    const double agiant = rgiant / (double)n;
+    for (int i = 0; i < n; i++) {
+        const double xabs = fabs(x[(long)i * stride]);
+        if (xabs > rdwarf && xabs < agiant) {
+            s2 += xabs * xabs;
+        } else if (xabs <= rdwarf) {
+            if (xabs > x3max) {
+                const double q = x3max / xabs;
+                s3 = 1 + s3 * (q * q);
+                x3max = xabs;
+            } else if (xabs != 0) {
+                const double q = xabs / x3max;
+                s3 += q * q;
+            }
+        } else {
+            if (xabs > x1max) {
+                const double q = x1max / xabs;
+                s1 = 1 + s1 * (q * q);
+                x1max = xabs;
+            } else {
+                const double q = xabs / x1max;
+                s1 += q * q;
+            }
+        }
+    }
+    if (s1 != 0) return x1max * sqrt(s1 + (s2 / x1max) / x1max);
+    if (s2 != 0) {
+        if (s2 >= x3max) return sqrt(s2 * (1 + (x3max / s2) * (x3max * s3)));
+        return sqrt(x3max * ((s2 / x3max) + (x3max * s3)));
+    }
+    return x3max * sqrt(s3);
+}
+
+SOCP_HD double max_of(double a, double b) { return (a < b) ? b : a; }      // std::max(a, b)
+SOCP_HD double min_of(double a, double b) { return (b < a) ? b : a; }      // std::min(a, b)
+SOCP_HD long row_off(int n, int i) { return (long)i * n - (long)i * (i - 1) / 2; }   // start of row i of the packed R
+
+// One Jacobian refresh's factor work: qrfac (no pivoting) with Q^T fvec riding along as column n, R packed by rows, qform in
+// place.  In: A[i][j] = J(i, j), fvec.  Out: A = Q (row-major), r, qtf, rdiag (wa1), acnorm (wa2); returns "singular".
+template <class E>
+SOCP_HD bool factor(const E &ex, int n, int ld, Work &w)
+{
+    double *A = w.A, *rdiag = w.wa1, *acnorm = w.wa2, *v = w.vb;
+    SOCP_PAR_FOR(j, 0, n) acnorm[j] = enorm(n, A + j, ld);
+    SOCP_PAR_FOR(i, 0, n) A[(long)i * ld + n] = w.fvec[i];
+    ex.sync();
+    for (int j = 0; j < n; j++) {
+        // finish reflector j on its column (every thread computes the same norm from the same loads)
+        double ajnorm = enorm(n - j, A + (long)j * ld + j, ld);
+        if (ajnorm != 0 && A[(long)j * ld + j] < 0) ajnorm = -ajnorm;
+        ex.sync();                                           // all have read column j before it is scaled
+        if (ajnorm != 0) {
+            SOCP_PAR_FOR(i, j, n) {
+                double t = A[(long)i * ld + j] / ajnorm;
+                if (i == j) t += 1;
+                A[(long)i * ld + j] = t;
+                v[i] = t;
+            }
+        }
+        if (ex.tid == 0) rdiag[j] = -ajnorm;
+        ex.sync();
+        if (ajnorm != 0) {
+            const double piv = v[j];
+            SOCP_PAR_FOR(k, j + 1, n + 1) {                  // the later columns, and fvec's column
+                double sum = 0;
+                for (int i = j; i < n; i++) sum += v[i] * A[(long)i * ld + k];
+                const double temp = sum / piv;
+                for (int i = j; i < n; i++) A[(long)i * ld + k] -= temp * v[i];
+            }
+        }
+        ex.sync();
+    }
+    SOCP_PAR_FOR(i, 0, n) w.qtf[i] = A[(long)i * ld + n];
+    // R by rows: row i = [rdiag[i], A(i, i+1 .. n-1)]
+    for (int i = 0; i < n; i++) {
+        const long off = row_off(n, i);
+        SOCP_PAR_FOR(k, i, n) w.r[off + (k - i)] = (k == i) ? rdiag[i] : A[(long)i * ld + k];
+    }
+    bool sing = false;
+    for (int j = 0; j < n; j++) if (rdiag[j] == 0) sing = true;
+    ex.sync();
+    // qform, MINPACK's in-place order: the strict upper triangle is cleared, then for k = n-1 .. 0 column k's Householder
+    // vector moves out, the column becomes e_k and the columns j >= k go through reflector k
+    for (int i = 0; i < n; i++)
+        SOCP_PAR_FOR(j, i + 1, n) A[(long)i * ld + j] = 0;
+    ex.sync();
+    for (int k = n - 1; k >= 0; k--) {
+        SOCP_PAR_FOR(i, k, n) { v[i] = A[(long)i * ld + k]; A[(long)i * ld + k] = (i == k) ? 1.0 : 0.0; }
+        ex.sync();
+        const double piv = v[k];
+        if (piv != 0) {
+            SOCP_PAR_FOR(j, k, n) {
+                double sum = 0;
+                for (int i = k; i < n; i++) sum += A[(long)i * ld + j] * v[i];
+                const double temp = sum / piv;
+                for (int i = k; i < n; i++) A[(long)i * ld + j] -= temp * v[i];
+            }
+        }
+        ex.sync();
+    }
+    return sing;
+}
+
+// minpack.cpp: dogleg.  x = wa1, scratch = wa2, wa3.  Every thread returns with the step in w.wa1 complete (synchronised).
+template <class E>
+SOCP_HD void dogleg(const E &ex, int n, Work &w, double delta)
+{
+    const double *r = w.r, *diag = w.diag, *qtb = w.qtf;
+    double *x = w.wa1, *wa1 = w.wa2, *wa2 = w.wa3;
+    if (ex.tid == 0) {
+        // Gauss-Newton direction by back substitution: x[j] needs every later x[i], last computed first -- one serial chain
+        long jj = (long)n * (n + 1) / 2;
+        for (int k = 1; k <= n; k++) {
+            const int j = n - k;
+            jj -= k;
+            long l = jj + 1;
+            double sum = 0;
+            for (int i = j + 1; i < n; i++) { sum += r[l] * x[i]; l++; }
+            double temp = r[jj];
+            if (temp == 0) {
+                l = j;
+                for (int i = 0; i <= j; i++) { temp = max_of(temp, fabs(r[l])); l += n - i - 1; }
+                temp = kEpsMch * temp;
+                if (temp == 0) temp = kEpsMch;
+            }
+            x[j] = (qtb[j] - sum) / temp;
+        }
+    }
+    ex.sync();
+    SOCP_PAR_FOR(j, 0, n) { wa1[j] = 0; wa2[j] = diag[j] * x[j]; }
+    ex.sync();
+    const double qnorm = enorm(n, wa2);
+    ex.sync();                                               // everyone has its norm before wa2 is written again (here or by the caller)
+    if (qnorm <= delta) return;
+    // scaled gradient direction: element i collects r(j, i) qtb[j] for j = 0 .. i in that order, then is divided
+    SOCP_PAR_FOR(i, 0, n) {
+        double acc = 0;                                      // wa1[i] starts at 0
+        for (int j = 0; j <= i; j++) acc += r[row_off(n, j) + (i - j)] * qtb[j];
+        wa1[i] = acc / diag[i];
+    }
+    ex.sync();
+    const double gnorm = enorm(n, wa1);
+    double sgnorm = 0;
+    double alpha = delta / qnorm;
+    if (gnorm != 0) {
+        ex.sync();
+        SOCP_PAR_FOR(j, 0, n) wa1[j] = (wa1[j] / gnorm) / diag[j];
+        ex.sync();
+        SOCP_PAR_FOR(j, 0, n) {
+            const long off = row_off(n, j);
+            double sum = 0;
+            for (int i = j; i < n; i++) sum += r[off + (i - j)] * wa1[i];
+            wa2[j] = sum;
+        }
+        ex.sync();
+        double temp = enorm(n, wa2);
+        sgnorm = (gnorm / temp) / temp;
+        alpha = 0;
+        if (sgnorm < delta) {
+            const double bnorm = enorm(n, qtb);
+            const double dq = delta / qnorm, sd = sgnorm / delta;
+            temp = (bnorm / gnorm) * (bnorm / qnorm) * sd;
+            const double d1 = temp - dq;
+            temp = temp - dq * (sd * sd) + sqrt(d1 * d1 + (1 - dq * dq) * (1 - sd * sd));
+            alpha = (dq * (1 - sd * sd)) / temp;
+        }
+    }
+    const double temp = (1 - alpha) * min_of(sgnorm, delta);
+    SOCP_PAR_FOR(j, 0, n) x[j] = temp * wa1[j] + alpha * x[j];
+    ex.sync();
+}
+
+SOCP_HD void givens(double a, double b, double &cs, double &sn, double &tau)
+{
+    if (fabs(a) < fabs(b)) {
+        const double cotan = a / b;
+        sn = 0.5 / sqrt(0.25 + 0.25 * (cotan * cotan));
+        cs = sn * cotan;
+        tau = 1;
+        if (fabs(cs) * kGiant > 1) tau = 1 / cs;
+    } else {
+        const double tn = b / a;
+        cs = 0.5 / sqrt(0.25 + 0.25 * (tn * tn));
+        sn = cs * tn;
+        tau = sn;
+    }
+}
+
+SOCP_HD void decode_rotation(double t, double &cs, double &sn)
+{
+    if (fabs(t) > 1) { cs = 1 / t; sn = sqrt(1 - cs * cs); }
+    else { sn = t; cs = sqrt(1 - sn * sn); }
+}
+
+// minpack.cpp: r1updt on the packed R (m = n), u = wa1, v = wa2, w = wa3.  The rotation encodings MINPACK leaves in v[0..n-2]
+// go to w.rot instead (v stays read-only, so no thread can see a half-updated v); w[0..n-2] receives the second sweep's as
+// there.  A thread owns element i of w and column-position i of every row of s for the whole routine.
+template <class E>
+SOCP_HD bool r1updt(const E &ex, int n, Work &wk)
+{
+    double *s = wk.r, *w = wk.wa3, *rot = wk.rot;
+    const double *u = wk.wa1, *v = wk.wa2;
+    long jj = (long)n * (n + 1) / 2 - 1;                     // the last diagonal entry
+    if (ex.tid == (n - 1) % ex.nt) w[n - 1] = s[jj];
+    double vn = v[n - 1];
+    for (int nmj = 1; nmj <= n - 1; nmj++) {
+        const int j = n - 1 - nmj;
+        jj -= (n - j);
+        const double vj = v[j];
+        double cs = 0, sn = 0, tau = vj;
+        if (vj != 0) {
+            givens(vn, vj, cs, sn, tau);
+            vn = sn * vj + cs * vn;
+        }
+        if (ex.tid == 0) rot[j] = tau;
+        if (vj != 0) {
+            SOCP_PAR_FOR(i, j, n) {
+                const long l = jj + (i - j);
+                const double wi = (i == j) ? 0.0 : w[i];     // w[j] = 0 before the rotation reaches it
+                const double temp = cs * s[l] - sn * wi;
+                w[i] = sn * s[l] + cs * wi;
+                s[l] = temp;
+            }
+        } else if (ex.tid == j % ex.nt) {
+            w[j] = 0;
+        }
+    }
+    SOCP_PAR_FOR(i, 0, n) w[i] += vn * u[i];
+    bool sing = false;
+    for (int j = 0; j < n - 1; j++) {
+        ex.sync();                                           // s(j, j) and w[j] come from the thread that owns element j
+        const double wj = w[j], sjj = s[jj];
+        double cs = 0, sn = 0, tau = 0;
+        if (wj != 0) givens(sjj, wj, cs, sn, tau);
+        ex.sync();                                           // both read by everyone before they change
+        if (wj != 0) {
+            SOCP_PAR_FOR(i, j, n) {
+                const long l = jj + (i - j);
+                const double temp = cs * s[l] + sn * w[i];
+                const double wn = -sn * s[l] + cs * w[i];
+                s[l] = temp;
+                w[i] = (i == j) ? tau : wn;
+            }
+            if (cs * sjj + sn * wj == 0) sing = true;        // s(j, j) after the rotation, as every thread can compute it
+        } else if (sjj == 0) {
+            sing = true;
+        }
+        jj += (n - j);
+    }
+    ex.sync();
+    const double last = w[n - 1];
+    ex.sync();
+    if (ex.tid == 0) s[jj] = last;
+    if (last == 0) sing = true;
+    return sing;
+}
+
+// minpack.cpp: r1mpyq on Q (n x n, row-major here) and on qtf, with the rotations of the last r1updt
+template <class E>
+SOCP_HD void r1mpyq_all(const E &ex, int n, int ld, Work &wk)
+{
+    double *c1 = wk.c1, *s1 = wk.s1, *c2 = wk.c2, *s2 = wk.s2;
+    ex.sync();
+    SOCP_PAR_FOR(j, 0, n - 1) {
+        decode_rotation(wk.rot[j], c1[j], s1[j]);
+        decode_rotation(wk.wa3[j], c2[j], s2[j]);
+    }
+    ex.sync();
+    SOCP_PAR_FOR(i, 0, n) {                                  // a row of Q goes through all rotations on its own
+        double *a = wk.A + (long)i * ld;
+        double an = a[n - 1];
+        for (int j = n - 2; j >= 0; j--) {
+            const double aj = a[j];
+            const double temp = c1[j] * aj - s1[j] * an;
+            an = s1[j] * aj + c1[j] * an;
+            a[j] = temp;
+        }
+        for (int j = 0; j < n - 1; j++) {
+            const double aj = a[j];
+            const double temp = c2[j] * aj + s2[j] * an;
+            an = -s2[j] * aj + c2[j] * an;
+            a[j] = temp;
+        }
+        a[n - 1] = an;
+    }
+    if (ex.tid == 0) {                                       // qtf is the one-row case
+        double *a = wk.qtf;
+        double an = a[n - 1];
+        for (int j = n - 2; j >= 0; j--) {
+            const double aj = a[j];
+            const double temp = c1[j] * aj - s1[j] * an;
+            an = s1[j] * aj + c1[j] * an;
+            a[j] = temp;
+        }
+        for (int j = 0; j < n - 1; j++) {
+            const double aj = a[j];
+            const double temp = c2[j] * aj + s2[j] * an;
+            an = -s2[j] * aj + c2[j] * an;
+            a[j] = temp;
+        }
+        a[n - 1] = an;
+    }
+    ex.sync();
+}
+
+// ---- the state machine (Core::advance of minpack.cpp).  Every thread of the problem's workgroup calls it with the same
+// arguments; scalars are computed by all threads alike and stored by thread 0.
+template <class E>
+struct Machine {
+    const E &ex;
+    const Config &c;
+    State &st;                 // in global memory; `s` is this thread's copy
+    State s;
+    Work w;
+    SOCP_HD Machine(const E &e, const Config &cfg, State &state, double *base) : ex(e), c(cfg), st(state), s(state), w(base, cfg.n, cfg.ld) {}
+
+    SOCP_HD void store() { ex.sync(); if (ex.tid == 0) st = s; }
+    SOCP_HD void finish(int code) { s.info = code; s.phase = PH_DONE; s.req = RQ_DONE; }
+    SOCP_HD void request_jac() { s.jeval = 1; s.phase = PH_JAC; s.req = RQ_JAC; }
+
+    SOCP_HD void request_trial()
+    {
+        const int n = c.n;
+        dogleg(ex, n, w, s.delta);
+        SOCP_PAR_FOR(j, 0, n) {
+            const double p = -w.wa1[j];
+            w.wa1[j] = p;
+            w.wa2[j] = w.x[j] + p;
+            w.wa3[j] = w.diag[j] * p;
+        }
+        ex.sync();
+        s.pnorm = enorm(n, w.wa3);
+        if (s.iter == 1) s.delta = min_of(s.delta, s.pnorm);
+        s.phase = PH_TRIAL;
+        s.req = RQ_FVEC; s.eval_sel = 1;
+    }
+
+    SOCP_HD void after_jacobian()
+    {
+        const int n = c.n;
+        if (c.analytic) s.njev += 1; else s.nfev += n;
+        const bool sing = factor(ex, n, c.ld, w);            // wa1 = diag(R), wa2 = column norms
+        if (s.iter == 1) {
+            if (c.mode != 2) SOCP_PAR_FOR(j, 0, n) w.diag[j] = (w.wa2[j] == 0) ? 1.0 : w.wa2[j];
+            ex.sync();
+            SOCP_PAR_FOR(j, 0, n) w.wa3[j] = w.diag[j] * w.x[j];
+            ex.sync();
+            s.xnorm = enorm(n, w.wa3);
+            s.delta = c.factor * s.xnorm;
+            if (s.delta == 0) s.delta = c.factor;
+        }
+        s.sing = sing ? 1 : 0;
+        ex.sync();
+        if (c.mode != 2) SOCP_PAR_FOR(j, 0, n) w.diag[j] = max_of(w.diag[j], w.wa2[j]);
+        ex.sync();
+    }
+
+    SOCP_HD void after_trial()
+    {
+        const double p1 = .1, p5 = .5, p001 = .001, p0001 = 1e-4;
+        const int n = c.n;
+        s.nfev += 1;
+        const double fnorm1 = enorm(n, w.wa4);
+        double actred = -1;
+        if (fnorm1 < s.fnorm) { const double q = fnorm1 / s.fnorm; actred = 1 - q * q; }
+        // predicted reduction from |qtf + R p|
+        SOCP_PAR_FOR(i, 0, n) {
+            const long off = row_off(n, i);
+            double sum = 0;
+            for (int j = i; j < n; j++) sum += w.r[off + (j - i)] * w.wa1[j];
+            w.wa3[i] = w.qtf[i] + sum;
+        }
+        ex.sync();
+        const double temp = enorm(n, w.wa3);
+        double prered = 0;
+        if (temp < s.fnorm) { const double q = temp / s.fnorm; prered = 1 - q * q; }
+        const double ratio = prered > 0 ? actred / prered : 0;
+
+        if (ratio < p1) {
+            s.ncsuc = 0; s.ncfail += 1; s.delta = p5 * s.delta;
+        } else {
+            s.ncfail = 0; s.ncsuc += 1;
+            if (ratio >= p5 || s.ncsuc > 1) s.delta = max_of(s.delta, s.pnorm / p5);
+            if (fabs(ratio - 1) <= p1) s.delta = s.pnorm / p5;
+        }
+        if (ratio >= p0001) {
+            ex.sync();
+            SOCP_PAR_FOR(j, 0, n) { const double xj = w.wa2[j]; w.x[j] = xj; w.wa2[j] = w.diag[j] * xj; w.fvec[j] = w.wa4[j]; }
+            ex.sync();
+            s.xnorm = enorm(n, w.wa2);
+            s.fnorm = fnorm1;
+            s.iter += 1;
+        }
+        s.nslow1 += 1; if (actred >= p001) s.nslow1 = 0;
+        if (s.jeval) s.nslow2 += 1;
+        if (actred >= p1) s.nslow2 = 0;
+
+        if (s.delta <= c.xtol * s.xnorm || s.fnorm == 0) { finish(1); return; }
+        int code = 0;
+        if (s.nfev >= c.maxfev) code = 2;
+        if (p1 * max_of(p1 * s.delta, s.pnorm) <= kEpsMch * s.xnorm) code = 3;
+        if (s.nslow2 == 5) code = 4;
+        if (s.nslow1 == 10) code = 5;
+        if (code != 0) { finish(code); return; }
+        if (s.ncfail == 2) { request_jac(); return; }
+
+        // Broyden rank-1 update of (Q, R, Q^T f)
+        ex.sync();
+        const double pnorm = s.pnorm;
+        SOCP_PAR_FOR(j, 0, n) {
+            double sum = 0;
+            for (int i = 0; i < n; i++) sum += w.A[(long)i * c.ld + j] * w.wa4[i];
+            w.wa2[j] = (sum - w.wa3[j]) / pnorm;
+            w.wa1[j] = w.diag[j] * ((w.diag[j] * w.wa1[j]) / pnorm);
+            if (ratio >= p0001) w.qtf[j] = sum;
+        }
+        ex.sync();
+        s.sing = r1updt(ex, n, w) ? 1 : 0;
+        r1mpyq_all(ex, n, c.ld, w);
+        s.jeval = 0;
+        request_trial();
+    }
+
+    // user_flag: what the evaluation of the pending request returned (< 0 aborts the solve, shooting.cpp:873)
+    SOCP_HD void advance(int flag)
+    {
+        if (s.phase == PH_DONE) { s.req = RQ_DONE; store(); return; }
+        if (s.phase != PH_INIT && flag < 0) { finish(flag); store(); return; }
+        switch (s.phase) {
+        case PH_INIT: {
+            s.info = 0; s.nfev = 0; s.njev = 0;
+            bool bad = c.n <= 0 || c.xtol < 0 || c.maxfev <= 0 || c.factor <= 0;
+            if (!bad && c.mode == 2)
+                for (int j = 0; j < c.n; j++) if (w.diag[j] <= 0) bad = true;
+            if (bad) { finish(0); break; }
+            s.phase = PH_F0;
+            s.req = RQ_FVEC; s.eval_sel = 0;
+            break;
+        }
+        case PH_F0:
+            s.nfev = 1;
+            s.fnorm = enorm(c.n, w.fvec);
+            s.iter = 1; s.ncsuc = s.ncfail = s.nslow1 = s.nslow2 = 0;
+            request_jac();
+            break;
+        case PH_JAC:
+            after_jacobian();
+            request_trial();
+            break;
+        case PH_TRIAL:
+            after_trial();
+            break;
+        default:
+            s.req = RQ_DONE;
+        }
+        store();
+    }
+};
+
+// (re)start a problem from x0 (socp_hybr_start with diag = NULL, mode 1)
+template <class E>
+SOCP_HD void start(const E &ex, const Config &c, State &st, double *base, const double *x0)
+{
+    Work w(base, c.n, c.ld);
+    SOCP_PAR_FOR(j, 0, c.n) { w.x[j] = x0[j]; w.diag[j] = 1.0; }
+    ex.sync();
+    if (ex.tid == 0) {
+        State s = st;
+        s.phase = PH_INIT; s.req = RQ_DONE; s.eval_sel = 0; s.info = 0; s.nfev = 0; s.njev = 0;
+        st = s;
+    }
+    ex.sync();
+}
+
+#undef SOCP_PAR_FOR
+
+}  // namespace devsolver
+}  // namespace socp

@@ -11,49 +11,8 @@
 // bit-identical to the x86 path.
 #pragma once
 #include "dev_common.hpp"
-#include "models_exact.hpp"
 
 namespace socp {
-
-// ---- double integrator: variational right-hand side and dH/dX ---------------------------------
-struct DIntVar : DIntExact {
-    static constexpr int L = (S + 1) * S;
-
-    // element e of Model(t, Y, isJac = 1) (doubleIntegrator.cpp:113-213).  df/dX is constant and has
-    // one nonzero per row (:155-166): rows 0-2 -> +R[row+3], rows 3-5 -> -R[row+6], rows 6-8 -> 0,
-    // rows 9-11 -> -R[row-3]; the reference sums the zero terms too, which changes nothing finite.
-    __device__ static __forceinline__ double aug_rhs(const ModelParams &P, int e, const double *Y)
-    {
-        if (e < S) {
-            if (e < 3) return Y[e + 3];
-            if (e < 6) {
-                double X[S];
-#pragma unroll
-                for (int k = 0; k < S; k++) X[k] = Y[k];
-                double u[3];
-                control_only(P, 0, 0, 0, X, u);
-                return P.p[DP_AMAX] * u[e - 3];
-            }
-            if (e < 9) return 0.0;
-            return -Y[e - 3];
-        }
-        const int i = (e - S) / S, j = (e - S) - i * S;
-        if (i < 3) return 0.0 + 1.0 * Y[S + S * (i + 3) + j];
-        if (i < 6) return 0.0 + (-1.0) * Y[S + S * (i + 6) + j];
-        if (i < 9) return 0.0;
-        return 0.0 + (-1.0) * Y[S + S * (i - 3) + j];
-    }
-
-    // doubleIntegrator.cpp:293-297: {0,0,0, p_x,p_y,p_z, vx,vy,vz, -p_vx,-p_vy,-p_vz, 0}
-    __device__ static __forceinline__ void dhamiltonian(const ModelParams &, const double *X, double (&dH)[S + 1])
-    {
-        dH[0] = 0; dH[1] = 0; dH[2] = 0;
-        dH[3] = X[6]; dH[4] = X[7]; dH[5] = X[8];
-        dH[6] = X[3]; dH[7] = X[4]; dH[8] = X[5];
-        dH[9] = -X[9]; dH[10] = -X[10]; dH[11] = -X[11];
-        dH[12] = 0;
-    }
-};
 
 // K_var: B augmented trajectories, one wave each.  X0, Xf: [B][L].  pp_params (may be null): per-problem parameter blocks
 // [B / M][pp_stride] (dev_common.hpp), trajectory b belongs to problem b / M.
@@ -64,7 +23,7 @@ __global__ __launch_bounds__(64) void traj_var_wave_kernel(ModelParams P, const 
                                                            double *__restrict__ Xf,
                                                            const double *__restrict__ pp_params, int pp_stride, int M)
 {
-    constexpr int L = Mdl::L;
+    constexpr int L = (Mdl::S + 1) * Mdl::S;
     constexpr int K = (L + 63) / 64;
     __shared__ double Y[L];
     const int lane = threadIdx.x;
@@ -82,13 +41,13 @@ __global__ __launch_bounds__(64) void traj_var_wave_kernel(ModelParams P, const 
         X[k] = e < L ? X0[b * L + e] : 0.0;
     }
     // publish a stage vector, then evaluate this lane's elements of the variational RHS
-    auto stage = [&](const double (&v)[K], double (&out)[K]) {
+    auto stage = [&](double ts, const double (&v)[K], double (&out)[K]) {
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < K; k++) { const int e = lane + 64 * k; if (e < L) Y[e] = v[k]; }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < K; k++) { const int e = lane + 64 * k; out[k] = e < L ? Mdl::aug_rhs(P, e, Y) : 0.0; }
+        for (int k = 0; k < K; k++) { const int e = lane + 64 * k; out[k] = e < L ? Mdl::aug_rhs(P, ts, e, Y) : 0.0; }
     };
     const double ta = t0[b], tb = tf[b];
     const double dt = (tb - ta) / P.step_nbr;
@@ -97,16 +56,16 @@ __global__ __launch_bounds__(64) void traj_var_wave_kernel(ModelParams P, const 
     while (t < (tb - dt / 2) && guard-- > 0) {          // wave-uniform: same t in every lane
         const double step = (t + dt > tb) ? (tb - t) : dt;
         const double h2 = step / 2.0;
-        stage(X, F1);
+        stage(t, X, F1);
 #pragma unroll
         for (int k = 0; k < K; k++) V[k] = X[k] + h2 * F1[k];
-        stage(V, Fs);
+        stage(t + step / 2.0, V, Fs);
 #pragma unroll
         for (int k = 0; k < K; k++) V[k] = X[k] + h2 * Fs[k];
-        stage(V, F);
+        stage(t + step / 2.0, V, F);
 #pragma unroll
         for (int k = 0; k < K; k++) { V[k] = X[k] + step * F[k]; Fs[k] = Fs[k] + F[k]; }
-        stage(V, F);
+        stage(t + step, V, F);
         const double h6 = step / 6.0;
 #pragma unroll
         for (int k = 0; k < K; k++) X[k] = X[k] + h6 * (F1[k] + (F[k] + 2.0 * Fs[k]));
@@ -123,7 +82,7 @@ template <class Mdl>
 __global__ void var_prepare_kernel(ProblemDev pb, const double *__restrict__ Zb, double *__restrict__ Xaug,
                                    double *__restrict__ t0, double *__restrict__ tf)
 {
-    constexpr int S = Mdl::S, L = Mdl::L;
+    constexpr int S = Mdl::S, L = (Mdl::S + 1) * Mdl::S;
     const long prob = blockIdx.x / pb.M;
     const int i = blockIdx.x - (int)prob * pb.M;
     const double *z = Zb + prob * pb.n;
@@ -147,7 +106,7 @@ template <class Mdl>
 __global__ void var_assemble_kernel(ModelParams P, ProblemDev pb, int np, const double *__restrict__ Zb,
                                     const double *__restrict__ Xtf_all, double *__restrict__ Fjac)
 {
-    constexpr int S = Mdl::S, D = Mdl::D, L = Mdl::L;
+    constexpr int S = Mdl::S, D = Mdl::D, L = (Mdl::S + 1) * Mdl::S;
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int M = pb.M, n = pb.n;
     if (gid >= (long)np * M) return;
@@ -174,7 +133,7 @@ __global__ void var_assemble_kernel(ModelParams P, ProblemDev pb, int np, const 
         }
         if (col_t >= 0) {                                                     // InitialHFunction, model.hpp:256-289
             Mdl::rhs(P, 0, 0, t1, X1, fx);
-            Mdl::dhamiltonian(P, X1, dH);
+            Mdl::dhamiltonian(P, t1, X1, dH);
             for (int k = 0; k < D; k++) J(k, col_t) = (mx[k] == 1) ? fx[k + D] : fx[k];
             for (int c = 0; c < S; c++) {
                 double acc = 0;
@@ -221,8 +180,8 @@ __global__ void var_assemble_kernel(ModelParams P, ProblemDev pb, int np, const 
                 for (int k = 0; k < S; k++) J(index + k, spill) = J(index + k, col_t);
             // model.hpp:305-326 SwitchingTimesFunction, isJac = 1
             double dH[S + 1], dHp[S + 1];
-            Mdl::dhamiltonian(P, Xs, dH);
-            Mdl::dhamiltonian(P, Xp, dHp);
+            Mdl::dhamiltonian(P, t2, Xs, dH);
+            Mdl::dhamiltonian(P, t2, Xp, dHp);
             for (int c = 0; c < S; c++) {
                 double a = 0, b = 0;
                 for (int k = 0; k < S; k++) {
@@ -249,7 +208,7 @@ __global__ void var_assemble_kernel(ModelParams P, ProblemDev pb, int np, const 
 #pragma unroll
             for (int k = 0; k < S; k++) Xs[k] = Xtf[k];
             Mdl::rhs(P, 0, 0, t2, Xs, fx);
-            Mdl::dhamiltonian(P, Xs, dH);
+            Mdl::dhamiltonian(P, t2, Xs, dH);
             for (int k = 0; k < D; k++) J(D + k, col_t) = (mx[k] == 1) ? fx[k + D] : fx[k];
             for (int c = 0; c < S; c++) {
                 double acc = 0;
@@ -266,20 +225,57 @@ __global__ void var_assemble_kernel(ModelParams P, ProblemDev pb, int np, const 
 // K_veval: Model(t, X, isJac = 1) on an augmented state and Hamiltonian(t, X, isJac = 1), one point
 // per thread (host mirror's virtuals; not hot)
 template <class Mdl>
-__global__ void var_eval_kernel(ModelParams P, int what, int B, const double *__restrict__ Xin, int len,
+__global__ void var_eval_kernel(ModelParams P, int what, int B, const double *__restrict__ tin, const double *__restrict__ Xin, int len,
                                 double *__restrict__ out)
 {
-    constexpr int S = Mdl::S, L = Mdl::L;
+    constexpr int S = Mdl::S, L = (Mdl::S + 1) * Mdl::S;
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const double *X = Xin + (long)b * len;
+    const double t = tin ? tin[b] : 0.0;
     if (what == 0) {
-        for (int e = 0; e < L; e++) out[(long)b * L + e] = Mdl::aug_rhs(P, e, X);
+        for (int e = 0; e < L; e++) out[(long)b * L + e] = Mdl::aug_rhs(P, t, e, X);
     } else {
         double dH[S + 1];
-        Mdl::dhamiltonian(P, X, dH);
+        Mdl::dhamiltonian(P, t, X, dH);
         for (int k = 0; k <= S; k++) out[(long)b * (S + 1) + k] = dH[k];
     }
 }
+
+// ---- launchers, one set per model with variational equations (the in-tree double integrator; plugins with the optional
+// aug_rhs / dhamiltonian trait, plugin_impl.hpp) ----------------------------------------------------------------------------
+namespace varimpl {
+
+template <class Mdl>
+hipError_t traj(hipStream_t st, const ModelParams &P, int B, const double *t0, const double *tf, const double *X0, double *Xf)
+{
+    if (B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(traj_var_wave_kernel<Mdl>, dim3(B), dim3(64), 0, st, P, t0, tf, X0, Xf, (const double *)nullptr, 0, 1);
+    return hipGetLastError();
+}
+
+template <class Mdl>
+hipError_t jacobian(hipStream_t st, const ModelParams &P, const ProblemDev &pb, int np, const double *z, double *Xaug, double *Xtf,
+                    double *t0, double *tf, double *fjac)
+{
+    if (np <= 0) return hipSuccess;
+    const unsigned B = (unsigned)((long)np * pb.M);                 // one wavefront per (problem, segment)
+    hipLaunchKernelGGL(var_prepare_kernel<Mdl>, dim3(B), dim3(64), 0, st, pb, z, Xaug, t0, tf);
+    hipLaunchKernelGGL(traj_var_wave_kernel<Mdl>, dim3(B), dim3(64), 0, st, P, t0, tf, Xaug, Xtf, pb.pp_params, pb.pp_stride, pb.M);
+    hipError_t e = hipMemsetAsync(fjac, 0, sizeof(double) * (size_t)np * pb.n * pb.n, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(var_assemble_kernel<Mdl>, dim3((B + 63) / 64), dim3(64), 0, st, P, pb, np, z, Xtf, fjac);
+    return hipGetLastError();
+}
+
+template <class Mdl>
+hipError_t eval(hipStream_t st, const ModelParams &P, int what, int B, const double *t, const double *X, int len, double *out)
+{
+    if (B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(var_eval_kernel<Mdl>, dim3((B + 63) / 64), dim3(64), 0, st, P, what, B, t, X, len, out);
+    return hipGetLastError();
+}
+
+}  // namespace varimpl
 
 }  // namespace socp

@@ -26,6 +26,28 @@ struct Lqr1D {
         const double u = -P.p[0] * X[3];
         return u * u / 2 + X[2] * X[1] + X[3] * u;
     }
+    // optional trait: variational equations -> modelOrder = 1 / hybrj works for this model.  df/dX is constant:
+    // x' = v, v' = -g p_v, p_x' = 0, p_v' = -p_x  =>  dR/dt rows:  R[1], -g R[3], 0, -R[2]
+    __device__ static double aug_rhs(const socp::ModelParams &P, double, int e, const double *Y)
+    {
+        if (e < S) {
+            if (e == 0) return Y[1];
+            if (e == 1) return -P.p[0] * Y[3];
+            if (e == 2) return 0.0;
+            return -Y[2];
+        }
+        const int i = (e - S) / S, j = (e - S) - i * S;
+        if (i == 0) return Y[S + S * 1 + j];
+        if (i == 1) return -P.p[0] * Y[S + S * 3 + j];
+        if (i == 2) return 0.0;
+        return -Y[S + S * 2 + j];
+    }
+    // H = u^2/2 + p_x v + p_v u with u = -g p_v:  dH/d(x, v, p_x, p_v) = (0, p_x, v, g^2 p_v - 2 g p_v), dH/dt = 0
+    __device__ static void dhamiltonian(const socp::ModelParams &P, double, const double *X, double (&dH)[S + 1])
+    {
+        const double g = P.p[0];
+        dH[0] = 0; dH[1] = X[2]; dH[2] = X[1]; dH[3] = g * g * X[3] - 2 * g * X[3]; dH[4] = 0;
+    }
     __device__ static double switching_fn(const socp::ModelParams &P, double a, double b, double t, const double (&X)[S], const double (&Xp)[S])
     {
         return hamiltonian(P, a, b, t, X) - hamiltonian(P, a, b, t, Xp);

@@ -55,6 +55,62 @@ def test_user_model_class_with_plugin(M):
     assert abs(r["p_x"] + 12.0) <= 1e-8 and abs(r["p_v"] + 6.0) <= 1e-8 and abs(r["u0"] - 6.0) <= 1e-8
 
 
+def test_plugin_variational_trait_gives_the_analytic_jacobian():
+    """The optional aug_rhs / dhamiltonian trait (plugin_impl.hpp) puts a plugin on the hybrj path: the
+    variational Jacobian of the linear-quadratic problem is known in closed form -- the flow of the linear system over T is
+    Phi(T) = [[1, T, T^3/6, -T^2/2], [0, 1, T^2/2, -T], [0, 0, 1, 0], [0, 0, -T, 1]] (RK4 reproduces these cubics exactly up to
+    rounding), and the single-shooting residual F = [x0 - a, v0 - b, x(T) - c, v(T) - d] has Jacobian [I2 0 ; Phi rows 0-1]."""
+    from socp_amd import capi
+    capi.plugin_load(PLUGIN)
+    ctx = capi.Context(1001, nparams=1)
+    assert ctx.has_variational()
+    mode_x = np.zeros((2, 2), dtype=np.int32)
+    Xn = np.zeros((2, 4))
+    Xn[1, 0] = 1.0
+    T = 1.0
+    assert ctx.problem_set([capi.FIXED, capi.FIXED], mode_x, [0.0, T], Xn) == 4
+    z = np.array([0.1, -0.2, -3.0, 2.0])
+    J = ctx.var_jacobian(z)
+    want = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [1, T, T ** 3 / 6, -T ** 2 / 2], [0, 1, T ** 2 / 2, -T]])
+    assert np.max(np.abs(J - want)) <= 1e-14, J
+    Jfd = ctx.fd_jacobian(z, ctx.residual(z))
+    assert np.max(np.abs(J - Jfd)) <= 1e-6
+    # free final time: the H row and the time column (model.hpp:149-183) against finite differences of the residual
+    assert ctx.problem_set([capi.FIXED, capi.FREE], mode_x, [0.0, T], Xn) == 5
+    z5 = np.append(z, 0.9)
+    J5 = ctx.var_jacobian(z5)
+    J5fd = ctx.fd_jacobian(z5, ctx.residual(z5), epsfcn=1e-12)
+    assert np.max(np.abs(J5 - J5fd)) <= 1e-4 * max(1.0, np.max(np.abs(J5)))
+    # solved with hybrj through the C-ABI: the analytic optimum
+    ctx.problem_set([capi.FIXED, capi.FIXED], mode_x, [0.0, T], Xn)
+    out = capi.hybrj(lambda v: ctx.residual(v), lambda v: ctx.var_jacobian(v), np.array([0.0, 0.0, -1.0, -1.0]), xtol=1e-12)
+    assert out["info"] == 1 and out["njev"] >= 1
+    assert np.allclose(out["x"], [0.0, 0.0, -12.0, -6.0], rtol=0, atol=1e-9)
+    # hybrj chains through the lock-step engine (analytic_jac = 1) for a plugin model
+    starts = np.tile([0.0, 0.0, -1.0, -1.0], (5, 1)) + np.linspace(0, 1, 5)[:, None] * [0, 0, -3.0, 2.0]
+    r = ctx.chains_solve(starts, kind=capi.CHAIN_PLAIN, xtol=1e-9, analytic_jac=True)
+    # (a linear problem with its exact Jacobian: the first Newton step lands on the root to rounding, after which MINPACK may
+    # stop on "no progress" -- info 4 / 5 -- before the trust region has shrunk to xtol; the root is what is checked)
+    assert np.all(r["njev"] >= 1) and np.all(r["fnorm"] <= 1e-12) and np.allclose(r["z"][:, 2:], [-12.0, -6.0], atol=1e-9)
+    ctx.close()
+    # a model without the trait says so
+    g = capi.Context(capi.MODEL_GODDARD)
+    assert not g.has_variational()
+    g.close()
+
+
+@pytest.mark.parametrize("M", [1, 3])
+def test_user_model_class_with_plugin_and_model_order_1(M):
+    """shooting::SolveOCP of a user class with modelOrder = 1 whose dynamics AND variational equations live in the plugin:
+    the mirror calls hybrj with the device Jacobian (shooting.cpp:828-852)."""
+    exe = os.path.join(ROOT, "socp_amd", "_build", "bin", "plugin_flow")
+    out = subprocess.run([exe, PLUGIN, str(M), "1"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    assert r["info"] == 1 and r["n"] == 4 * M and r["njev"] >= 1
+    assert abs(r["p_x"] + 12.0) <= 1e-8 and abs(r["p_v"] + 6.0) <= 1e-8 and abs(r["u0"] - 6.0) <= 1e-8
+
+
 def test_unregistered_id_is_rejected():
     from socp_amd import capi
     with pytest.raises(capi.SocpError) as e:
