@@ -104,7 +104,8 @@ typedef struct socp_chain_options {
     double factor;
     int dedup;                /* launched FD Jacobians integrate only the segments a column can change */
     int speculate;            /* residual requests evaluated as whole FD batches so that later Jacobian requests at an accepted
-                                 point need no launch: -1 = when the chip has idle SIMDs (default), 0 = never, 1 = always.
+                                 point need no launch: -1 = when the chip has idle SIMDs (default), 0 = never (also what a zeroed
+                                 struct means), 1 = always.
                                  No iterate depends on it.  Environment SOCP_CHAINS_SPECULATE overrides. */
     int max_rounds;           /* 0 = no limit.  > 0: chains still solving after that many launch rounds are stopped with
                                  info = SOCP_INFO_ROUND_LIMIT, like a callback returning < 0 (shooting.cpp:873): a sweep's wall
@@ -114,7 +115,17 @@ typedef struct socp_chain_options {
                                  (modelOrder 1, shooting.cpp:828-852,996-1130; models with variational equations only): the
                                  Jacobian requests of a round are one batched variational integration, one wavefront per
                                  (chain, segment); nfev / njev are accounted as hybrj does. */
+    int solver;               /* where the chains' hybrd / hybrj state machines run: SOCP_SOLVER_AUTO (0; also what a zeroed struct
+                                 means), SOCP_SOLVER_HOST, SOCP_SOLVER_DEVICE.  DEVICE: one workgroup per chain runs MINPACK's qrfac /
+                                 qform / dogleg / r1updt / r1mpyq in HBM with the per-column operation order of the host code, so
+                                 every iterate, nfev and info is the host solver's, bit for bit; Jacobians never cross PCIe.  AUTO
+                                 picks DEVICE where the host side is the bottleneck (n >= 32 and P n^2 >= 2e6) and the solver state
+                                 fits HBM.  Without speculation (that pays at n = 14, where AUTO stays on the host).  Environment
+                                 SOCP_CHAINS_SOLVER=host|device overrides. */
 } socp_chain_options;
+#define SOCP_SOLVER_AUTO   0
+#define SOCP_SOLVER_HOST   1
+#define SOCP_SOLVER_DEVICE 2
 #define SOCP_INFO_ROUND_LIMIT (-3)
 
 typedef struct socp_chain_stats {

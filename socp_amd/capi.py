@@ -34,13 +34,15 @@ _lib = None
 
 
 CHAIN_PLAIN, CHAIN_PARAM, CHAIN_DATA = 0, 1, 2
+SOLVER_AUTO, SOLVER_HOST, SOLVER_DEVICE = 0, 1, 2
 
 
 class ChainOptions(C.Structure):
     """socp_chain_options (include/socp_solver.h)."""
     _fields_ = [("kind", C.c_int), ("param_index", C.c_int), ("step", C.c_double), ("step_min", C.c_double),
                 ("xtol", C.c_double), ("maxfev", C.c_int), ("epsfcn", C.c_double), ("factor", C.c_double),
-                ("dedup", C.c_int), ("speculate", C.c_int), ("max_rounds", C.c_int), ("analytic_jac", C.c_int)]
+                ("dedup", C.c_int), ("speculate", C.c_int), ("max_rounds", C.c_int), ("analytic_jac", C.c_int),
+                ("solver", C.c_int)]
 
 
 class ChainStats(C.Structure):
@@ -389,12 +391,12 @@ class Context:
 
     def chains_solve(self, Z0, kind=CHAIN_PLAIN, param_index=0, step=1.0, step_min=1e-12, goal=None, params=None,
                      time_prev=None, x_prev=None, time_goal=None, x_goal=None, xtol=1e-8, maxfev=10000, epsfcn=1e-15,
-                     factor=1.0, dedup=True, speculate=-1, max_rounds=0, analytic_jac=False):
+                     factor=1.0, dedup=True, speculate=-1, max_rounds=0, analytic_jac=False, solver=SOLVER_AUTO):
         """Lock-step continuation chains (socp_chains_solve).  Returns a dict of per-chain arrays + 'stats'."""
         Z0 = _f64(Z0).reshape(-1, self.n)
         P = Z0.shape[0]
         opt = ChainOptions(int(kind), int(param_index), float(step), float(step_min), float(xtol), int(maxfev), float(epsfcn),
-                           float(factor), int(bool(dedup)), int(speculate), int(max_rounds), int(bool(analytic_jac)))
+                           float(factor), int(bool(dedup)), int(speculate), int(max_rounds), int(bool(analytic_jac)), int(solver))
         keep = []
 
         def arr(a, width=None):

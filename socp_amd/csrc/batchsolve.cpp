@@ -29,7 +29,14 @@
 #include <thread>
 #include <vector>
 
+#include "chains_common.hpp"
 #include "host_pool.hpp"
+
+// batchsolve_dev.cpp: the same engine with the solvers on the device
+int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt, const double *Z0, const double *params,
+                             const double *goal, const double *time_prev, const double *x_prev, const double *time_goal,
+                             const double *x_goal, double *Zout, int *info, int *nfev_last, int *nfev_total, int *njev_last,
+                             int *solves, double *b_reached, double *param_final, double *fnorm, socp_chain_stats *stats);
 
 namespace {
 
@@ -80,13 +87,8 @@ bool copy_blocks(hipStream_t st, const double *src, const int *d_src_idx, double
     return hipGetLastError() == hipSuccess;
 }
 
-struct Chain {
+struct Chain : socp::chains::ChainCore {
     socp_hybr *solver = nullptr;
-    // homotopy state (shooting.cpp:598-692 / 695-778; the host mirror's `Homotopy`)
-    double b = 1, b_prec = 0;
-    bool finished = false;
-    int info = 0, nfev_last = 0, nfev_total = 0, solves = 0;
-    std::vector<double> committed;      // tab_param: the unknowns of the last converged solve (or the start)
     // request state
     int flag = 0, req = SOCP_REQ_DONE;
     const double *xin = nullptr;
@@ -98,8 +100,6 @@ struct Chain {
     std::vector<double> slot_x;         // the point whose rows sit in this chain's slot
     bool slot_valid = false;
 };
-
-double blend(double b, double a0, double a1) { return (1 - b) * a0 + b * a1; }
 
 }  // namespace
 
@@ -126,16 +126,37 @@ extern "C" int socp_chains_solve_ex(socp_ctx *ctx, int P, const socp_chain_optio
     double shared_params[SOCP_MAX_NPARAMS + 2] = {0};
     if (nparams < 0 || nparams > SOCP_MAX_NPARAMS || socp_ctx_get_params(ctx, shared_params, nparams) != SOCP_OK) return SOCP_ERR_ARG;
     const int kind = opt->kind;
-    if (kind != SOCP_CHAIN_PLAIN && kind != SOCP_CHAIN_PARAM && kind != SOCP_CHAIN_DATA) return SOCP_ERR_ARG;
-    if (kind == SOCP_CHAIN_PARAM && (!goal || opt->param_index < 0 || opt->param_index >= nparams)) return SOCP_ERR_ARG;
-    if (kind == SOCP_CHAIN_DATA && (!time_prev || !x_prev || !time_goal || !x_goal)) return SOCP_ERR_ARG;
-    if (kind != SOCP_CHAIN_PLAIN && !(opt->step > 0)) return SOCP_ERR_ARG;
-    // continuationStepMin: a negative or NaN value can never end the bisection of a chain whose solves keep failing (0 can: the
-    // halving stops moving b after ~55 steps, see solve_finished)
-    if (kind != SOCP_CHAIN_PLAIN && !(opt->step_min >= 0)) return SOCP_ERR_ARG;
+    if (int bad = socp::chains::validate(opt, nparams, goal, time_prev, x_prev, time_goal, x_goal)) return bad;
     // the variational Jacobian exists for models with variational equations only (modelOrder 1: the double integrator, plugins with the trait)
     if (opt->analytic_jac && socp_ctx_has_variational(ctx) != 1) return SOCP_ERR_UNSUPPORTED;
     if (P == 0) return SOCP_OK;
+
+    // ---- where the state machines run (socp_chain_options.solver) -----------------------------------------------------------
+    {
+        int solver = opt->solver;
+        if (const char *e = std::getenv("SOCP_CHAINS_SOLVER")) {
+            if (std::strcmp(e, "device") == 0) solver = SOCP_SOLVER_DEVICE;
+            else if (std::strcmp(e, "host") == 0) solver = SOCP_SOLVER_HOST;
+        }
+        if (solver != SOCP_SOLVER_AUTO && solver != SOCP_SOLVER_HOST && solver != SOCP_SOLVER_DEVICE) return SOCP_ERR_ARG;
+        if (solver == SOCP_SOLVER_AUTO) {
+            // the host side is the bottleneck of sweeps with n >= 32 (P factorisations of O(n^3) per refresh, P n^2 doubles over
+            // PCIe); at n = 14 the rounds are kernel latency and the host engine's speculative FD rows are what pays
+            solver = (n >= 32 && (double)P * n * n >= 2e6) ? SOCP_SOLVER_DEVICE : SOCP_SOLVER_HOST;
+            if (solver == SOCP_SOLVER_DEVICE) {
+                size_t free_b = 0, total_b = 0;
+                int prev = -1;
+                const double need = 8.0 * ((double)P * ((double)n * (n + 9) + 0.5 * n * (n + 1) + 14.0 * n) + std::min((double)P * n * n, 1.1e9));
+                if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(socp_ctx_device(ctx)) != hipSuccess ||
+                    hipMemGetInfo(&free_b, &total_b) != hipSuccess || need > 0.8 * (double)free_b)
+                    solver = SOCP_SOLVER_HOST;
+                if (prev >= 0) (void)hipSetDevice(prev);
+            }
+        }
+        if (solver == SOCP_SOLVER_DEVICE)
+            return socp_chains_solve_device(ctx, P, opt, Z0, params, goal, time_prev, x_prev, time_goal, x_goal, Zout, info, nfev_last, nfev_total,
+                                            njev_last, solves, b_reached, param_final, fnorm, stats);
+    }
 
     // every allocation, copy and stream below lives on the context's device, whatever the calling thread's current device
     struct DeviceGuard {
@@ -149,11 +170,12 @@ extern "C" int socp_chains_solve_ex(socp_ctx *ctx, int P, const socp_chain_optio
     const int nodes = socp_problem_num_nodes(ctx);          // M + 1
     if (nodes < 2) return SOCP_ERR_ARG;
     const int segs = nodes - 1;
-    const bool pp_params = params != nullptr || kind == SOCP_CHAIN_PARAM;
-    const bool pp_bound = kind == SOCP_CHAIN_DATA || (time_goal && x_goal);
-    const int stride = nparams + 2;
     double shared_sw[2] = {0, 0};
     socp_ctx_get_switching_times(ctx, shared_sw);
+    socp::chains::Blocks blk;
+    blk.init(P, *opt, nparams, nodes, S, dim, params, shared_params, shared_sw, goal, time_prev, x_prev, time_goal, x_goal);
+    const bool pp_params = blk.pp_params, pp_bound = blk.pp_bound;
+    const int stride = blk.stride;
 
     using clk = std::chrono::steady_clock;
     const clk::time_point t_begin = clk::now();
@@ -172,21 +194,6 @@ extern "C" int socp_chains_solve_ex(socp_ctx *ctx, int P, const socp_chain_optio
 
     // ---- per-chain state --------------------------------------------------------------------------------------------
     std::vector<Chain> ch(P);
-    std::vector<double> pblock(pp_params ? (size_t)P * stride : 0), rstart(P, 0.0);
-    std::vector<double> tblock(pp_bound ? (size_t)P * nodes : 0), xblock(pp_bound ? (size_t)P * nodes * S : 0);
-    auto set_blocks = [&](int p) {
-        Chain &c = ch[p];
-        if (kind == SOCP_CHAIN_PARAM) pblock[(size_t)p * stride + opt->param_index] = blend(c.b, rstart[p], goal[p]);
-        if (kind == SOCP_CHAIN_DATA) {
-            for (int i = 0; i < nodes; i++) {
-                tblock[(size_t)p * nodes + i] = blend(c.b, time_prev[(size_t)p * nodes + i], time_goal[(size_t)p * nodes + i]);
-                for (int j = 0; j < dim; j++) {
-                    const size_t e = ((size_t)p * nodes + i) * S + j;
-                    xblock[e] = blend(c.b, x_prev[e], x_goal[e]);
-                }
-            }
-        }
-    };
     bool alloc_ok = true;
     socp_hybr_pool *pool = socp_hybr_pool_create(P, n, opt->xtol, opt->maxfev, opt->epsfcn, 1, opt->factor, opt->analytic_jac ? 1 : 0);
     if (!pool) return SOCP_ERR_ARG;
@@ -195,18 +202,8 @@ extern "C" int socp_chains_solve_ex(socp_ctx *ctx, int P, const socp_chain_optio
         c.solver = socp_hybr_pool_get(pool, p);
         c.committed.assign(Z0 + (size_t)p * n, Z0 + (size_t)(p + 1) * n);
         c.eval_x.resize(n); c.slot_x.resize(n);
-        if (pp_params) {
-            double *blk = &pblock[(size_t)p * stride];
-            std::memcpy(blk, params ? params + (size_t)p * nparams : shared_params, sizeof(double) * nparams);
-            blk[nparams] = shared_sw[0]; blk[nparams + 1] = shared_sw[1];
-            rstart[p] = kind == SOCP_CHAIN_PARAM ? blk[opt->param_index] : 0.0;
-        }
-        if (pp_bound && kind != SOCP_CHAIN_DATA) {
-            std::memcpy(&tblock[(size_t)p * nodes], time_goal + (size_t)p * nodes, sizeof(double) * nodes);
-            std::memcpy(&xblock[(size_t)p * nodes * S], x_goal + (size_t)p * nodes * S, sizeof(double) * nodes * S);
-        }
         if (kind != SOCP_CHAIN_PLAIN) { c.b = std::min(opt->step, 1.0); c.b_prec = 0; }
-        set_blocks(p);
+        blk.set(p, c.b);
         if (c.solver) socp_hybr_start(c.solver, c.committed.data(), nullptr);
     });
     auto cleanup = [&]() { for (Chain &c : ch) c.solver = nullptr; socp_hybr_pool_destroy(pool); pool = nullptr; };
@@ -315,39 +312,16 @@ extern "C" int socp_chains_solve_ex(socp_ctx *ctx, int P, const socp_chain_optio
     const double t_setup = ms_since(t_begin);
     int rc = SOCP_OK;
 
-    // chain logic at the end of one Newton solve: the bisection rules of shooting.cpp:627-660 / 724-760
+    // chain logic at the end of one Newton solve (chains_common.hpp: the bisection rules of shooting.cpp:627-660 / 724-760)
     auto solve_finished = [&](int p) {
         Chain &c = ch[p];
-        c.info = socp_hybr_info(c.solver);
-        c.nfev_last = socp_hybr_nfev(c.solver);
-        c.nfev_total += c.nfev_last;
-        c.solves++;
-        const double *x = socp_hybr_x(c.solver);
-        if (kind == SOCP_CHAIN_PLAIN) {
-            c.committed.assign(x, x + n);                         // multi-start: the final iterate, whatever info says
-            c.finished = true;
-            return;
-        }
-        if (c.info < 0) { c.finished = true; return; }             // aborted (round limit): no further homotopy step
-        bool running = true;
         std::vector<double> next;                                  // tab_param_temp for the next solve
-        if (c.info != 1) {
-            if (std::fabs(c.b - c.b_prec) < opt->step_min) running = false;
-            // the halving has stopped moving b (only reachable with step_min = 0, where the reference's loop never ends)
-            if (c.b == c.b_prec) running = false;
-            c.b = c.b_prec + (c.b - c.b_prec) / 2;
-            next = c.committed;
-        } else if (c.b == 1) {
-            running = false;
-            c.committed.assign(x, x + n);
-        } else {
-            c.b_prec = c.b;
-            c.b = std::min(c.b + opt->step, 1.0);
-            c.committed.assign(x, x + n);
-            next = c.committed;
-        }
-        set_blocks(p);                                             // the reference also moves Rdata / the boundary data on the failing exit
-        if (!running) { c.finished = true; return; }
+        const double *f = socp_hybr_fvec(c.solver);
+        double ss = 0;
+        for (int i = 0; i < n; i++) ss += f[i] * f[i];
+        c.fnorm = std::sqrt(ss);
+        if (!socp::chains::after_solve(*opt, blk, p, c, socp_hybr_x(c.solver), n, socp_hybr_info(c.solver), socp_hybr_nfev(c.solver),
+                                       socp_hybr_njev(c.solver), next)) return;
         socp_hybr_start(c.solver, next.data(), nullptr);
         c.slot_valid = false;                                      // another problem now: cached rows are not its rows
         c.stage_idx = -1;
@@ -459,22 +433,14 @@ extern "C" int socp_chains_solve_ex(socp_ctx *ctx, int P, const socp_chain_optio
         for (int k = 0; k < kF; k++) {
             const int p = q.reqF[k];
             std::memcpy(q.hX.d() + (size_t)k * n, ch[p].xin, rowB);
-            if (pp_params) std::memcpy(q.hPF.d() + (size_t)k * stride, &pblock[(size_t)p * stride], sizeof(double) * stride);
-            if (pp_bound) {
-                std::memcpy(q.hTF.d() + (size_t)k * nodes, &tblock[(size_t)p * nodes], sizeof(double) * nodes);
-                std::memcpy(q.hXF.d() + (size_t)k * nodes * S, &xblock[(size_t)p * nodes * S], sizeof(double) * nodes * S);
-            }
+            blk.stage(p, k, q.hPF.d(), q.hTF.d(), q.hXF.d());
             if (k < kS) { std::memcpy(ch[p].eval_x.data(), ch[p].xin, rowB); ch[p].stage_idx = k; }
         }
         for (int k = 0; k < kJ; k++) {
             const int p = q.reqJ[k];
             std::memcpy(q.hJx.d() + (size_t)k * n, ch[p].xin, rowB);
             std::memcpy(q.hJf.d() + (size_t)k * n, socp_hybr_fvec(ch[p].solver), rowB);
-            if (pp_params) std::memcpy(q.hPJ.d() + (size_t)k * stride, &pblock[(size_t)p * stride], sizeof(double) * stride);
-            if (pp_bound) {
-                std::memcpy(q.hTJ.d() + (size_t)k * nodes, &tblock[(size_t)p * nodes], sizeof(double) * nodes);
-                std::memcpy(q.hXJ.d() + (size_t)k * nodes * S, &xblock[(size_t)p * nodes * S], sizeof(double) * nodes * S);
-            }
+            blk.stage(p, k, q.hPJ.d(), q.hTJ.d(), q.hXJ.d());
         }
         t_adv += ms_since(ta);
         int r = SOCP_OK;
@@ -591,16 +557,11 @@ extern "C" int socp_chains_solve_ex(socp_ctx *ctx, int P, const socp_chain_optio
             info[p] = c.info;
             if (nfev_last) nfev_last[p] = c.nfev_last;
             if (nfev_total) nfev_total[p] = c.nfev_total;
-            if (njev_last) njev_last[p] = socp_hybr_njev(c.solver);
+            if (njev_last) njev_last[p] = c.njev_last;
             if (solves) solves[p] = c.solves;
             if (b_reached) b_reached[p] = kind == SOCP_CHAIN_PLAIN ? 1.0 : (c.info == 1 ? c.b : c.b_prec);
-            if (param_final) param_final[p] = kind == SOCP_CHAIN_PARAM ? pblock[(size_t)p * stride + opt->param_index] : 0.0;
-            if (fnorm) {
-                const double *f = socp_hybr_fvec(c.solver);
-                double s = 0;
-                for (int i = 0; i < n; i++) s += f[i] * f[i];
-                fnorm[p] = std::sqrt(s);
-            }
+            if (param_final) param_final[p] = kind == SOCP_CHAIN_PARAM ? blk.pblock[(size_t)p * stride + opt->param_index] : 0.0;
+            if (fnorm) fnorm[p] = c.fnorm;
         }
     }
     for (int p = 0; p < P; p++) restarts += std::max(0, ch[p].solves - 1);

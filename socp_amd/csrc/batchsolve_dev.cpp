@@ -1,0 +1,303 @@
+// batchsolve_dev.cpp -- the lock-step engine with the Newton solvers ON THE DEVICE (VERDICT r2 "Next" #2).
+//
+// batchsolve.cpp advances P resumable hybrd state machines on the host: for sweeps of n = 85 .. 253 that is 75-90 % of the wall
+// time (P factorisations per Jacobian refresh on <= 16 host threads) plus P n^2 doubles over PCIe per refresh (237 MB at
+// n = 85, 1 GB at n = 253).  Here the state machines live in HBM (solver_dev.hpp: one workgroup per problem, MINPACK's
+// per-column / per-row operation order kept, so every chain follows the host engine's iterates bit for bit):
+//
+//   per round:  advance kernel (all chains that received what they asked for)
+//               -> states back to the host (48 B per chain: which request is pending)
+//               -> host: request lists in chain order, homotopy logic of chains whose solve ended (restart / retire)
+//               -> gather the evaluation points on the device, ONE residual launch, ONE Jacobian launch (two streams),
+//                  scatter the results into the problems' workspaces (the Jacobian transposed into the solver's row-major
+//                  matrix on the way).  No Jacobian, factor or iterate ever crosses PCIe.
+//
+// The chain logic (continuation homotopy, bisection, per-chain parameter / boundary blocks) is the host engine's
+// (chains_common.hpp).  Not here: speculative FD rows and chain groups (they pay at n = 14, where this engine is not chosen).
+#include "../../include/socp_hip.h"
+#include "../../include/socp_solver.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "chains_common.hpp"
+#include "solver_launch.hpp"
+
+namespace {
+
+using socp::devsolver::PoolDev;
+using socp::devsolver::State;
+
+struct Pinned {
+    void *p = nullptr;
+    bool alloc(size_t bytes) { return hipHostMalloc(&p, bytes ? bytes : 8, hipHostMallocDefault) == hipSuccess; }
+    ~Pinned() { if (p) (void)hipHostFree(p); }
+    double *d() const { return static_cast<double *>(p); }
+    int *i() const { return static_cast<int *>(p); }
+};
+struct Dev {
+    void *p = nullptr;
+    bool alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8) == hipSuccess; }
+    ~Dev() { if (p) (void)hipFree(p); }
+    double *d() const { return static_cast<double *>(p); }
+    int *i() const { return static_cast<int *>(p); }
+};
+
+}  // namespace
+
+// Same contract as socp_chains_solve_ex (include/socp_solver.h); called from there when the device solvers are chosen.
+int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt, const double *Z0, const double *params,
+                             const double *goal, const double *time_prev, const double *x_prev, const double *time_goal,
+                             const double *x_goal, double *Zout, int *info, int *nfev_last, int *nfev_total, int *njev_last,
+                             int *solves, double *b_reached, double *param_final, double *fnorm, socp_chain_stats *stats)
+{
+    using clk = std::chrono::steady_clock;
+    const clk::time_point t_begin = clk::now();
+    auto ms_since = [](clk::time_point t) { return std::chrono::duration<double, std::milli>(clk::now() - t).count(); };
+    static const bool trace = std::getenv("SOCP_MULTISTART_TRACE") != nullptr;
+
+    const int n = socp_problem_num_param(ctx), nodes = socp_problem_num_nodes(ctx);
+    int dim = 0, S = 0;
+    socp_ctx_dims(ctx, &dim, &S, nullptr);
+    const int nparams = socp_ctx_num_params(ctx), kind = opt->kind;
+    double shared_params[SOCP_MAX_NPARAMS + 2] = {0}, shared_sw[2] = {0, 0};
+    if (socp_ctx_get_params(ctx, shared_params, nparams) != SOCP_OK) return SOCP_ERR_ARG;
+    socp_ctx_get_switching_times(ctx, shared_sw);
+
+    struct DeviceGuard {
+        int prev = -1;
+        bool ok = false;
+        explicit DeviceGuard(int dev) { ok = hipGetDevice(&prev) == hipSuccess && hipSetDevice(dev) == hipSuccess; }
+        ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    } device_guard(socp_ctx_device(ctx));
+    if (!device_guard.ok) return SOCP_ERR_HIP;
+
+    socp::chains::Blocks blk;
+    blk.init(P, *opt, nparams, nodes, S, dim, params, shared_params, shared_sw, goal, time_prev, x_prev, time_goal, x_goal);
+    const bool pp_params = blk.pp_params, pp_bound = blk.pp_bound;
+    const int stride = blk.stride;
+
+    std::vector<socp::chains::ChainCore> ch(P);
+    for (int p = 0; p < P; p++) {
+        ch[p].committed.assign(Z0 + (size_t)p * n, Z0 + (size_t)(p + 1) * n);
+        if (kind != SOCP_CHAIN_PLAIN) { ch[p].b = std::min(opt->step, 1.0); ch[p].b_prec = 0; }
+        blk.set(p, ch[p].b);
+    }
+
+    // ---- the pool of device solvers and the round's buffers -----------------------------------------------------------
+    PoolDev pool;
+    pool.cfg.n = n; pool.cfg.ld = socp::devsolver::ld_for(n); pool.cfg.maxfev = opt->maxfev; pool.cfg.mode = 1;
+    pool.cfg.analytic = opt->analytic_jac ? 1 : 0; pool.cfg.xtol = opt->xtol; pool.cfg.epsfcn = opt->epsfcn; pool.cfg.factor = opt->factor;
+    pool.ws_stride = socp::devsolver::ws_doubles(n, pool.cfg.ld);
+    pool.P = P;
+    const size_t rowB = sizeof(double) * n, jacB = rowB * n;
+    // Jacobians of a round: one launch whenever they fit 8 GiB (batchsolve.cpp has the measurement), else passes
+    const int jlaunch = (int)std::max<size_t>(1, std::min<size_t>((size_t)P, ((size_t)8 << 30) / jacB));
+
+    void *main_stream_v = nullptr;
+    if (socp_ctx_synchronize(ctx) != SOCP_OK || socp_ctx_get_stream(ctx, &main_stream_v) != SOCP_OK) return SOCP_ERR_HIP;
+    hipStream_t main_stream = static_cast<hipStream_t>(main_stream_v), fs = nullptr;
+
+    Dev dWs, dStates, dList, dFlags, dListF, dListJ, dX, dF, dJx, dJf, dJ, dRes, dPF, dTF, dXF, dPJ, dTJ, dXJ;
+    Pinned hStates, hList, hFlags, hListF, hListJ, hX, hRes, hPF, hTF, hXF, hPJ, hTJ, hXJ;
+    bool ok = dWs.alloc(sizeof(double) * pool.ws_stride * P) && dStates.alloc(sizeof(State) * P) && dList.alloc(sizeof(int) * P) &&
+              dFlags.alloc(sizeof(int) * P) && dListF.alloc(sizeof(int) * P) && dListJ.alloc(sizeof(int) * P) && dX.alloc(rowB * P) &&
+              dF.alloc(rowB * P) && dJx.alloc(rowB * P) && dJf.alloc(rowB * P) && dJ.alloc(jacB * jlaunch) && dRes.alloc(2 * rowB * P) &&
+              hStates.alloc(sizeof(State) * P) && hList.alloc(sizeof(int) * P) && hFlags.alloc(sizeof(int) * P) &&
+              hListF.alloc(sizeof(int) * P) && hListJ.alloc(sizeof(int) * P) && hX.alloc(rowB * P) && hRes.alloc(2 * rowB * P);
+    if (ok && pp_params) ok = dPF.alloc(sizeof(double) * stride * P) && dPJ.alloc(sizeof(double) * stride * P) &&
+                              hPF.alloc(sizeof(double) * stride * P) && hPJ.alloc(sizeof(double) * stride * P);
+    if (ok && pp_bound) ok = dTF.alloc(sizeof(double) * nodes * P) && dTJ.alloc(sizeof(double) * nodes * P) &&
+                             dXF.alloc(sizeof(double) * nodes * S * P) && dXJ.alloc(sizeof(double) * nodes * S * P) &&
+                             hTF.alloc(sizeof(double) * nodes * P) && hTJ.alloc(sizeof(double) * nodes * P) &&
+                             hXF.alloc(sizeof(double) * nodes * S * P) && hXJ.alloc(sizeof(double) * nodes * S * P);
+    if (ok) ok = hipStreamCreateWithFlags(&fs, hipStreamNonBlocking) == hipSuccess;
+    if (!ok) { (void)hipGetLastError(); if (fs) (void)hipStreamDestroy(fs); return SOCP_ERR_HIP; }
+    pool.states = static_cast<State *>(dStates.p);
+    pool.ws = dWs.d();
+    State *hS = static_cast<State *>(hStates.p);
+
+    int rc = SOCP_OK;
+    long long rounds = 0, jac_launched = 0, restarts = 0;
+    bool round_limit_hit = false;
+    double t_adv = 0, t_eval = 0, t_host = 0;
+    const double t_setup = ms_since(t_begin);
+    auto hip_ok = [&](hipError_t e) { if (e != hipSuccess && rc == SOCP_OK) rc = SOCP_ERR_HIP; return e == hipSuccess; };
+
+    // (re)start the chains in `list` from their rows of hX (list order) -- they then need an advance
+    std::vector<int> adv, advflag, reqF, reqJ, done, restart;
+    auto start_chains = [&](const std::vector<int> &list) {
+        if (list.empty()) return;
+        std::memcpy(hList.p, list.data(), sizeof(int) * list.size());
+        hip_ok(hipMemcpyAsync(dList.p, hList.p, sizeof(int) * list.size(), hipMemcpyHostToDevice, main_stream));
+        hip_ok(hipMemcpyAsync(dX.p, hX.p, rowB * list.size(), hipMemcpyHostToDevice, main_stream));
+        hip_ok(socp::devsolver::launch_start(main_stream, pool, dList.i(), (int)list.size(), dX.d()));
+    };
+
+    {
+        std::vector<int> all(P);
+        for (int p = 0; p < P; p++) { all[p] = p; std::memcpy(hX.d() + (size_t)p * n, ch[p].committed.data(), rowB); }
+        hip_ok(hipMemsetAsync(dStates.p, 0, sizeof(State) * P, main_stream));
+        start_chains(all);
+        adv = all;
+        advflag.assign(P, 0);
+    }
+
+    while (rc == SOCP_OK) {
+        // ---- advance until every live chain has one pending evaluation request -------------------------------------------
+        reqF.clear(); reqJ.clear();
+        while (!adv.empty() && rc == SOCP_OK) {
+            const clk::time_point ta = clk::now();
+            const int count = (int)adv.size();
+            std::memcpy(hList.p, adv.data(), sizeof(int) * count);
+            std::memcpy(hFlags.p, advflag.data(), sizeof(int) * count);
+            hip_ok(hipMemcpyAsync(dList.p, hList.p, sizeof(int) * count, hipMemcpyHostToDevice, main_stream));
+            hip_ok(hipMemcpyAsync(dFlags.p, hFlags.p, sizeof(int) * count, hipMemcpyHostToDevice, main_stream));
+            hip_ok(socp::devsolver::launch_advance(main_stream, pool, dList.i(), count, dFlags.i()));
+            hip_ok(hipMemcpyAsync(hStates.p, dStates.p, sizeof(State) * P, hipMemcpyDeviceToHost, main_stream));
+            hip_ok(hipStreamSynchronize(main_stream));
+            t_adv += ms_since(ta);
+            if (rc != SOCP_OK) break;
+            const clk::time_point th = clk::now();
+            done.clear();
+            for (int p : adv) {
+                const int rq = hS[p].req;
+                if (rq == socp::devsolver::RQ_FVEC) reqF.push_back(p);
+                else if (rq == socp::devsolver::RQ_JAC) reqJ.push_back(p);
+                else done.push_back(p);
+            }
+            adv.clear(); advflag.clear();
+            if (!done.empty()) {
+                // results of the solves that ended: x and fvec of those chains, then the homotopy logic on the host
+                std::memcpy(hList.p, done.data(), sizeof(int) * done.size());
+                hip_ok(hipMemcpyAsync(dList.p, hList.p, sizeof(int) * done.size(), hipMemcpyHostToDevice, main_stream));
+                hip_ok(socp::devsolver::launch_gather_result(main_stream, pool, dList.i(), (int)done.size(), dRes.d()));
+                hip_ok(hipMemcpyAsync(hRes.p, dRes.p, 2 * rowB * done.size(), hipMemcpyDeviceToHost, main_stream));
+                hip_ok(hipStreamSynchronize(main_stream));
+                if (rc != SOCP_OK) break;
+                restart.clear();
+                std::vector<double> next;
+                for (size_t k = 0; k < done.size(); k++) {
+                    const int p = done[k];
+                    const double *x = hRes.d() + 2 * (size_t)n * k, *f = x + n;
+                    double ss = 0;
+                    for (int i = 0; i < n; i++) ss += f[i] * f[i];
+                    ch[p].fnorm = std::sqrt(ss);
+                    if (socp::chains::after_solve(*opt, blk, p, ch[p], x, n, hS[p].info, hS[p].nfev, hS[p].njev, next)) {
+                        std::memcpy(hX.d() + (size_t)restart.size() * n, next.data(), rowB);
+                        restart.push_back(p);
+                    }
+                }
+                restarts += (long long)restart.size();
+                start_chains(restart);
+                adv = restart;
+                advflag.assign(adv.size(), 0);
+            }
+            t_host += ms_since(th);
+        }
+        if (rc != SOCP_OK) break;
+        // chain order keeps the batches those of the host engine (a restarted chain's request arrives in a later inner pass)
+        std::sort(reqF.begin(), reqF.end());
+        std::sort(reqJ.begin(), reqJ.end());
+        const int kF = (int)reqF.size(), kJ = (int)reqJ.size();
+        if (kF == 0 && kJ == 0) break;
+        if (opt->max_rounds > 0 && rounds >= opt->max_rounds) {
+            // round budget spent: the chains still solving stop the way a negative callback return stops hybrd
+            round_limit_hit = true;
+            adv = reqF;
+            adv.insert(adv.end(), reqJ.begin(), reqJ.end());
+            advflag.assign(adv.size(), SOCP_INFO_ROUND_LIMIT);
+            continue;
+        }
+        rounds++;
+        if (trace) std::fprintf(stderr, "[socp_chains/device] round %lld: %d residual requests, %d Jacobian requests\n", rounds, kF, kJ);
+        const clk::time_point te = clk::now();
+        // ---- residual requests: stream fs ------------------------------------------------------------------------------------
+        if (kF) {
+            std::memcpy(hListF.p, reqF.data(), sizeof(int) * kF);
+            for (int k = 0; k < kF; k++) blk.stage(reqF[k], k, hPF.d(), hTF.d(), hXF.d());
+            hip_ok(hipMemcpyAsync(dListF.p, hListF.p, sizeof(int) * kF, hipMemcpyHostToDevice, fs));
+            if (pp_params) hip_ok(hipMemcpyAsync(dPF.p, hPF.p, sizeof(double) * stride * kF, hipMemcpyHostToDevice, fs));
+            if (pp_bound) {
+                hip_ok(hipMemcpyAsync(dTF.p, hTF.p, sizeof(double) * nodes * kF, hipMemcpyHostToDevice, fs));
+                hip_ok(hipMemcpyAsync(dXF.p, hXF.p, sizeof(double) * nodes * S * kF, hipMemcpyHostToDevice, fs));
+            }
+            hip_ok(socp::devsolver::launch_gather_eval(fs, pool, dListF.i(), kF, dX.d()));
+            socp_ctx_set_stream(ctx, fs, 0);
+            socp_problem_set_blocks_dev(ctx, pp_params ? dPF.d() : nullptr, stride, pp_bound ? dTF.d() : nullptr, pp_bound ? dXF.d() : nullptr);
+            const int r = socp_residual_batch_dev(ctx, kF, dX.d(), dF.d());
+            socp_ctx_set_stream(ctx, main_stream, 0);
+            if (r != SOCP_OK) { rc = r; break; }
+            hip_ok(socp::devsolver::launch_scatter_fvec(fs, pool, dListF.i(), kF, dF.d()));
+        }
+        // ---- Jacobian requests: the context's stream, in passes of jlaunch -----------------------------------------------------
+        if (kJ) {
+            std::memcpy(hListJ.p, reqJ.data(), sizeof(int) * kJ);
+            for (int k = 0; k < kJ; k++) blk.stage(reqJ[k], k, hPJ.d(), hTJ.d(), hXJ.d());
+            hip_ok(hipMemcpyAsync(dListJ.p, hListJ.p, sizeof(int) * kJ, hipMemcpyHostToDevice, main_stream));
+            if (pp_params) hip_ok(hipMemcpyAsync(dPJ.p, hPJ.p, sizeof(double) * stride * kJ, hipMemcpyHostToDevice, main_stream));
+            if (pp_bound) {
+                hip_ok(hipMemcpyAsync(dTJ.p, hTJ.p, sizeof(double) * nodes * kJ, hipMemcpyHostToDevice, main_stream));
+                hip_ok(hipMemcpyAsync(dXJ.p, hXJ.p, sizeof(double) * nodes * S * kJ, hipMemcpyHostToDevice, main_stream));
+            }
+            hip_ok(socp::devsolver::launch_gather_jac(main_stream, pool, dListJ.i(), kJ, dJx.d(), dJf.d()));
+            for (int j0 = 0; j0 < kJ && rc == SOCP_OK; j0 += jlaunch) {
+                const int kc = std::min(jlaunch, kJ - j0);
+                socp_problem_set_blocks_dev(ctx, pp_params ? dPJ.d() + (size_t)j0 * stride : nullptr, stride,
+                                            pp_bound ? dTJ.d() + (size_t)j0 * nodes : nullptr, pp_bound ? dXJ.d() + (size_t)j0 * nodes * S : nullptr);
+                const int r = opt->analytic_jac
+                                  ? socp_var_jacobian_multi_dev(ctx, kc, dJx.d() + (size_t)j0 * n, dJ.d())
+                                  : socp_fd_jacobian_multi_dev(ctx, kc, dJx.d() + (size_t)j0 * n, dJf.d() + (size_t)j0 * n, opt->epsfcn, dJ.d(), opt->dedup);
+                if (r != SOCP_OK) { rc = r; break; }
+                hip_ok(socp::devsolver::launch_scatter_jac(main_stream, pool, dListJ.i() + j0, kc, dJ.d()));
+            }
+            jac_launched += kJ;
+        }
+        if (rc != SOCP_OK) break;
+        hip_ok(hipStreamSynchronize(fs));
+        hip_ok(hipStreamSynchronize(main_stream));
+        t_eval += ms_since(te);
+        adv = reqF;
+        adv.insert(adv.end(), reqJ.begin(), reqJ.end());
+        std::sort(adv.begin(), adv.end());
+        advflag.assign(adv.size(), 0);
+    }
+    socp_problem_set_blocks_dev(ctx, nullptr, 0, nullptr, nullptr);
+    socp_ctx_set_stream(ctx, main_stream, 0);
+    (void)hipStreamSynchronize(fs);
+    (void)hipStreamSynchronize(main_stream);
+    (void)hipStreamDestroy(fs);
+
+    if (rc == SOCP_OK) {
+        for (int p = 0; p < P; p++) {
+            const socp::chains::ChainCore &c = ch[p];
+            std::memcpy(Zout + (size_t)p * n, c.committed.data(), rowB);
+            info[p] = c.info;
+            if (nfev_last) nfev_last[p] = c.nfev_last;
+            if (nfev_total) nfev_total[p] = c.nfev_total;
+            if (njev_last) njev_last[p] = c.njev_last;
+            if (solves) solves[p] = c.solves;
+            if (b_reached) b_reached[p] = kind == SOCP_CHAIN_PLAIN ? 1.0 : (c.info == 1 ? c.b : c.b_prec);
+            if (param_final) param_final[p] = kind == SOCP_CHAIN_PARAM ? blk.pblock[(size_t)p * stride + opt->param_index] : 0.0;
+            if (fnorm) fnorm[p] = c.fnorm;
+        }
+    }
+    if (trace && round_limit_hit) std::fprintf(stderr, "[socp_chains/device] round limit %d reached: the chains still solving were stopped\n", opt->max_rounds);
+    if (trace)
+        std::fprintf(stderr, "[socp_chains/device] set-up %.1f ms, solver kernels + state read-back %.1f ms, evaluation launches %.1f ms, host chain logic %.1f ms, "
+                             "total %.1f ms; %lld rounds, %lld Jacobians, %lld solver restarts; %d threads per problem, %.1f MB of solver state\n",
+                     t_setup, t_adv, t_eval, t_host, ms_since(t_begin), rounds, jac_launched, restarts, socp::devsolver::threads_for(n),
+                     1e-6 * sizeof(double) * pool.ws_stride * P);
+    if (stats) {
+        stats->rounds = rounds; stats->jacobians_launched = jac_launched; stats->jacobians_from_cache = 0;
+        stats->speculative_rounds = 0; stats->restarts = restarts; stats->wall_ms = ms_since(t_begin);
+    }
+    return rc;
+}

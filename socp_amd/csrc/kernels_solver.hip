@@ -1,0 +1,144 @@
+// kernels_solver.hip -- the Powell hybrid iteration of many small problems on the device (solver_dev.hpp): one workgroup per
+// problem.  MUST be compiled with -ffp-contract=off: every iterate has to equal the host solver's (minpack.cpp) bit for bit.
+#include "solver_launch.hpp"
+
+namespace socp {
+namespace devsolver {
+
+namespace {
+
+__global__ void start_kernel(Config c, State *states, double *ws, long ws_stride, const int *__restrict__ list, const double *__restrict__ X0)
+{
+    const int p = list[blockIdx.x];
+    BlockExec ex;
+    start(ex, c, states[p], ws + (long)p * ws_stride, X0 + (long)blockIdx.x * c.n);
+}
+
+__global__ void advance_kernel(Config c, State *states, double *ws, long ws_stride, const int *__restrict__ list, const int *__restrict__ flags)
+{
+    const int p = list[blockIdx.x];
+    BlockExec ex;
+    Machine<BlockExec> m(ex, c, states[p], ws + (long)p * ws_stride);
+    m.advance(flags ? flags[blockIdx.x] : 0);
+}
+
+__global__ void gather_eval_kernel(Config c, const State *states, double *ws, long ws_stride, const int *__restrict__ list, double *__restrict__ dst)
+{
+    const int p = list[blockIdx.x];
+    const Work w(ws + (long)p * ws_stride, c.n, c.ld);
+    const double *src = states[p].eval_sel ? w.wa2 : w.x;
+    for (int j = threadIdx.x; j < c.n; j += blockDim.x) dst[(long)blockIdx.x * c.n + j] = src[j];
+}
+
+__global__ void scatter_fvec_kernel(Config c, const State *states, double *ws, long ws_stride, const int *__restrict__ list, const double *__restrict__ src)
+{
+    const int p = list[blockIdx.x];
+    const Work w(ws + (long)p * ws_stride, c.n, c.ld);
+    double *dst = states[p].eval_sel ? w.wa4 : w.fvec;
+    for (int j = threadIdx.x; j < c.n; j += blockDim.x) dst[j] = src[(long)blockIdx.x * c.n + j];
+}
+
+__global__ void gather_jac_kernel(Config c, double *ws, long ws_stride, const int *__restrict__ list, double *__restrict__ dX, double *__restrict__ dF)
+{
+    const int p = list[blockIdx.x];
+    const Work w(ws + (long)p * ws_stride, c.n, c.ld);
+    for (int j = threadIdx.x; j < c.n; j += blockDim.x) {
+        dX[(long)blockIdx.x * c.n + j] = w.x[j];
+        dF[(long)blockIdx.x * c.n + j] = w.fvec[j];
+    }
+}
+
+__global__ void gather_result_kernel(Config c, double *ws, long ws_stride, const int *__restrict__ list, double *__restrict__ out)
+{
+    const int p = list[blockIdx.x];
+    const Work w(ws + (long)p * ws_stride, c.n, c.ld);
+    for (int j = threadIdx.x; j < c.n; j += blockDim.x) {
+        out[(long)blockIdx.x * 2 * c.n + j] = w.x[j];
+        out[(long)blockIdx.x * 2 * c.n + c.n + j] = w.fvec[j];
+    }
+}
+
+// A[i][j] (row-major, stride ld) = J[i + n j] (column-major): 32 x 32 tiles through LDS so that both sides are accessed along
+// their contiguous direction.  grid = (tiles, tiles, count), block = (32, 8)
+__global__ void scatter_jac_kernel(Config c, double *ws, long ws_stride, const int *__restrict__ list, const double *__restrict__ J)
+{
+    __shared__ double tile[32][33];
+    const int p = list[blockIdx.z], n = c.n;
+    const double *src = J + (long)blockIdx.z * n * n;
+    double *A = ws + (long)p * ws_stride;
+    const int i0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
+    for (int jj = threadIdx.y; jj < 32; jj += 8) {           // read: consecutive threads along i (contiguous in J)
+        const int i = i0 + threadIdx.x, j = j0 + jj;
+        if (i < n && j < n) tile[jj][threadIdx.x] = src[i + (long)n * j];
+    }
+    __syncthreads();
+    for (int ii = threadIdx.y; ii < 32; ii += 8) {           // write: consecutive threads along j (contiguous in A)
+        const int i = i0 + ii, j = j0 + threadIdx.x;
+        if (i < n && j < n) A[(long)i * c.ld + j] = tile[threadIdx.x][ii];
+    }
+}
+
+}  // namespace
+
+int threads_for(int n)
+{
+    const int t = ((n + 1 + 63) / 64) * 64;
+    return t > 1024 ? 1024 : t;
+}
+
+hipError_t launch_start(hipStream_t st, const PoolDev &pool, const int *d_list, int count, const double *d_X0)
+{
+    if (count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(start_kernel, dim3(count), dim3(64), 0, st, pool.cfg, pool.states, pool.ws, pool.ws_stride, d_list, d_X0);
+    return hipGetLastError();
+}
+
+hipError_t launch_advance(hipStream_t st, const PoolDev &pool, const int *d_list, int count, const int *d_flags)
+{
+    if (count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(advance_kernel, dim3(count), dim3(threads_for(pool.cfg.n)), 0, st, pool.cfg, pool.states, pool.ws, pool.ws_stride, d_list, d_flags);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_eval(hipStream_t st, const PoolDev &pool, const int *d_list, int count, double *d_dst)
+{
+    if (count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_eval_kernel, dim3(count), dim3(64), 0, st, pool.cfg, pool.states, pool.ws, pool.ws_stride, d_list, d_dst);
+    return hipGetLastError();
+}
+
+hipError_t launch_scatter_fvec(hipStream_t st, const PoolDev &pool, const int *d_list, int count, const double *d_src)
+{
+    if (count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(scatter_fvec_kernel, dim3(count), dim3(64), 0, st, pool.cfg, pool.states, pool.ws, pool.ws_stride, d_list, d_src);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_jac(hipStream_t st, const PoolDev &pool, const int *d_list, int count, double *d_X, double *d_F)
+{
+    if (count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_jac_kernel, dim3(count), dim3(64), 0, st, pool.cfg, pool.ws, pool.ws_stride, d_list, d_X, d_F);
+    return hipGetLastError();
+}
+
+hipError_t launch_scatter_jac(hipStream_t st, const PoolDev &pool, const int *d_list, int count, const double *d_J)
+{
+    if (count <= 0) return hipSuccess;
+    const unsigned tiles = (unsigned)((pool.cfg.n + 31) / 32);
+    for (int k0 = 0; k0 < count; k0 += 32768) {              // grid.z is limited to 65535
+        const int kc = count - k0 < 32768 ? count - k0 : 32768;
+        hipLaunchKernelGGL(scatter_jac_kernel, dim3(tiles, tiles, (unsigned)kc), dim3(32, 8), 0, st, pool.cfg, pool.ws, pool.ws_stride, d_list + k0,
+                           d_J + (long)k0 * pool.cfg.n * pool.cfg.n);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_result(hipStream_t st, const PoolDev &pool, const int *d_list, int count, double *d_out)
+{
+    if (count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_result_kernel, dim3(count), dim3(64), 0, st, pool.cfg, pool.ws, pool.ws_stride, d_list, d_out);
+    return hipGetLastError();
+}
+
+}  // namespace devsolver
+}  // namespace socp

@@ -82,7 +82,11 @@ struct SerialExec {
     SOCP_HD void sync() const {}
 };
 
-#define SOCP_PAR_FOR(i, lo, hi) for (int i = (lo) + ex.tid; i < (hi); i += ex.nt)
+// Elements are dealt out by ABSOLUTE index: element i belongs to thread i mod nt whatever the loop bounds are.  r1updt relies
+// on it (a thread keeps "its" w[i] and s(., i) across rotation steps without a barrier), and a thread re-visits the same
+// columns of A from reflector to reflector.
+SOCP_HD int par_first(int lo, int tid, int nt) { return lo + ((tid - lo % nt) + nt) % nt; }
+#define SOCP_PAR_FOR(i, lo, hi) for (int i = par_first((lo), ex.tid, ex.nt); i < (hi); i += ex.nt)
 
 constexpr double kEpsMch = DBL_EPSILON;
 constexpr double kGiant = DBL_MAX;
@@ -306,7 +310,7 @@ SOCP_HD bool r1updt(const E &ex, int n, Work &wk)
             givens(vn, vj, cs, sn, tau);
             vn = sn * vj + cs * vn;
         }
-        if (ex.tid == 0) rot[j] = tau;
+        if (ex.tid == 0) rot[j] = tau;                       // (read again only after a barrier, in r1mpyq_all)
         if (vj != 0) {
             SOCP_PAR_FOR(i, j, n) {
                 const long l = jj + (i - j);

@@ -1,0 +1,37 @@
+// solver_launch.hpp -- host-callable launchers of the device Powell iteration (kernels_solver.hip) for the lock-step engine
+// (batchsolve_dev.cpp).  A pool = P problems of one size n: states[P], workspaces[P][ws_stride] in HBM.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "solver_dev.hpp"
+
+namespace socp {
+namespace devsolver {
+
+struct PoolDev {
+    Config cfg;
+    State *states = nullptr;       // [P]
+    double *ws = nullptr;          // [P][ws_stride]
+    long ws_stride = 0;
+    int P = 0;
+};
+
+int threads_for(int n);            // workgroup size of the per-problem kernels: n + 1 columns rounded up to whole waves, <= 1024
+
+// problems list[0 .. count): (re)start from X0[k][n] (k = position in the list)
+hipError_t launch_start(hipStream_t st, const PoolDev &pool, const int *d_list, int count, const double *d_X0);
+// advance the state machines of list[0 .. count); d_flags[k] (may be null = 0): what the pending evaluation returned
+hipError_t launch_advance(hipStream_t st, const PoolDev &pool, const int *d_list, int count, const int *d_flags);
+// dst[k][n] = the point problem list[k] asked to be evaluated (x, or the trial point)
+hipError_t launch_gather_eval(hipStream_t st, const PoolDev &pool, const int *d_list, int count, double *d_dst);
+// the residual of that evaluation back into the problem (fvec, or the trial residual)
+hipError_t launch_scatter_fvec(hipStream_t st, const PoolDev &pool, const int *d_list, int count, const double *d_src);
+// Jacobian requests: dX[k] = x, dF[k] = fvec of problem list[k]
+hipError_t launch_gather_jac(hipStream_t st, const PoolDev &pool, const int *d_list, int count, double *d_X, double *d_F);
+// column-major Jacobians J[k][n * n] (what the FD / variational kernels write) into the problems' row-major matrices
+hipError_t launch_scatter_jac(hipStream_t st, const PoolDev &pool, const int *d_list, int count, const double *d_J);
+// out[k] = [x (n) | fvec (n)] of problem list[k] (a finished solve's result)
+hipError_t launch_gather_result(hipStream_t st, const PoolDev &pool, const int *d_list, int count, double *d_out);
+
+}  // namespace devsolver
+}  // namespace socp

@@ -1,0 +1,146 @@
+"""CPU: the DEVICE Powell iteration (socp_amd/csrc/solver_dev.hpp -- what the gfx950 solver kernels run, one workgroup per
+problem) compiled for the host with one thread per problem (tests/tools/solver_sim.cpp) against the library's host solver
+(minpack.cpp, itself equal to SciPy's MINPACK bit for bit): same iterates, same factors, same counters -- to the last bit.
+This pins the ARITHMETIC of the device solver without a GPU; that the many-thread form computes the same is what
+tests/test_gpu_devsolver.py checks on the device."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from socp_amd import capi
+from test_minpack import CASES, rosen, rosen_jac, broyden_tri
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_dp = C.POINTER(C.c_double)
+FCN = C.CFUNCTYPE(C.c_int, C.c_int, _dp, _dp)
+JAC = C.CFUNCTYPE(C.c_int, C.c_int, _dp, _dp, _dp)
+
+
+@pytest.fixture(scope="module")
+def sim(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("solver_sim") / "libsolver_sim.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-o", so,
+                           os.path.join(ROOT, "tests", "tools", "solver_sim.cpp")])
+    L = C.CDLL(so)
+    L.sim_solve.argtypes = [C.c_int, _dp, _dp, C.c_double, C.c_int, C.c_double, C.c_double, C.c_int, FCN, JAC,
+                            C.POINTER(C.c_int), C.POINTER(C.c_int), _dp, _dp, _dp, _dp]
+    return L
+
+
+def fd_jacobian(f, x, fvec, epsfcn):
+    """MINPACK fdjac1, J[row, col]."""
+    eps = np.sqrt(max(epsfcn, np.finfo(float).eps))
+    n = len(x)
+    J = np.empty((n, n))
+    for j in range(n):
+        h = eps * abs(x[j]) or eps
+        xp = x.copy()
+        xp[j] = x[j] + h
+        J[:, j] = (f(xp) - fvec) / h
+    return J
+
+
+def sim_solve(L, f, jac, x0, xtol, factor, analytic, epsfcn=1e-15, maxfev=10000, abort_after=None):
+    n = len(x0)
+    x = np.array(x0, dtype=np.float64)
+    out = dict(fvec=np.zeros(n), fjac=np.zeros((n, n)), r=np.zeros(n * (n + 1) // 2), qtf=np.zeros(n), diag=np.zeros(n))
+    calls = [0]
+
+    def _f(nn, xp, fp):
+        calls[0] += 1
+        if abort_after is not None and calls[0] > abort_after:
+            return -7
+        np.ctypeslib.as_array(fp, shape=(nn,))[:] = f(np.ctypeslib.as_array(xp, shape=(nn,)).copy())
+        return 0
+
+    def _j(nn, xp, fp, jp):
+        xx = np.ctypeslib.as_array(xp, shape=(nn,)).copy()
+        J = jac(xx) if analytic else fd_jacobian(f, xx, np.ctypeslib.as_array(fp, shape=(nn,)).copy(), epsfcn)
+        np.ctypeslib.as_array(jp, shape=(nn, nn))[:] = np.asarray(J).T          # column-major
+        return 0
+    d = lambda a: a.ctypes.data_as(_dp)  # noqa: E731
+    nfev, njev = C.c_int(0), C.c_int(0)
+    info = L.sim_solve(n, d(x), d(out["fvec"]), xtol, maxfev, epsfcn, factor, int(analytic), FCN(_f), JAC(_j), C.byref(nfev), C.byref(njev),
+                       d(out["fjac"]), d(out["r"]), d(out["qtf"]), d(out["diag"]))
+    out.update(x=x, info=info, nfev=nfev.value, njev=njev.value)
+    return out
+
+
+def same(a, b):
+    for k in ("x", "fvec", "r", "qtf", "diag", "fjac"):
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+    assert a["info"] == b["info"] and a["nfev"] == b["nfev"]
+
+
+@pytest.mark.parametrize("name,f,x0", CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize("factor", [1.0, 100.0])
+def test_device_iteration_equals_host_hybrd(sim, name, f, x0, factor):
+    host = capi.hybrd(f, x0.copy(), xtol=1e-8, epsfcn=1e-15, factor=factor,
+                      fdjac=lambda x, fv, e: fd_jacobian(f, x, fv, e))
+    dev = sim_solve(sim, f, None, x0, 1e-8, factor, analytic=False)
+    same(dev, host)
+
+
+def test_device_iteration_equals_host_hybrj(sim):
+    x0 = np.array([-1.2, 1.0, -1.2, 1.0])
+    host = capi.hybrj(rosen, rosen_jac, x0.copy(), xtol=1e-8, factor=1.0)
+    dev = sim_solve(sim, rosen, rosen_jac, x0, 1e-8, 1.0, analytic=True)
+    same(dev, host)
+    assert dev["njev"] == host["njev"] >= 1
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 33, 130])
+def test_sizes_and_random_systems(sim, n):
+    """Mildly nonlinear random systems across the vector-length boundaries of the device layout (ld = n + 1 rounded up to 8):
+    many Jacobian refreshes, Broyden updates with zero and non-zero rotations, singular trial factors."""
+    rng = np.random.default_rng(n)
+    A = rng.normal(size=(n, n)) + 3 * np.eye(n)
+    b = rng.normal(size=n)
+
+    def f(x):
+        return A @ x + 0.3 * np.sin(x) * np.roll(x, 1) - b
+    x0 = rng.normal(size=n)
+    for xtol in (1e-8, 1e-13):
+        host = capi.hybrd(f, x0.copy(), xtol=xtol, epsfcn=1e-15, fdjac=lambda x, fv, e: fd_jacobian(f, x, fv, e))
+        dev = sim_solve(sim, f, None, x0, xtol, 1.0, analytic=False)
+        same(dev, host)
+
+
+def test_failure_paths_are_the_host_ones(sim):
+    """info 2 (maxfev), info 4 / 5 (no progress), a singular Jacobian (zero column -> identity reflector, zero pivot in the back
+    substitution), NaN residuals and a negative callback return: the state machine ends as the host one does."""
+    x0 = -np.ones(10)
+    host = capi.hybrd(broyden_tri, x0.copy(), xtol=1e-8, maxfev=15, epsfcn=1e-15)
+    dev = sim_solve(sim, broyden_tri, None, x0, 1e-8, 1.0, analytic=False, maxfev=15)
+    same(dev, host)
+    assert dev["info"] == 2
+
+    def flat(x):                       # the last unknown does not enter: zero Jacobian column
+        f = broyden_tri(x)
+        f[-1] = 1.0 + 0 * x[-1]
+        return f
+    host = capi.hybrd(flat, x0.copy(), xtol=1e-8, epsfcn=1e-15, fdjac=lambda x, fv, e: fd_jacobian(flat, x, fv, e))
+    dev = sim_solve(sim, flat, None, x0, 1e-8, 1.0, analytic=False)
+    same(dev, host)
+    assert dev["info"] in (4, 5)
+
+    def nanny(x):
+        f = broyden_tri(x)
+        f[3] = np.nan
+        return f
+    host = capi.hybrd(nanny, x0.copy(), xtol=1e-8, epsfcn=1e-15, fdjac=lambda x, fv, e: fd_jacobian(nanny, x, fv, e))
+    dev = sim_solve(sim, nanny, None, x0, 1e-8, 1.0, analytic=False)
+    same(dev, host)
+
+    calls = [0]
+
+    def stopper(x):
+        calls[0] += 1
+        return None if calls[0] > 4 else broyden_tri(x)
+    host = capi.hybrd(stopper, x0.copy(), xtol=1e-8, epsfcn=1e-15, fdjac=lambda x, fv, e: fd_jacobian(broyden_tri, x, fv, e))
+    dev = sim_solve(sim, broyden_tri, None, x0, 1e-8, 1.0, analytic=False, abort_after=4)
+    assert host["info"] == -1 and dev["info"] == -7          # the callback's own negative value becomes info (shooting.cpp:873)
+    assert np.array_equal(dev["x"], host["x"]) and np.array_equal(dev["fvec"], host["fvec"])

@@ -1,0 +1,190 @@
+"""GPU: the lock-step engine with the Newton solvers ON THE DEVICE (socp_chain_options.solver = SOCP_SOLVER_DEVICE:
+kernels_solver.hip, one workgroup per chain) against the same engine with the solvers on the host.  The bar is the one every
+engine feature has: no iterate changes -- unknowns, info, evaluation counts, homotopy state and |F| of every chain equal TO THE
+LAST BIT, for plain multi-start solves, both continuation kinds (bisection after failed solves included), forward-difference
+and variational Jacobians, fixed-step and adaptive integration, n from 14 to 253.  (The arithmetic of the device solver is
+pinned on the CPU by tests/test_devsolver_sim.py; this file checks the many-thread kernels and the engine around them.)"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+KEYS = ("z", "info", "nfev", "nfev_total", "njev", "solves", "b_reached", "param_final", "fnorm")
+
+
+def both(ctx, Z0, **kw):
+    from socp_amd import capi
+    host = ctx.chains_solve(Z0, solver=capi.SOLVER_HOST, speculate=0, **kw)
+    dev = ctx.chains_solve(Z0, solver=capi.SOLVER_DEVICE, **kw)
+    for k in KEYS:
+        assert np.array_equal(host[k], dev[k], equal_nan=True), k
+    assert host["stats"]["rounds"] == dev["stats"]["rounds"]
+    assert host["stats"]["jacobians_launched"] == dev["stats"]["jacobians_launched"]
+    return host, dev
+
+
+@pytest.mark.parametrize("variant", ["exact", "fast"])
+def test_single_shooting_sweep_n14(variant):
+    from socp_amd import capi, sweep
+    ctx = capi.Context(capi.MODEL_GODDARD)
+    ctx.set_params(sweep.GODDARD_PARAMS)
+    ctx.set_step_number(200)
+    ctx.set_variant(capi.VARIANT_LANE_EXACT if variant == "exact" else capi.VARIANT_LANE_FAST)
+    sweep.goddard_single_shooting_problem(ctx)
+    Z0 = sweep.goddard_starts(96, 3e-3)               # wide enough for failures (info 4 / 5) beside converged starts
+    host, dev = both(ctx, Z0, kind=capi.CHAIN_PLAIN, xtol=1e-8)
+    assert (dev["info"] == 1).sum() >= 60 and (dev["info"] != 1).sum() >= 1
+    ctx.close()
+
+
+@pytest.mark.parametrize("M,P", [(6, 70), (9, 40)])
+def test_multiple_shooting_sweeps(M, P):
+    """The testGoddard layout with M segments (n = 85, 127): Jacobian refreshes of thousands of columns, Broyden updates,
+    every start on the CPU path's root."""
+    from socp_amd import capi, sweep
+    ctx = capi.Context(capi.MODEL_GODDARD)
+    ctx.set_params(sweep.GODDARD_PARAMS)
+    ctx.set_step_number(10)
+    ctx.set_variant(capi.VARIANT_LANE_FAST)
+    n = sweep.goddard_multiple_shooting_problem(ctx, M)
+    assert n == 14 * M + 1
+    Z0 = sweep.goddard_multiple_shooting_starts(ctx, sweep.goddard_starts(P, 0.05), M)
+    host, dev = both(ctx, Z0, kind=capi.CHAIN_PLAIN, xtol=1e-10)
+    assert np.all(dev["info"] == 1)
+    ctx.close()
+
+
+def test_kd_continuation_chains_with_bisection():
+    """testGoddard's drag continuation as chains with their own goals (one far enough that solves fail and the step is halved):
+    restarts, per-chain parameter blocks and the bisection logic around the device solvers."""
+    from socp_amd import capi
+    from test_gpu_chains import STAGE2_INIT, PARAMS0, KD, goddard_m6, make_ctx
+    ctx = make_ctx("exact")
+    goddard_m6(ctx)
+    goals = np.array([310.0, 250.0, 400.0, 310.0, 120.0, 5000.0, 310.0, 600.0])
+    P = len(goals)
+    Z0 = np.tile(STAGE2_INIT, (P, 1))
+    Z0[3, 7:14] *= 1 + 1e-6
+    for step in (1.0, 0.4):
+        host, dev = both(ctx, Z0, kind=capi.CHAIN_PARAM, param_index=KD, step=step, goal=goals, params=np.tile(PARAMS0, (P, 1)), xtol=1e-6)
+        assert np.all(dev["info"][[0, 1, 2, 3, 4]] == 1)
+    assert np.max(dev["solves"]) > 1
+    gold2 = [g for g in json.load(open(os.path.join(ROOT, "tests", "golden", "goddard_flow.json")))["goddard_single_stage"]
+             if g["stage"] == 2 and g["xtol"] == 1e-6][0]
+    r = ctx.chains_solve(Z0[:1], kind=capi.CHAIN_PARAM, param_index=KD, step=1.0, goal=goals[:1], params=np.array(PARAMS0)[None, :], xtol=1e-6,
+                         solver=capi.SOLVER_DEVICE)
+    assert np.array_equal(r["z"][0], np.array(gold2["z"])) and r["nfev"][0] == gold2["nfev"]      # testGoddard's own stage 2, CPU golden
+    ctx.close()
+
+
+def test_boundary_data_chains():
+    from socp_amd import capi
+    from test_gpu_chains import GOLD, goddard_m6, make_ctx
+    ctx = make_ctx("exact")
+    ctx.set_param("KD", 310.0)
+    mode_t, mode_x, time, X = goddard_m6(ctx)
+    z_conv = np.array(GOLD["goddard_N10_M6"][1]["z"])
+    goals = np.array([1.0102, 1.0105, 1.011, 1.03])
+    P = len(goals)
+    Xp = np.tile(X.ravel(), (P, 1))
+    Xg = Xp.copy()
+    Xg[:, 6 * 14] = goals
+    Tp = np.tile(time, (P, 1))
+    for step in (1.0, 0.5):
+        both(ctx, np.tile(z_conv, (P, 1)), kind=capi.CHAIN_DATA, step=step, time_prev=Tp, x_prev=Xp, time_goal=Tp, x_goal=Xg, xtol=1e-6)
+    ctx.close()
+
+
+@pytest.mark.parametrize("order", [1, 0])
+def test_double_integrator_chains_hybrj_and_hybrd(order):
+    """The way-point layout with M = 5 segments (FREE interior and final times, n = 65): hybrj chains with the batched variational
+    Jacobian, and the same with forward differences, per-chain a_max / muT."""
+    from socp_amd import capi
+    ctx = capi.Context(capi.MODEL_DOUBLE_INTEGRATOR)
+    M = 5
+    mode_t = [capi.FIXED] + [capi.FREE] * M
+    mode_x = np.zeros((M + 1, 6), dtype=np.int32)
+    mode_x[1:M, 3:6] = capi.CONTINUOUS
+    X = np.zeros((M + 1, 12))
+    X[:, 0] = 20.0 * np.arange(M + 1) / M
+    X[:M, 6:] = 0.001
+    tn = 60.0 * np.arange(M + 1) / M
+    n = ctx.problem_set(mode_t, mode_x, tn, X)
+    z = np.concatenate([X[:M].ravel(), tn[1:]])
+    P = 6
+    rng = np.random.default_rng(order)
+    Z0 = np.tile(z, (P, 1))
+    Z0[:, 6:12] *= 1 + 0.2 * rng.uniform(-1, 1, (P, 6))
+    params = np.tile(ctx.get_params(), (P, 1))
+    params[:, 2] = 0.01 * (1 + 0.3 * np.arange(P))
+    host, dev = both(ctx, Z0, kind=capi.CHAIN_PLAIN, params=params, xtol=1e-8, analytic_jac=bool(order))
+    if order:
+        assert np.all(dev["njev"] >= 1)
+    assert n == 65
+    ctx.close()
+
+
+def test_interceptor_adaptive_n253():
+    """BASELINE config 5's layout: 253 unknowns, adaptive integrator, table-driven model -- 4 threads' worth of columns per
+    workgroup (256), Jacobians of 64 009 entries scattered into the solver matrices on the device."""
+    from socp_amd import capi, sweep
+    ctx = capi.Context(capi.MODEL_INTERCEPTOR)
+    ctx.set_variant(capi.VARIANT_LANE_FAST)
+    n, z = sweep.interceptor_config5_problem(ctx)
+    ctx.set_integrator(capi.INT_DOPRI5, 1e-11)
+    rng = np.random.default_rng(4)
+    Z0 = np.tile(z, (8, 1))
+    Z0[:, 6:12] *= 1 + 1e-3 * rng.uniform(-1, 1, (8, 6))
+    host, dev = both(ctx, Z0, kind=capi.CHAIN_PLAIN, xtol=1e-9)
+    assert n == 253 and np.all(dev["info"] == 1)
+    ctx.close()
+
+
+def test_nan_start_round_limit_and_refusals():
+    from socp_amd import capi
+    from test_gpu_chains import STAGE2_INIT, PARAMS0, KD, goddard_m6, make_ctx
+    ctx = make_ctx("exact")
+    goddard_m6(ctx)
+    Z0 = np.tile(STAGE2_INIT, (3, 1))
+    Z0[1, 20] = np.nan
+    goals = np.array([310.0, 310.0, 310.0])
+    kw = dict(kind=capi.CHAIN_PARAM, param_index=KD, step=1.0, step_min=1e-3, goal=goals, params=np.tile(PARAMS0, (3, 1)), xtol=1e-6)
+    host, dev = both(ctx, Z0, max_rounds=400, **kw)
+    assert dev["info"][0] == 1 and dev["info"][2] == 1 and dev["info"][1] != 1
+    # a round budget: the stragglers stop with info = -3, everyone else is untouched
+    full = ctx.chains_solve(Z0[[0, 2]], solver=capi.SOLVER_DEVICE, kind=capi.CHAIN_PARAM, param_index=KD, step=1.0, goal=goals[:2],
+                            params=np.tile(PARAMS0, (2, 1)), xtol=1e-6)
+    cut_h, cut_d = both(ctx, Z0[[0, 2]], kind=capi.CHAIN_PARAM, param_index=KD, step=1.0, goal=goals[:2], params=np.tile(PARAMS0, (2, 1)),
+                        xtol=1e-6, max_rounds=3)
+    assert np.all(cut_d["info"] == -3) and full["stats"]["rounds"] > 3
+    with pytest.raises(capi.SocpError):
+        ctx.chains_solve(Z0, solver=7, **kw)
+    # an empty batch, and the context is still good for a residual afterwards
+    r = ctx.chains_solve(np.zeros((0, 85)), solver=capi.SOLVER_DEVICE, kind=capi.CHAIN_PLAIN, xtol=1e-6)
+    assert r["z"].shape == (0, 85)
+    assert np.all(np.isfinite(ctx.residual(STAGE2_INIT)))
+    ctx.close()
+
+
+def test_auto_picks_the_device_for_large_sweeps_only():
+    """socp_chain_options.solver = AUTO: the host engine (with its speculative FD rows) at n = 14, the device engine from
+    n >= 32 and P n^2 >= 2e6 -- visible in the stats: the device engine never forms Jacobians from cached rows."""
+    from socp_amd import capi, sweep
+    ctx = capi.Context(capi.MODEL_GODDARD)
+    ctx.set_params(sweep.GODDARD_PARAMS)
+    ctx.set_step_number(10)
+    ctx.set_variant(capi.VARIANT_LANE_FAST)
+    sweep.goddard_single_shooting_problem(ctx)
+    small = ctx.chains_solve(sweep.goddard_starts(64, 1e-3), kind=capi.CHAIN_PLAIN, xtol=1e-8)
+    assert small["stats"]["jacobians_from_cache"] > 0
+    sweep.goddard_multiple_shooting_problem(ctx, 6)
+    Z0 = sweep.goddard_multiple_shooting_starts(ctx, sweep.goddard_starts(300, 0.05), 6)
+    big = ctx.chains_solve(Z0, kind=capi.CHAIN_PLAIN, xtol=1e-8)
+    assert big["stats"]["jacobians_from_cache"] == 0 and big["stats"]["speculative_rounds"] == 0 and np.all(big["info"] == 1)
+    forced = ctx.chains_solve(Z0, kind=capi.CHAIN_PLAIN, xtol=1e-8, solver=capi.SOLVER_HOST)
+    assert np.array_equal(forced["z"], big["z"]) and np.array_equal(forced["nfev"], big["nfev"])
+    ctx.close()
