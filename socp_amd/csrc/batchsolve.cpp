@@ -142,7 +142,7 @@ extern "C" int socp_chains_solve_ex(socp_ctx *ctx, int P, const socp_chain_optio
         if (solver == SOCP_SOLVER_AUTO) {
             // the host side is the bottleneck of sweeps with n >= 32 (P factorisations of O(n^3) per refresh, P n^2 doubles over
             // PCIe); at n = 14 the rounds are kernel latency and the host engine's speculative FD rows are what pays
-            solver = (n >= 32 && (double)P * n * n >= 2e6) ? SOCP_SOLVER_DEVICE : SOCP_SOLVER_HOST;
+            solver = (n >= 32 && n <= 2048 && (double)P * n * n >= 2e6) ? SOCP_SOLVER_DEVICE : SOCP_SOLVER_HOST;
             if (solver == SOCP_SOLVER_DEVICE) {
                 size_t free_b = 0, total_b = 0;
                 int prev = -1;

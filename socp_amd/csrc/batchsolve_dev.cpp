@@ -133,6 +133,7 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
 
     // (re)start the chains in `list` from their rows of hX (list order) -- they then need an advance
     std::vector<int> adv, advflag, reqF, reqJ, done, restart;
+    int adv_jac = 0;                     // the first adv_jac entries of `adv` are chains whose pending request was a Jacobian
     auto start_chains = [&](const std::vector<int> &list) {
         if (list.empty()) return;
         std::memcpy(hList.p, list.data(), sizeof(int) * list.size());
@@ -160,7 +161,10 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
             std::memcpy(hFlags.p, advflag.data(), sizeof(int) * count);
             hip_ok(hipMemcpyAsync(dList.p, hList.p, sizeof(int) * count, hipMemcpyHostToDevice, main_stream));
             hip_ok(hipMemcpyAsync(dFlags.p, hFlags.p, sizeof(int) * count, hipMemcpyHostToDevice, main_stream));
-            hip_ok(socp::devsolver::launch_advance(main_stream, pool, dList.i(), count, dFlags.i()));
+            // the chains that have just received a Jacobian come first in the list (adv_jac of them) and go in their own launch
+            hip_ok(socp::devsolver::launch_advance(main_stream, pool, dList.i(), adv_jac, dFlags.i(), true));
+            hip_ok(socp::devsolver::launch_advance(main_stream, pool, dList.i() + adv_jac, count - adv_jac, dFlags.i() + adv_jac, false));
+            adv_jac = 0;
             hip_ok(hipMemcpyAsync(hStates.p, dStates.p, sizeof(State) * P, hipMemcpyDeviceToHost, main_stream));
             hip_ok(hipStreamSynchronize(main_stream));
             t_adv += ms_since(ta);
@@ -213,6 +217,7 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
             round_limit_hit = true;
             adv = reqF;
             adv.insert(adv.end(), reqJ.begin(), reqJ.end());
+            adv_jac = 0;
             advflag.assign(adv.size(), SOCP_INFO_ROUND_LIMIT);
             continue;
         }
@@ -264,9 +269,9 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
         hip_ok(hipStreamSynchronize(fs));
         hip_ok(hipStreamSynchronize(main_stream));
         t_eval += ms_since(te);
-        adv = reqF;
-        adv.insert(adv.end(), reqJ.begin(), reqJ.end());
-        std::sort(adv.begin(), adv.end());
+        adv = reqJ;
+        adv.insert(adv.end(), reqF.begin(), reqF.end());
+        adv_jac = kJ;
         advflag.assign(adv.size(), 0);
     }
     socp_problem_set_blocks_dev(ctx, nullptr, 0, nullptr, nullptr);

@@ -1,5 +1,8 @@
 // kernels_solver.hip -- the Powell hybrid iteration of many small problems on the device (solver_dev.hpp): one workgroup per
 // problem.  MUST be compiled with -ffp-contract=off: every iterate has to equal the host solver's (minpack.cpp) bit for bit.
+#include <algorithm>
+#include <cstdlib>
+
 #include "solver_launch.hpp"
 
 namespace socp {
@@ -14,12 +17,24 @@ __global__ void start_kernel(Config c, State *states, double *ws, long ws_stride
     start(ex, c, states[p], ws + (long)p * ws_stride, X0 + (long)blockIdx.x * c.n);
 }
 
-__global__ void advance_kernel(Config c, State *states, double *ws, long ws_stride, const int *__restrict__ list, const int *__restrict__ flags)
+// LDS: eight vectors of n doubles every thread reads again and again (solver_dev.hpp: Work::f) and, optionally, the matrix of
+// the problem in hand for the factor work (lds_matrix_doubles > 0).  A workgroup takes problems blockIdx.x,
+// blockIdx.x + gridDim.x, ... one after the other (the grid may be capped, launch_advance).
+// MAXT: the workgroup size the instantiation is built for -- without it the compiler budgets registers for 1024 threads
+// (128 VGPRs) and spills the rest of this large function to scratch.
+template <int MAXT>
+__global__ __launch_bounds__(MAXT) void advance_kernel(Config c, State *states, double *ws, long ws_stride, const int *__restrict__ list,
+                                                       const int *__restrict__ flags, int count, int lds_matrix_doubles)
 {
-    const int p = list[blockIdx.x];
+    extern __shared__ double lds[];
     BlockExec ex;
-    Machine<BlockExec> m(ex, c, states[p], ws + (long)p * ws_stride);
-    m.advance(flags ? flags[blockIdx.x] : 0);
+    for (int b = blockIdx.x; b < count; b += gridDim.x) {
+        const int p = list[b];
+        Machine<BlockExec> m(ex, c, states[p], ws + (long)p * ws_stride, lds);
+        if (lds_matrix_doubles > 0) m.fast_matrix = lds + 8 * (long)c.n;
+        m.advance(flags ? flags[b] : 0);
+        __syncthreads();
+    }
 }
 
 __global__ void gather_eval_kernel(Config c, const State *states, double *ws, long ws_stride, const int *__restrict__ list, double *__restrict__ dst)
@@ -93,10 +108,41 @@ hipError_t launch_start(hipStream_t st, const PoolDev &pool, const int *d_list, 
     return hipGetLastError();
 }
 
-hipError_t launch_advance(hipStream_t st, const PoolDev &pool, const int *d_list, int count, const int *d_flags)
+hipError_t launch_advance(hipStream_t st, const PoolDev &pool, const int *d_list, int count, const int *d_flags, bool factor_phase)
 {
     if (count <= 0) return hipSuccess;
-    hipLaunchKernelGGL(advance_kernel, dim3(count), dim3(threads_for(pool.cfg.n)), 0, st, pool.cfg, pool.states, pool.ws, pool.ws_stride, d_list, d_flags);
+    const int n = pool.cfg.n;
+    const size_t matrix_bytes = sizeof(double) * (size_t)n * pool.cfg.ld, vector_bytes = sizeof(double) * 8 * (size_t)n;
+    // Launches whose problems all hold a fresh Jacobian (factor_phase) CAN run the factor work on an LDS copy of the matrix when
+    // that fits beside the vectors (SOCP_SOLVER_LDS_BYTES=65536: n <= 85) -- a refresh streams its matrix ~2n/3 times.  Off by
+    // default: measured on 4096 problems of n = 85 the in-place refresh takes 8.4 ms (at HBM bandwidth, 4.8 TB/s) and the LDS
+    // form no less (KD chains 51 -> 58 ms of solver time): 60 KB of LDS per problem leaves 512 problems in flight instead of
+    // 4096, and one problem alone is bound by the latency of its serial chains, not by bandwidth.
+    static const long lds_limit = [] { const char *e = std::getenv("SOCP_SOLVER_LDS_BYTES"); return e ? std::atol(e) : 0L; }();
+    const int lds_matrix = (factor_phase && (long)(matrix_bytes + vector_bytes) <= lds_limit) ? (int)((size_t)n * pool.cfg.ld) : 0;
+    // Optional (SOCP_SOLVER_MAX_GROUPS): cap on the problems in flight (a workgroup then takes several in turn).  Measured on
+    // the 2048 x (n = 253) sweep: 256 in flight (matrices within the last-level cache) took twice as long as all 2048 at once.
+    static const long cap = [] { const char *e = std::getenv("SOCP_SOLVER_MAX_GROUPS"); return e ? std::atol(e) : 0L; }();
+    const unsigned grid = (unsigned)((cap > 0 && cap < count) ? cap : count);
+    const size_t lds_bytes = vector_bytes + (lds_matrix ? matrix_bytes : 0);
+    if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;           // n > 2560: the caller keeps such problems on the host
+    const int threads = threads_for(n);
+#define SOCP_LAUNCH_ADVANCE(MAXT)                                                                                                          \
+    do {                                                                                                                                   \
+        if (lds_bytes > 65536) {                                                                                                           \
+            static const hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void *>(advance_kernel<MAXT>),                     \
+                                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                  \
+            if (raised != hipSuccess) return raised;                                                                                       \
+        }                                                                                                                                  \
+        hipLaunchKernelGGL(advance_kernel<MAXT>, dim3(grid), dim3(threads), lds_bytes, st, pool.cfg, pool.states, pool.ws, pool.ws_stride, \
+                           d_list, d_flags, count, lds_matrix);                                                                            \
+    } while (0)
+    if (threads <= 64) SOCP_LAUNCH_ADVANCE(64);
+    else if (threads <= 128) SOCP_LAUNCH_ADVANCE(128);
+    else if (threads <= 256) SOCP_LAUNCH_ADVANCE(256);
+    else if (threads <= 512) SOCP_LAUNCH_ADVANCE(512);
+    else SOCP_LAUNCH_ADVANCE(1024);
+#undef SOCP_LAUNCH_ADVANCE
     return hipGetLastError();
 }
 

@@ -53,19 +53,28 @@ struct State {
     double delta, xnorm, fnorm, pnorm;
 };
 
-constexpr int kVectors = 14;
+constexpr int kVectors = 16;
 SOCP_HD long ws_doubles(int n, int ld) { return (((long)n * ld + (long)n * (n + 1) / 2 + (long)kVectors * n) + 7) / 8 * 8; }
 SOCP_HD int ld_for(int n) { return (n + 1 + 7) / 8 * 8; }
 
 // views into one problem's workspace
 struct Work {
-    double *A, *r, *x, *fvec, *diag, *qtf, *wa1, *wa2, *wa3, *wa4, *rot, *c1, *s1, *c2, *s2, *vb;
-    SOCP_HD Work(double *base, int n, int ld)
+    double *A, *r, *x, *fvec, *diag, *qtf, *wa1, *wa2, *wa3, *wa4;
+    // eight "fast" vectors of n doubles for what every thread reads again and again (a column or row in hand, rotation
+    // tables, copies whose norm is taken): LDS on the device, the tail of the workspace otherwise
+    double *f[8];
+    SOCP_HD Work(double *base, int n, int ld, double *fast = nullptr)
     {
         A = base; r = A + (long)n * ld;
         double *v = r + (long)n * (n + 1) / 2;
         x = v; fvec = v + n; diag = v + 2 * n; qtf = v + 3 * n; wa1 = v + 4 * n; wa2 = v + 5 * n; wa3 = v + 6 * n; wa4 = v + 7 * n;
-        rot = v + 8 * n; c1 = v + 9 * n; s1 = v + 10 * n; c2 = v + 11 * n; s2 = v + 12 * n; vb = v + 13 * n;
+#if defined(__HIP_DEVICE_COMPILE__)
+        double *fb = fast;                                   // always LDS on the device: a select between an LDS and a global pointer
+                                                             // would make every access to the fast vectors a FLAT one
+#else
+        double *fb = fast ? fast : v + 8 * n;
+#endif
+        for (int k = 0; k < 8; k++) f[k] = fb + (long)k * n;
     }
 };
 
@@ -133,23 +142,115 @@ SOCP_HD double max_of(double a, double b) { return (a < b) ? b : a; }      // st
 SOCP_HD double min_of(double a, double b) { return (b < a) ? b : a; }      // std::min(a, b)
 SOCP_HD long row_off(int n, int i) { return (long)i * n - (long)i * (i - 1) / 2; }   // start of row i of the packed R
 
+// The inner loops below are serial recurrences over memory (a dot product in a fixed order, an axpy, a chain of rotations).
+// The ARITHMETIC must stay in that order; the LOADS need not wait for it: they are issued kBatch at a time into registers and
+// the recurrence then runs on the registers.  Written out by hand because the compiler cannot do it: it has to assume that a
+// store to the matrix may alias the next load (all pointers are generic -- global or LDS), and one trip to HBM per iteration
+// is what a 253-unknown factorisation then costs 128 000 times per thread.
+#ifndef SOCP_SOLVER_BATCH
+#define SOCP_SOLVER_BATCH 8
+#endif
+constexpr int kBatch = SOCP_SOLVER_BATCH;
+
+// sum + sum_{i = lo}^{hi - 1} v[i] * a[i * stride], added in the order of i
+SOCP_HD double dot_run(const double *v, const double *a, long stride, int lo, int hi, double sum)
+{
+    int i = lo;
+    for (; i + kBatch <= hi; i += kBatch) {
+        double av[kBatch], vv[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; u++) { av[u] = a[(long)(i + u) * stride]; vv[u] = v[i + u]; }
+#pragma unroll
+        for (int u = 0; u < kBatch; u++) sum += vv[u] * av[u];
+    }
+    for (; i < hi; i++) sum += v[i] * a[(long)i * stride];
+    return sum;
+}
+
+// a[i * stride] -= temp * v[i] for i = lo .. hi - 1
+SOCP_HD void axpy_run(double *a, long stride, const double *v, int lo, int hi, double temp)
+{
+    int i = lo;
+    for (; i + kBatch <= hi; i += kBatch) {
+        double av[kBatch], vv[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; u++) { av[u] = a[(long)(i + u) * stride]; vv[u] = v[i + u]; }
+#pragma unroll
+        for (int u = 0; u < kBatch; u++) a[(long)(i + u) * stride] = av[u] - temp * vv[u];
+    }
+    for (; i < hi; i++) a[(long)i * stride] -= temp * v[i];
+}
+
+// One sweep of r1mpyq over a row a[0 .. n - 1] (contiguous): for j = n - 2 .. 0 (first = true: rotations of the first sweep of
+// r1updt, temp = c a_j - s a_n, a_n = s a_j + c a_n) or j = 0 .. n - 2 (first = false: temp = c a_j + s a_n, a_n = -s a_j + c a_n)
+SOCP_HD double rotate_row(double *a, const double *c, const double *s, int n, double an, bool first)
+{
+    if (first) {
+        int j = n - 2;
+        for (; j - kBatch + 1 >= 0; j -= kBatch) {
+            double av[kBatch], cv[kBatch], sv[kBatch];
+#pragma unroll
+            for (int u = 0; u < kBatch; u++) { av[u] = a[j - u]; cv[u] = c[j - u]; sv[u] = s[j - u]; }
+#pragma unroll
+            for (int u = 0; u < kBatch; u++) {
+                const double temp = cv[u] * av[u] - sv[u] * an;
+                an = sv[u] * av[u] + cv[u] * an;
+                av[u] = temp;
+            }
+#pragma unroll
+            for (int u = 0; u < kBatch; u++) a[j - u] = av[u];
+        }
+        for (; j >= 0; j--) {
+            const double aj = a[j];
+            const double temp = c[j] * aj - s[j] * an;
+            an = s[j] * aj + c[j] * an;
+            a[j] = temp;
+        }
+    } else {
+        int j = 0;
+        for (; j + kBatch <= n - 1; j += kBatch) {
+            double av[kBatch], cv[kBatch], sv[kBatch];
+#pragma unroll
+            for (int u = 0; u < kBatch; u++) { av[u] = a[j + u]; cv[u] = c[j + u]; sv[u] = s[j + u]; }
+#pragma unroll
+            for (int u = 0; u < kBatch; u++) {
+                const double temp = cv[u] * av[u] + sv[u] * an;
+                an = -sv[u] * av[u] + cv[u] * an;
+                av[u] = temp;
+            }
+#pragma unroll
+            for (int u = 0; u < kBatch; u++) a[j + u] = av[u];
+        }
+        for (; j < n - 1; j++) {
+            const double aj = a[j];
+            const double temp = c[j] * aj + s[j] * an;
+            an = -s[j] * aj + c[j] * an;
+            a[j] = temp;
+        }
+    }
+    return an;
+}
+
 // One Jacobian refresh's factor work: qrfac (no pivoting) with Q^T fvec riding along as column n, R packed by rows, qform in
 // place.  In: A[i][j] = J(i, j), fvec.  Out: A = Q (row-major), r, qtf, rdiag (wa1), acnorm (wa2); returns "singular".
+// A column's norm is a serial chain over its entries: the column is first copied to a fast vector by all threads at once (one
+// strided load each) and the chain then runs on that copy -- on the matrix itself it would be n dependent trips to memory.
 template <class E>
 SOCP_HD bool factor(const E &ex, int n, int ld, Work &w)
 {
-    double *A = w.A, *rdiag = w.wa1, *acnorm = w.wa2, *v = w.vb;
+    double *A = w.A, *rdiag = w.wa1, *acnorm = w.wa2, *col = w.f[0], *v = w.f[1];
     SOCP_PAR_FOR(j, 0, n) acnorm[j] = enorm(n, A + j, ld);
     SOCP_PAR_FOR(i, 0, n) A[(long)i * ld + n] = w.fvec[i];
     ex.sync();
     for (int j = 0; j < n; j++) {
-        // finish reflector j on its column (every thread computes the same norm from the same loads)
-        double ajnorm = enorm(n - j, A + (long)j * ld + j, ld);
-        if (ajnorm != 0 && A[(long)j * ld + j] < 0) ajnorm = -ajnorm;
-        ex.sync();                                           // all have read column j before it is scaled
+        SOCP_PAR_FOR(i, j, n) col[i] = A[(long)i * ld + j];
+        ex.sync();
+        // finish reflector j on its column (every thread computes the same norm from the same fast copy)
+        double ajnorm = enorm(n - j, col + j);
+        if (ajnorm != 0 && col[j] < 0) ajnorm = -ajnorm;
         if (ajnorm != 0) {
             SOCP_PAR_FOR(i, j, n) {
-                double t = A[(long)i * ld + j] / ajnorm;
+                double t = col[i] / ajnorm;
                 if (i == j) t += 1;
                 A[(long)i * ld + j] = t;
                 v[i] = t;
@@ -160,10 +261,9 @@ SOCP_HD bool factor(const E &ex, int n, int ld, Work &w)
         if (ajnorm != 0) {
             const double piv = v[j];
             SOCP_PAR_FOR(k, j + 1, n + 1) {                  // the later columns, and fvec's column
-                double sum = 0;
-                for (int i = j; i < n; i++) sum += v[i] * A[(long)i * ld + k];
+                const double sum = dot_run(v, A + k, ld, j, n, 0.0);
                 const double temp = sum / piv;
-                for (int i = j; i < n; i++) A[(long)i * ld + k] -= temp * v[i];
+                axpy_run(A + k, ld, v, j, n, temp);
             }
         }
         ex.sync();
@@ -175,8 +275,9 @@ SOCP_HD bool factor(const E &ex, int n, int ld, Work &w)
         SOCP_PAR_FOR(k, i, n) w.r[off + (k - i)] = (k == i) ? rdiag[i] : A[(long)i * ld + k];
     }
     bool sing = false;
-    for (int j = 0; j < n; j++) if (rdiag[j] == 0) sing = true;
+    SOCP_PAR_FOR(j, 0, n) col[j] = rdiag[j];
     ex.sync();
+    for (int j = 0; j < n; j++) if (col[j] == 0) sing = true;
     // qform, MINPACK's in-place order: the strict upper triangle is cleared, then for k = n-1 .. 0 column k's Householder
     // vector moves out, the column becomes e_k and the columns j >= k go through reflector k
     for (int i = 0; i < n; i++)
@@ -188,10 +289,9 @@ SOCP_HD bool factor(const E &ex, int n, int ld, Work &w)
         const double piv = v[k];
         if (piv != 0) {
             SOCP_PAR_FOR(j, k, n) {
-                double sum = 0;
-                for (int i = k; i < n; i++) sum += A[(long)i * ld + j] * v[i];
+                const double sum = dot_run(v, A + j, ld, k, n, 0.0);
                 const double temp = sum / piv;
-                for (int i = k; i < n; i++) A[(long)i * ld + j] -= temp * v[i];
+                axpy_run(A + j, ld, v, k, n, temp);
             }
         }
         ex.sync();
@@ -199,59 +299,62 @@ SOCP_HD bool factor(const E &ex, int n, int ld, Work &w)
     return sing;
 }
 
-// minpack.cpp: dogleg.  x = wa1, scratch = wa2, wa3.  Every thread returns with the step in w.wa1 complete (synchronised).
+// minpack.cpp: dogleg; the step comes out in w.wa1.  Fast vectors: f0 = the Gauss-Newton step, f1 / f2 = the row of R in hand
+// (alternating), f3 = qtb, f4 = scaled vectors whose norm is taken, f5 = the gradient direction.  Every thread returns with
+// the step complete (synchronised).
 template <class E>
 SOCP_HD void dogleg(const E &ex, int n, Work &w, double delta)
 {
-    const double *r = w.r, *diag = w.diag, *qtb = w.qtf;
-    double *x = w.wa1, *wa1 = w.wa2, *wa2 = w.wa3;
-    if (ex.tid == 0) {
-        // Gauss-Newton direction by back substitution: x[j] needs every later x[i], last computed first -- one serial chain
-        long jj = (long)n * (n + 1) / 2;
-        for (int k = 1; k <= n; k++) {
-            const int j = n - k;
-            jj -= k;
-            long l = jj + 1;
-            double sum = 0;
-            for (int i = j + 1; i < n; i++) { sum += r[l] * x[i]; l++; }
-            double temp = r[jj];
-            if (temp == 0) {
-                l = j;
-                for (int i = 0; i <= j; i++) { temp = max_of(temp, fabs(r[l])); l += n - i - 1; }
-                temp = kEpsMch * temp;
-                if (temp == 0) temp = kEpsMch;
-            }
-            x[j] = (qtb[j] - sum) / temp;
+    const double *r = w.r, *diag = w.diag;
+    double *x = w.wa1, *xl = w.f[0], *qtb = w.f[3], *sc = w.f[4], *g = w.f[5];
+    SOCP_PAR_FOR(j, 0, n) qtb[j] = w.qtf[j];
+    // Gauss-Newton direction by back substitution: x[j] needs every later x[i], the last computed first -- one serial chain.
+    // Row j of R is brought to a fast vector by all threads at once; every thread then runs the same sum.
+    long jj = (long)n * (n + 1) / 2;
+    for (int k = 1; k <= n; k++) {
+        const int j = n - k;
+        jj -= k;
+        double *row = (k & 1) ? w.f[2] : w.f[1];            // (no run-time index into the pointer table: it would go to scratch)
+        SOCP_PAR_FOR(i, j, n) row[i] = r[jj + (i - j)];
+        ex.sync();                                           // the row, qtb, and the x[j + 1] thread 0 stored before arriving here
+        const double sum = dot_run(row, xl, 1, j + 1, n, 0.0);
+        double temp = row[j];
+        if (temp == 0) {
+            long l = j;
+            for (int i = 0; i <= j; i++) { temp = max_of(temp, fabs(r[l])); l += n - i - 1; }
+            temp = kEpsMch * temp;
+            if (temp == 0) temp = kEpsMch;
         }
+        if (ex.tid == 0) xl[j] = (qtb[j] - sum) / temp;
     }
     ex.sync();
-    SOCP_PAR_FOR(j, 0, n) { wa1[j] = 0; wa2[j] = diag[j] * x[j]; }
+    SOCP_PAR_FOR(j, 0, n) sc[j] = diag[j] * xl[j];
     ex.sync();
-    const double qnorm = enorm(n, wa2);
-    ex.sync();                                               // everyone has its norm before wa2 is written again (here or by the caller)
-    if (qnorm <= delta) return;
+    const double qnorm = enorm(n, sc);
+    if (qnorm <= delta) {
+        SOCP_PAR_FOR(j, 0, n) x[j] = xl[j];
+        ex.sync();
+        return;
+    }
     // scaled gradient direction: element i collects r(j, i) qtb[j] for j = 0 .. i in that order, then is divided
     SOCP_PAR_FOR(i, 0, n) {
         double acc = 0;                                      // wa1[i] starts at 0
         for (int j = 0; j <= i; j++) acc += r[row_off(n, j) + (i - j)] * qtb[j];
-        wa1[i] = acc / diag[i];
+        g[i] = acc / diag[i];
     }
     ex.sync();
-    const double gnorm = enorm(n, wa1);
+    const double gnorm = enorm(n, g);
     double sgnorm = 0;
     double alpha = delta / qnorm;
     if (gnorm != 0) {
-        ex.sync();
-        SOCP_PAR_FOR(j, 0, n) wa1[j] = (wa1[j] / gnorm) / diag[j];
+        ex.sync();                                           // everyone has gnorm (and qnorm) before g and sc change
+        SOCP_PAR_FOR(j, 0, n) g[j] = (g[j] / gnorm) / diag[j];
         ex.sync();
         SOCP_PAR_FOR(j, 0, n) {
-            const long off = row_off(n, j);
-            double sum = 0;
-            for (int i = j; i < n; i++) sum += r[off + (i - j)] * wa1[i];
-            wa2[j] = sum;
+            sc[j] = dot_run(g, r + row_off(n, j) - j, 1, j, n, 0.0);
         }
         ex.sync();
-        double temp = enorm(n, wa2);
+        double temp = enorm(n, sc);
         sgnorm = (gnorm / temp) / temp;
         alpha = 0;
         if (sgnorm < delta) {
@@ -264,7 +367,7 @@ SOCP_HD void dogleg(const E &ex, int n, Work &w, double delta)
         }
     }
     const double temp = (1 - alpha) * min_of(sgnorm, delta);
-    SOCP_PAR_FOR(j, 0, n) x[j] = temp * wa1[j] + alpha * x[j];
+    SOCP_PAR_FOR(j, 0, n) x[j] = temp * g[j] + alpha * xl[j];
     ex.sync();
 }
 
@@ -290,14 +393,15 @@ SOCP_HD void decode_rotation(double t, double &cs, double &sn)
     else { sn = t; cs = sqrt(1 - sn * sn); }
 }
 
-// minpack.cpp: r1updt on the packed R (m = n), u = wa1, v = wa2, w = wa3.  The rotation encodings MINPACK leaves in v[0..n-2]
-// go to w.rot instead (v stays read-only, so no thread can see a half-updated v); w[0..n-2] receives the second sweep's as
-// there.  A thread owns element i of w and column-position i of every row of s for the whole routine.
+// minpack.cpp: r1updt on the packed R (m = n).  Fast vectors: v = f4 (in), u = f5 (in), w = f6, the first sweep's rotation
+// encodings -> f7, the diagonal of s after the first sweep -> f1, the second sweep's encodings -> f4 (v is dead by then).
+// MINPACK leaves the encodings in v and w themselves; here nobody may see a half-updated vector, so they go elsewhere.
+// A thread owns element i of w and column-position i of every row of s for the whole routine.
 template <class E>
 SOCP_HD bool r1updt(const E &ex, int n, Work &wk)
 {
-    double *s = wk.r, *w = wk.wa3, *rot = wk.rot;
-    const double *u = wk.wa1, *v = wk.wa2;
+    double *s = wk.r, *w = wk.f[6], *rot = wk.f[7], *sd = wk.f[1], *rot2 = wk.f[4];
+    const double *u = wk.f[5], *v = wk.f[4];
     long jj = (long)n * (n + 1) / 2 - 1;                     // the last diagonal entry
     if (ex.tid == (n - 1) % ex.nt) w[n - 1] = s[jj];
     double vn = v[n - 1];
@@ -318,84 +422,66 @@ SOCP_HD bool r1updt(const E &ex, int n, Work &wk)
                 const double temp = cs * s[l] - sn * wi;
                 w[i] = sn * s[l] + cs * wi;
                 s[l] = temp;
+                if (i == j) sd[j] = temp;
             }
         } else if (ex.tid == j % ex.nt) {
             w[j] = 0;
+            sd[j] = s[jj];
         }
     }
     SOCP_PAR_FOR(i, 0, n) w[i] += vn * u[i];
     bool sing = false;
     for (int j = 0; j < n - 1; j++) {
         ex.sync();                                           // s(j, j) and w[j] come from the thread that owns element j
-        const double wj = w[j], sjj = s[jj];
+        const double wj = w[j], sjj = sd[j];
         double cs = 0, sn = 0, tau = 0;
-        if (wj != 0) givens(sjj, wj, cs, sn, tau);
-        ex.sync();                                           // both read by everyone before they change
         if (wj != 0) {
+            givens(sjj, wj, cs, sn, tau);
             SOCP_PAR_FOR(i, j, n) {
                 const long l = jj + (i - j);
                 const double temp = cs * s[l] + sn * w[i];
                 const double wn = -sn * s[l] + cs * w[i];
                 s[l] = temp;
-                w[i] = (i == j) ? tau : wn;
+                if (i != j) w[i] = wn;                       // (MINPACK stores the encoding in w[j]: rot2 here)
             }
             if (cs * sjj + sn * wj == 0) sing = true;        // s(j, j) after the rotation, as every thread can compute it
         } else if (sjj == 0) {
             sing = true;
         }
+        if (ex.tid == 0) rot2[j] = (wj != 0) ? tau : wj;
         jj += (n - j);
     }
     ex.sync();
     const double last = w[n - 1];
-    ex.sync();
     if (ex.tid == 0) s[jj] = last;
     if (last == 0) sing = true;
     return sing;
 }
 
-// minpack.cpp: r1mpyq on Q (n x n, row-major here) and on qtf, with the rotations of the last r1updt
+// minpack.cpp: r1mpyq on Q (n x n, row-major here) and on qtf, with the rotations of the last r1updt (f7, f4) decoded into
+// f0 .. f3
 template <class E>
 SOCP_HD void r1mpyq_all(const E &ex, int n, int ld, Work &wk)
 {
-    double *c1 = wk.c1, *s1 = wk.s1, *c2 = wk.c2, *s2 = wk.s2;
+    double *c1 = wk.f[0], *s1 = wk.f[1], *c2 = wk.f[2], *s2 = wk.f[3];
     ex.sync();
     SOCP_PAR_FOR(j, 0, n - 1) {
-        decode_rotation(wk.rot[j], c1[j], s1[j]);
-        decode_rotation(wk.wa3[j], c2[j], s2[j]);
+        decode_rotation(wk.f[7][j], c1[j], s1[j]);
+        decode_rotation(wk.f[4][j], c2[j], s2[j]);
     }
     ex.sync();
     SOCP_PAR_FOR(i, 0, n) {                                  // a row of Q goes through all rotations on its own
         double *a = wk.A + (long)i * ld;
         double an = a[n - 1];
-        for (int j = n - 2; j >= 0; j--) {
-            const double aj = a[j];
-            const double temp = c1[j] * aj - s1[j] * an;
-            an = s1[j] * aj + c1[j] * an;
-            a[j] = temp;
-        }
-        for (int j = 0; j < n - 1; j++) {
-            const double aj = a[j];
-            const double temp = c2[j] * aj + s2[j] * an;
-            an = -s2[j] * aj + c2[j] * an;
-            a[j] = temp;
-        }
+        an = rotate_row(a, c1, s1, n, an, true);
+        an = rotate_row(a, c2, s2, n, an, false);
         a[n - 1] = an;
     }
-    if (ex.tid == 0) {                                       // qtf is the one-row case
+    if (ex.tid == ex.nt - 1) {                               // qtf is the one-row case (on the thread least likely to own a row)
         double *a = wk.qtf;
         double an = a[n - 1];
-        for (int j = n - 2; j >= 0; j--) {
-            const double aj = a[j];
-            const double temp = c1[j] * aj - s1[j] * an;
-            an = s1[j] * aj + c1[j] * an;
-            a[j] = temp;
-        }
-        for (int j = 0; j < n - 1; j++) {
-            const double aj = a[j];
-            const double temp = c2[j] * aj + s2[j] * an;
-            an = -s2[j] * aj + c2[j] * an;
-            a[j] = temp;
-        }
+        an = rotate_row(a, c1, s1, n, an, true);
+        an = rotate_row(a, c2, s2, n, an, false);
         a[n - 1] = an;
     }
     ex.sync();
@@ -410,7 +496,9 @@ struct Machine {
     State &st;                 // in global memory; `s` is this thread's copy
     State s;
     Work w;
-    SOCP_HD Machine(const E &e, const Config &cfg, State &state, double *base) : ex(e), c(cfg), st(state), s(state), w(base, cfg.n, cfg.ld) {}
+    double *fast_matrix = nullptr;   // device: an LDS buffer of n * ld doubles for the factor work (null: work in place)
+    SOCP_HD Machine(const E &e, const Config &cfg, State &state, double *base, double *fast_vectors = nullptr)
+        : ex(e), c(cfg), st(state), s(state), w(base, cfg.n, cfg.ld, fast_vectors) {}
 
     SOCP_HD void store() { ex.sync(); if (ex.tid == 0) st = s; }
     SOCP_HD void finish(int code) { s.info = code; s.phase = PH_DONE; s.req = RQ_DONE; }
@@ -420,14 +508,15 @@ struct Machine {
     {
         const int n = c.n;
         dogleg(ex, n, w, s.delta);
+        double *sc = w.f[0];
         SOCP_PAR_FOR(j, 0, n) {
             const double p = -w.wa1[j];
             w.wa1[j] = p;
             w.wa2[j] = w.x[j] + p;
-            w.wa3[j] = w.diag[j] * p;
+            sc[j] = w.diag[j] * p;
         }
         ex.sync();
-        s.pnorm = enorm(n, w.wa3);
+        s.pnorm = enorm(n, sc);
         if (s.iter == 1) s.delta = min_of(s.delta, s.pnorm);
         s.phase = PH_TRIAL;
         s.req = RQ_FVEC; s.eval_sel = 1;
@@ -437,13 +526,27 @@ struct Machine {
     {
         const int n = c.n;
         if (c.analytic) s.njev += 1; else s.nfev += n;
-        const bool sing = factor(ex, n, c.ld, w);            // wa1 = diag(R), wa2 = column norms
+        bool sing;
+        if (fast_matrix) {
+            // the refresh streams its matrix ~2n/3 times: do that on a copy in LDS, bring Q back once
+            double *const home = w.A;
+            const long len = (long)n * c.ld;
+            SOCP_PAR_FOR(e, 0, (int)len) fast_matrix[e] = home[e];
+            ex.sync();
+            w.A = fast_matrix;
+            sing = factor(ex, n, c.ld, w);                   // wa1 = diag(R), wa2 = column norms
+            w.A = home;
+            SOCP_PAR_FOR(e, 0, (int)len) home[e] = fast_matrix[e];
+            ex.sync();
+        } else {
+            sing = factor(ex, n, c.ld, w);
+        }
         if (s.iter == 1) {
             if (c.mode != 2) SOCP_PAR_FOR(j, 0, n) w.diag[j] = (w.wa2[j] == 0) ? 1.0 : w.wa2[j];
             ex.sync();
-            SOCP_PAR_FOR(j, 0, n) w.wa3[j] = w.diag[j] * w.x[j];
+            SOCP_PAR_FOR(j, 0, n) w.f[0][j] = w.diag[j] * w.x[j];
             ex.sync();
-            s.xnorm = enorm(n, w.wa3);
+            s.xnorm = enorm(n, w.f[0]);
             s.delta = c.factor * s.xnorm;
             if (s.delta == 0) s.delta = c.factor;
         }
@@ -458,18 +561,18 @@ struct Machine {
         const double p1 = .1, p5 = .5, p001 = .001, p0001 = 1e-4;
         const int n = c.n;
         s.nfev += 1;
-        const double fnorm1 = enorm(n, w.wa4);
+        double *f4c = w.f[0], *pc = w.f[1], *pr = w.f[2], *sx = w.f[3];      // fast copies: trial residual, step, qtf + R p, diag x
+        SOCP_PAR_FOR(j, 0, n) { f4c[j] = w.wa4[j]; pc[j] = w.wa1[j]; }
+        ex.sync();
+        const double fnorm1 = enorm(n, f4c);
         double actred = -1;
         if (fnorm1 < s.fnorm) { const double q = fnorm1 / s.fnorm; actred = 1 - q * q; }
         // predicted reduction from |qtf + R p|
         SOCP_PAR_FOR(i, 0, n) {
-            const long off = row_off(n, i);
-            double sum = 0;
-            for (int j = i; j < n; j++) sum += w.r[off + (j - i)] * w.wa1[j];
-            w.wa3[i] = w.qtf[i] + sum;
+            pr[i] = w.qtf[i] + dot_run(pc, w.r + row_off(n, i) - i, 1, i, n, 0.0);
         }
         ex.sync();
-        const double temp = enorm(n, w.wa3);
+        const double temp = enorm(n, pr);
         double prered = 0;
         if (temp < s.fnorm) { const double q = temp / s.fnorm; prered = 1 - q * q; }
         const double ratio = prered > 0 ? actred / prered : 0;
@@ -482,10 +585,9 @@ struct Machine {
             if (fabs(ratio - 1) <= p1) s.delta = s.pnorm / p5;
         }
         if (ratio >= p0001) {
+            SOCP_PAR_FOR(j, 0, n) { const double xj = w.wa2[j]; w.x[j] = xj; sx[j] = w.diag[j] * xj; w.fvec[j] = f4c[j]; }
             ex.sync();
-            SOCP_PAR_FOR(j, 0, n) { const double xj = w.wa2[j]; w.x[j] = xj; w.wa2[j] = w.diag[j] * xj; w.fvec[j] = w.wa4[j]; }
-            ex.sync();
-            s.xnorm = enorm(n, w.wa2);
+            s.xnorm = enorm(n, sx);
             s.fnorm = fnorm1;
             s.iter += 1;
         }
@@ -502,14 +604,12 @@ struct Machine {
         if (code != 0) { finish(code); return; }
         if (s.ncfail == 2) { request_jac(); return; }
 
-        // Broyden rank-1 update of (Q, R, Q^T f)
-        ex.sync();
+        // Broyden rank-1 update of (Q, R, Q^T f): v -> f4, u -> f5 (r1updt's inputs)
         const double pnorm = s.pnorm;
         SOCP_PAR_FOR(j, 0, n) {
-            double sum = 0;
-            for (int i = 0; i < n; i++) sum += w.A[(long)i * c.ld + j] * w.wa4[i];
-            w.wa2[j] = (sum - w.wa3[j]) / pnorm;
-            w.wa1[j] = w.diag[j] * ((w.diag[j] * w.wa1[j]) / pnorm);
+            const double sum = dot_run(f4c, w.A + j, c.ld, 0, n, 0.0);
+            w.f[4][j] = (sum - pr[j]) / pnorm;
+            w.f[5][j] = w.diag[j] * ((w.diag[j] * pc[j]) / pnorm);
             if (ratio >= p0001) w.qtf[j] = sum;
         }
         ex.sync();
@@ -537,7 +637,9 @@ struct Machine {
         }
         case PH_F0:
             s.nfev = 1;
-            s.fnorm = enorm(c.n, w.fvec);
+            SOCP_PAR_FOR(j, 0, c.n) w.f[0][j] = w.fvec[j];
+            ex.sync();
+            s.fnorm = enorm(c.n, w.f[0]);
             s.iter = 1; s.ncsuc = s.ncfail = s.nslow1 = s.nslow2 = 0;
             request_jac();
             break;

@@ -20,8 +20,9 @@ int threads_for(int n);            // workgroup size of the per-problem kernels:
 
 // problems list[0 .. count): (re)start from X0[k][n] (k = position in the list)
 hipError_t launch_start(hipStream_t st, const PoolDev &pool, const int *d_list, int count, const double *d_X0);
-// advance the state machines of list[0 .. count); d_flags[k] (may be null = 0): what the pending evaluation returned
-hipError_t launch_advance(hipStream_t st, const PoolDev &pool, const int *d_list, int count, const int *d_flags);
+// advance the state machines of list[0 .. count); d_flags[k] (may be null = 0): what the pending evaluation returned.
+// factor_phase: every problem of the list has just received a Jacobian (its advance is a factorisation)
+hipError_t launch_advance(hipStream_t st, const PoolDev &pool, const int *d_list, int count, const int *d_flags, bool factor_phase);
 // dst[k][n] = the point problem list[k] asked to be evaluated (x, or the trial point)
 hipError_t launch_gather_eval(hipStream_t st, const PoolDev &pool, const int *d_list, int count, double *d_dst);
 // the residual of that evaluation back into the problem (fvec, or the trial residual)

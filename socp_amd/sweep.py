@@ -196,7 +196,8 @@ def interceptor_sweep(args, torch, dist, capi, world, rank, local_rank, dev, rec
     stats = {}
 
     def solve_block(Zb):
-        r = ctx.chains_solve(Zb, kind=capi.CHAIN_PLAIN, xtol=args.xtol, speculate=args.speculate, max_rounds=args.max_rounds)
+        r = ctx.chains_solve(Zb, kind=capi.CHAIN_PLAIN, xtol=args.xtol, speculate=args.speculate, max_rounds=args.max_rounds,
+                             solver={"auto": capi.SOLVER_AUTO, "host": capi.SOLVER_HOST, "device": capi.SOLVER_DEVICE}[args.solver])
         stats.update(r["stats"])
         r["rounds"] = r["stats"]["rounds"]
         return r
@@ -213,7 +214,7 @@ def interceptor_sweep(args, torch, dist, capi, world, rank, local_rank, dev, rec
         info = table[:, -2].astype(int)
         conv = table[info == 1, :n]
         record = json.dumps({"sweep": "interceptor_config5_M21_n%d_%s" % (n, "rk4" if args.fixed_step else "dopri5_tol%g" % args.ode_tol),
-                             "starts": args.starts, "eps": eps, "n_gpus": world, "variant": args.variant, "xtol": args.xtol, "wall_s": wall,
+                             "starts": args.starts, "eps": eps, "n_gpus": world, "variant": args.variant, "solver": args.solver, "xtol": args.xtol, "wall_s": wall,
                              "converged": int(np.sum(info == 1)), "info_histogram": {str(k): int(np.sum(info == k)) for k in np.unique(info)},
                              "solution_spread_rel": float(np.max(np.abs(conv - np.median(conv, axis=0))) / np.max(np.abs(conv))) if len(conv) else None,
                              "solves_per_s": args.starts / wall, "trajectories": int(traj.item()), "trajectories_per_s": traj.item() / wall,
@@ -251,6 +252,8 @@ def main():
     ap.add_argument("--max-rounds", type=int, default=0, help="socp_chain_options.max_rounds: stop chains still solving after "
                     "that many launch rounds (info = -3); 0 = no limit")
     ap.add_argument("--speculate", type=int, default=-1, help="socp_chain_options.speculate: -1 auto, 0 never, 1 always")
+    ap.add_argument("--solver", choices=["auto", "host", "device"], default="auto", help="socp_chain_options.solver: where the chains' "
+                    "hybrd state machines run (auto: on the device from n >= 32 and P n^2 >= 2e6)")
     args = ap.parse_args()
 
     # stdout carries only the JSON record: RCCL prints a version banner to file descriptor 1 when a process group is created
@@ -312,12 +315,14 @@ def main():
     t0 = time.perf_counter()
     stats = {}
 
+    solver = {"auto": capi.SOLVER_AUTO, "host": capi.SOLVER_HOST, "device": capi.SOLVER_DEVICE}[args.solver]
+
     def solve_block(Zb):
         lo, hi = shard(args.starts, rank, world)
         if chain_kw is not None:
-            r = ctx.chains_solve(Zb, goal=goals[lo:hi], params=params[lo:hi], xtol=args.xtol, max_rounds=args.max_rounds, **chain_kw)
+            r = ctx.chains_solve(Zb, goal=goals[lo:hi], params=params[lo:hi], xtol=args.xtol, max_rounds=args.max_rounds, solver=solver, **chain_kw)
         else:
-            r = ctx.chains_solve(Zb, kind=capi.CHAIN_PLAIN, xtol=args.xtol, speculate=args.speculate, max_rounds=args.max_rounds)
+            r = ctx.chains_solve(Zb, kind=capi.CHAIN_PLAIN, xtol=args.xtol, speculate=args.speculate, max_rounds=args.max_rounds, solver=solver)
         stats.update(r["stats"])
         stats["solves"] = int(np.sum(r["solves"]))
         r["rounds"] = r["stats"]["rounds"]
@@ -340,7 +345,7 @@ def main():
                           "chains_per_s": (args.starts / wall) if chain_kw is not None else None,
                           "continuation": None if chain_kw is None else {"parameter": "KD", "from": 0.0, "goal": args.kd_goal, "goal_spread": args.kd_spread, "step": args.step},
                           "engine_rank0": stats,
-                          "starts": args.starts, "eps": eps, "n_gpus": world,
+                          "starts": args.starts, "eps": eps, "n_gpus": world, "solver": args.solver,
                           "rk4_steps": args.rk4_steps, "variant": args.variant, "xtol": args.xtol, "wall_s": wall, "max_rounds": args.max_rounds,
                           "converged": int(np.sum(info == 1)), "info_histogram": {str(k): int(np.sum(info == k)) for k in np.unique(info)},
                           "trajectories": int(traj.item()), "trajectories_per_s": traj.item() / wall,
