@@ -156,6 +156,52 @@ int socp_chains_solve_ex(struct socp_ctx *ctx, int P, const socp_chain_options *
                          const double *x_goal, double *Zout, int *info, int *nfev_last, int *nfev_total, int *njev_last,
                          int *solves, double *b_reached, double *param_final, double *fnorm, socp_chain_stats *stats);
 
+/* ---- multi-GPU sweep from C++ (SURVEY 8e level 1; north_star: "a continuation/multi-start outer loop shards independent
+ * shooting problems across the 8 GPUs of one node with a trivial gather").  The reference has no counterpart: its continuation
+ * loops (shooting.cpp:598-778) solve one problem at a time on one thread; what is kept is its plugin surface -- the problem is
+ * described once, through a context (or, from the C++ mirror, through model + shooting: shooting.hpp:29-219).
+ *
+ * Problems are independent, so the sharding is contiguous blocks with NO data-path exchange; the only communication is the
+ * gather of fixed-size result records at the end.
+ *
+ * socp_sweep_shard: the block of rank `rank` of `world` -- sizes differ by at most one (the reference's partition of segments
+ * over threads, shooting.cpp:1223-1231, applied to problems). */
+void socp_sweep_shard(int P, int rank, int world, int *lo, int *hi);
+
+/* A copy of `proto` on another device: same model, packed parameters, switching times, step number, integrator, arithmetic
+ * flavour and shooting problem (its tables are rebuilt there).  device < 0: the calling thread's current device. */
+int socp_ctx_clone(const struct socp_ctx *proto, int device, struct socp_ctx **out);
+
+typedef struct socp_sweep_stats {
+    int ndev;
+    double wall_ms;                   /* whole call */
+    double device_wall_ms[16];        /* per device: its block's lock-step solve */
+    long long device_rounds[16];
+    long long trajectories;           /* integrated on all devices */
+} socp_sweep_stats;
+
+/* ONE process, `ndev` GPUs: one host thread and one context (socp_ctx_clone of `proto`) per device, device k solving block k
+ * of the P starts Z0[P][n] with socp_chains_solve (opt->kind = SOCP_CHAIN_PLAIN: a multi-start sweep; the per-chain arrays
+ * params / goal / time_* / x_* of socp_chains_solve may be given for continuation chains, NULL otherwise) and writing its
+ * rows of the outputs -- the gather is the shared host memory.  devices[k]: HIP device indices (ndev <= 16; NULL = 0 .. ndev-1).
+ * Outputs as socp_chains_solve.  Every chain's result is the one it has on a single GPU (blocks are independent). */
+int socp_sweep_solve(const struct socp_ctx *proto, const int *devices, int ndev, int P, const socp_chain_options *opt, const double *Z0,
+                     const double *params, const double *goal, const double *time_prev, const double *x_prev, const double *time_goal,
+                     const double *x_goal, double *Zout, int *info, int *nfev_last, int *nfev_total, int *solves, double *b_reached,
+                     double *param_final, double *fnorm, socp_sweep_stats *stats);
+
+/* ONE process PER GPU (the layout of an MPI / RCCL job): rank `rank` of `world` solves its block on `ctx` and the records
+ * {Zout[n], fnorm, info, nfev_last, nfev_total, solves} (n + 5 doubles per start) of all ranks are gathered with the caller's
+ * collective: gather(user, send, count, recv) must behave like an all-gather of `count` doubles per rank into
+ * recv[world][count] -- ncclAllGather(send, recv, count, ncclDouble, comm, stream) + a stream synchronise, MPI_Allgather, or
+ * a copy when world = 1 (INTEGRATION.md shows the RCCL form; this library does not link a communication library itself).
+ * send / recv are HOST buffers unless gather_on_device != 0, in which case they are device buffers on ctx's device.
+ * Outputs: the full tables of all P starts, on every rank. */
+typedef int (*socp_allgather_fn)(void *user, const double *send, long count, double *recv);
+int socp_sweep_solve_rank(struct socp_ctx *ctx, int rank, int world, int P, const socp_chain_options *opt, const double *Z0,
+                          socp_allgather_fn gather, void *user, int gather_on_device, double *Zout, int *info, int *nfev_last,
+                          int *nfev_total, int *solves, double *fnorm, socp_chain_stats *stats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -366,13 +366,21 @@ class Ref:
         self.lib.ref_model_traj(self.h, C.c_double(t0), _d(X0), len(X0), C.c_double(tf), int(is_jac), _d(Xf))
         return Xf
 
-    def goddard_traj_batch(self, threads, step_nbr, params, t0, tf, X0):
-        """CPU baseline B1 (reference objects, one per thread). Returns (Xf, seconds)."""
+    def goddard_traj_batch(self, threads, step_nbr, params, t0, tf, X0, cpus=None):
+        """CPU baseline B1 (reference objects, one per thread; thread k pinned to logical CPU cpus[k] when given).
+        Returns (Xf, seconds)."""
         X0 = np.ascontiguousarray(X0, dtype=np.float64)
         B = X0.shape[0]
         t0 = np.ascontiguousarray(np.broadcast_to(t0, (B,)), dtype=np.float64)
         tf = np.ascontiguousarray(np.broadcast_to(tf, (B,)), dtype=np.float64)
         params = np.ascontiguousarray(params, dtype=np.float64)
         Xf = np.empty_like(X0)
-        sec = self.lib.ref_goddard_traj_batch(int(threads), int(step_nbr), _d(params), B, _d(t0), _d(tf), _d(X0), _d(Xf))
+        if cpus is not None:
+            cp = np.ascontiguousarray(cpus, dtype=np.int32)
+            assert len(cp) >= threads
+            self.lib.ref_goddard_traj_batch_pinned.restype = C.c_double
+            sec = self.lib.ref_goddard_traj_batch_pinned(int(threads), cp.ctypes.data_as(_ip), int(step_nbr), _d(params), B, _d(t0), _d(tf),
+                                                         _d(X0), _d(Xf))
+        else:
+            sec = self.lib.ref_goddard_traj_batch(int(threads), int(step_nbr), _d(params), B, _d(t0), _d(tf), _d(X0), _d(Xf))
         return Xf, sec

@@ -13,6 +13,9 @@
  *       (2) bench.py cpu_baseline kind "reference": model::ComputeTraj over a batch,
  *           one model object per std::thread (baseline B1).
  */
+#include <pthread.h>
+#include <sched.h>
+
 #include <chrono>
 #include <cstring>
 #include <string>
@@ -194,8 +197,18 @@ int ref_model_block(void *h, int which, double t, const double *X, int len, cons
  * split over `threads` std::threads, one goddard object per thread.  Returns seconds.
  * params = {C,b,KD,kr,u_max,mu1,mu2,singularControl}.
  */
+double ref_goddard_traj_batch_pinned(int threads, const int *cpus, int step_nbr, const double *params, int B,
+                                     const double *t0, const double *tf, const double *X0, double *Xf);
+
 double ref_goddard_traj_batch(int threads, int step_nbr, const double *params, int B,
                               const double *t0, const double *tf, const double *X0, double *Xf)
+{
+    return ref_goddard_traj_batch_pinned(threads, nullptr, step_nbr, params, B, t0, tf, X0, Xf);
+}
+
+/* The same with thread k pinned to logical CPU cpus[k] (NULL: not pinned) -- SURVEY 8d: "P = all physical cores (and P = 1), pinned". */
+double ref_goddard_traj_batch_pinned(int threads, const int *cpus, int step_nbr, const double *params, int B,
+                                     const double *t0, const double *tf, const double *X0, double *Xf)
 {
     static const char *names[8] = {"C", "b", "KD", "kr", "u_max", "mu1", "mu2", "singularControl"};
     if (threads < 1) threads = 1;
@@ -205,18 +218,27 @@ double ref_goddard_traj_batch(int threads, int step_nbr, const double *params, i
         for (int i = 0; i < 8; i++) models[k]->SetParameterDataName(names[i], params[i]);
     }
     auto work = [&](int k) {
+        if (cpus) {
+            cpu_set_t set;
+            CPU_ZERO(&set);
+            CPU_SET(cpus[k], &set);
+            (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+        }
         model *m = models[k];
         for (int b = k; b < B; b += threads) {
             model::mstate v = m->ComputeTraj(t0[b], to_vec(X0 + 14 * (size_t)b, 14), tf[b], 0, 0);
             std::memcpy(Xf + 14 * (size_t)b, v.data(), sizeof(double) * 14);
         }
     };
+    cpu_set_t caller;
+    const bool have_caller = pthread_getaffinity_np(pthread_self(), sizeof(caller), &caller) == 0;
     auto tic = std::chrono::steady_clock::now();
     std::vector<std::thread> pool;
     for (int k = 1; k < threads; k++) pool.emplace_back(work, k);
     work(0);
     for (auto &th : pool) th.join();
     double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - tic).count();
+    if (cpus && have_caller) (void)pthread_setaffinity_np(pthread_self(), sizeof(caller), &caller);   /* work(0) ran on the caller's thread */
     for (auto *g : models) delete g;
     return sec;
 }

@@ -225,6 +225,22 @@ int socp_ctx_create(socp_ctx **out, int model_id, int device)
     return SOCP_OK;
 }
 
+int socp_ctx_clone(const socp_ctx *proto, int device, socp_ctx **out)
+{
+    if (!proto || !out) return fail(nullptr, SOCP_ERR_ARG, "socp_ctx_clone: null argument");
+    *out = nullptr;
+    socp_ctx *c = nullptr;
+    int rc = socp_ctx_create(&c, proto->model_id, device);
+    if (rc != SOCP_OK) return rc;
+    c->P = proto->P;                                   // parameters, switching times, step number, integrator, tolerance
+    c->variant = proto->variant;
+    if (proto->has_problem)
+        rc = socp_problem_set(c, proto->M, proto->mode_t.data(), proto->mode_x.data(), proto->time.data(), proto->xnode.data());
+    if (rc != SOCP_OK) { g_create_error = c->err; socp_ctx_destroy(c); return rc; }
+    *out = c;
+    return SOCP_OK;
+}
+
 int socp_ctx_destroy(socp_ctx *c)
 {
     if (!c) return SOCP_OK;

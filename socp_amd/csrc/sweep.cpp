@@ -1,0 +1,133 @@
+// sweep.cpp -- multi-GPU sweeps from C++ (include/socp_solver.h: socp_sweep_solve, socp_sweep_solve_rank, socp_sweep_shard).
+// Independent shooting problems are dealt out to the GPUs in contiguous blocks; there is no data-path exchange, only the
+// gather of result records at the end (SURVEY 8e level 1).  One process with a thread per device shares the output arrays;
+// the one-process-per-GPU form gathers through the caller's collective (RCCL, MPI).
+#include "../../include/socp_hip.h"
+#include "../../include/socp_solver.h"
+
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+extern "C" void socp_sweep_shard(int P, int rank, int world, int *lo, int *hi)
+{
+    if (world < 1) world = 1;
+    if (rank < 0) rank = 0;
+    if (rank >= world) rank = world - 1;
+    if (P < 0) P = 0;
+    const int base = P / world, rem = P % world;
+    const int a = rank * base + (rank < rem ? rank : rem);
+    if (lo) *lo = a;
+    if (hi) *hi = a + base + (rank < rem ? 1 : 0);
+}
+
+extern "C" int socp_sweep_solve(const socp_ctx *proto, const int *devices, int ndev, int P, const socp_chain_options *opt, const double *Z0,
+                                const double *params, const double *goal, const double *time_prev, const double *x_prev,
+                                const double *time_goal, const double *x_goal, double *Zout, int *info, int *nfev_last, int *nfev_total,
+                                int *solves, double *b_reached, double *param_final, double *fnorm, socp_sweep_stats *stats)
+{
+    if (!proto || !opt || ndev < 1 || ndev > 16 || P < 0 || (P > 0 && (!Z0 || !Zout || !info))) return SOCP_ERR_ARG;
+    const int n = socp_problem_num_param(proto), nodes = socp_problem_num_nodes(proto), nparams = socp_ctx_num_params(proto);
+    int S = 0;
+    socp_ctx_dims(proto, nullptr, &S, nullptr);
+    if (n <= 0 || nodes < 2) return SOCP_ERR_ARG;
+    using clk = std::chrono::steady_clock;
+    const clk::time_point t0 = clk::now();
+    auto ms = [](clk::time_point a) { return std::chrono::duration<double, std::milli>(clk::now() - a).count(); };
+    std::vector<int> rc(ndev, SOCP_OK);
+    std::vector<socp_chain_stats> st(ndev);
+    std::vector<long long> traj(ndev, 0);
+    std::vector<double> wall(ndev, 0.0);
+    auto work = [&](int k) {
+        int lo = 0, hi = 0;
+        socp_sweep_shard(P, k, ndev, &lo, &hi);
+        socp_ctx *ctx = nullptr;
+        rc[k] = socp_ctx_clone(proto, devices ? devices[k] : k, &ctx);
+        if (rc[k] != SOCP_OK) return;
+        const clk::time_point t = clk::now();
+        auto at = [&](const double *a, size_t width) { return a ? a + (size_t)lo * width : nullptr; };
+        std::memset(&st[k], 0, sizeof(st[k]));
+        rc[k] = socp_chains_solve(ctx, hi - lo, opt, Z0 + (size_t)lo * n, at(params, nparams), at(goal, 1), at(time_prev, nodes),
+                                  at(x_prev, (size_t)nodes * S), at(time_goal, nodes), at(x_goal, (size_t)nodes * S), Zout + (size_t)lo * n,
+                                  info + lo, nfev_last ? nfev_last + lo : nullptr, nfev_total ? nfev_total + lo : nullptr,
+                                  solves ? solves + lo : nullptr, b_reached ? b_reached + lo : nullptr, param_final ? param_final + lo : nullptr,
+                                  fnorm ? fnorm + lo : nullptr, &st[k]);
+        wall[k] = ms(t);
+        long long launches = 0;
+        socp_ctx_counters(ctx, &traj[k], &launches);
+        socp_ctx_destroy(ctx);
+    };
+    if (ndev == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int k = 0; k < ndev; k++) th.emplace_back(work, k);
+        for (std::thread &t : th) t.join();
+    }
+    int worst = SOCP_OK;
+    for (int k = 0; k < ndev; k++) if (rc[k] != SOCP_OK) worst = rc[k];
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        stats->ndev = ndev;
+        stats->wall_ms = ms(t0);
+        for (int k = 0; k < ndev; k++) { stats->device_wall_ms[k] = wall[k]; stats->device_rounds[k] = st[k].rounds; stats->trajectories += traj[k]; }
+    }
+    return worst;
+}
+
+extern "C" int socp_sweep_solve_rank(socp_ctx *ctx, int rank, int world, int P, const socp_chain_options *opt, const double *Z0,
+                                     socp_allgather_fn gather, void *user, int gather_on_device, double *Zout, int *info, int *nfev_last,
+                                     int *nfev_total, int *solves, double *fnorm, socp_chain_stats *stats)
+{
+    if (!ctx || !opt || !gather || world < 1 || rank < 0 || rank >= world || P < 0 || (P > 0 && (!Z0 || !Zout || !info))) return SOCP_ERR_ARG;
+    if (opt->kind != SOCP_CHAIN_PLAIN) return SOCP_ERR_UNSUPPORTED;          // continuation chains: socp_sweep_solve / socp_chains_solve per rank
+    const int n = socp_problem_num_param(ctx);
+    if (n <= 0) return SOCP_ERR_ARG;
+    int lo = 0, hi = 0;
+    socp_sweep_shard(P, rank, world, &lo, &hi);
+    const int mine = hi - lo, kmax = (P + world - 1) / world;             // equal-size records: short blocks are padded by one row
+    const int W = n + 5;
+    std::vector<double> z((size_t)mine * n), fn(mine, 0.0), send((size_t)kmax * W, 0.0), recv((size_t)world * kmax * W, 0.0);
+    std::vector<int> inf(mine, 0), nl(mine, 0), nt(mine, 0), so(mine, 0);
+    const int rc = socp_chains_solve(ctx, mine, opt, Z0 + (size_t)lo * n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, z.data(), inf.data(),
+                                     nl.data(), nt.data(), so.data(), nullptr, nullptr, fn.data(), stats);
+    if (rc != SOCP_OK) return rc;
+    for (int k = 0; k < mine; k++) {
+        double *rec = &send[(size_t)k * W];
+        std::memcpy(rec, &z[(size_t)k * n], sizeof(double) * n);
+        rec[n] = fn[k]; rec[n + 1] = inf[k]; rec[n + 2] = nl[k]; rec[n + 3] = nt[k]; rec[n + 4] = so[k];
+    }
+    const long count = (long)kmax * W;
+    int grc = 0;
+    if (gather_on_device) {
+        if (hipSetDevice(socp_ctx_device(ctx)) != hipSuccess) return SOCP_ERR_HIP;
+        double *dsend = nullptr, *drecv = nullptr;
+        if (hipMalloc(&dsend, sizeof(double) * (count ? count : 1)) != hipSuccess) return SOCP_ERR_HIP;
+        if (hipMalloc(&drecv, sizeof(double) * (count ? count : 1) * world) != hipSuccess) { (void)hipFree(dsend); return SOCP_ERR_HIP; }
+        bool ok = hipMemcpy(dsend, send.data(), sizeof(double) * count, hipMemcpyHostToDevice) == hipSuccess;
+        if (ok) grc = gather(user, dsend, count, drecv);
+        ok = ok && grc == 0 && hipMemcpy(recv.data(), drecv, sizeof(double) * count * world, hipMemcpyDeviceToHost) == hipSuccess;
+        (void)hipFree(dsend); (void)hipFree(drecv);
+        if (!ok) return grc != 0 ? SOCP_ERR_ARG : SOCP_ERR_HIP;
+    } else {
+        grc = gather(user, send.data(), count, recv.data());
+        if (grc != 0) return SOCP_ERR_ARG;
+    }
+    for (int r = 0; r < world; r++) {
+        int a = 0, b = 0;
+        socp_sweep_shard(P, r, world, &a, &b);
+        for (int k = 0; k < b - a; k++) {
+            const double *rec = &recv[((size_t)r * kmax + k) * W];
+            std::memcpy(Zout + (size_t)(a + k) * n, rec, sizeof(double) * n);
+            if (fnorm) fnorm[a + k] = rec[n];
+            info[a + k] = (int)rec[n + 1];
+            if (nfev_last) nfev_last[a + k] = (int)rec[n + 2];
+            if (nfev_total) nfev_total[a + k] = (int)rec[n + 3];
+            if (solves) solves[a + k] = (int)rec[n + 4];
+        }
+    }
+    return SOCP_OK;
+}

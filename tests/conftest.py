@@ -17,7 +17,7 @@ def pytest_configure(config):
 def _artefacts():
     """Source-only checkout: build the product libraries and the test programs once."""
     need = [os.path.join(ROOT, "socp_amd", "_build", n) for n in
-            ("libsocp_hip.so", "libsocp_host.so", "bin/goddard_flow", "bin/dint_flow", "bin/covid_flow", "bin/plugin_flow", "bin/interceptor_flow", "bin/api_conventions", "bin/concurrent_solves", "bin/hostmodel_flow", "bin/hostjac_flow",
+            ("libsocp_hip.so", "libsocp_host.so", "bin/goddard_flow", "bin/dint_flow", "bin/covid_flow", "bin/plugin_flow", "bin/interceptor_flow", "bin/api_conventions", "bin/concurrent_solves", "bin/hostmodel_flow", "bin/hostjac_flow", "bin/sweep_flow",
              "plugins/liblqr1d_plugin.so")]
     if not all(os.path.exists(p) for p in need):
         import __graft_entry__

@@ -19,11 +19,11 @@ def _line(out):
 
 def test_bench_line_contract():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--starts", "4096",
-                          "--cpu-seconds", "2"], capture_output=True, text=True, timeout=900)
+                          "--cpu-seconds", "2", "--sweep-starts", "2048"], capture_output=True, text=True, timeout=900)
     d = _line(out)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "exact", "parity", "single_problem",
-                "north_star_128"):
+                "north_star_128", "sweep"):
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["dtype"] == "f64"
     assert d["vs_baseline"] is None and d["higher_is_better"] is True and d["data"] == "synthetic"
@@ -51,15 +51,25 @@ def test_bench_line_contract():
     assert ns["fast"]["full"]["finite"] and ns["exact"]["full"]["finite"]
     if "b0" in c:
         assert c["b0"]["info"] == 1 and c["b0"]["value"] > 0
+    # the strong-scaling leg: a fixed total of starts, solved
+    sw = d["sweep"]
+    assert sw["scaling"] == "strong" and sw["total_starts"] == 2048 and sw["n_gpus"] == 1 and sw["converged"] >= 2030
+    assert abs(sw["solves_per_s"] - 2048 / sw["wall_s"]) <= 1e-6 * sw["solves_per_s"] and sw["trajectories"] > 2048 * 15
+    # CPU baseline as SURVEY 8d asks: one thread and all cores, pinned; the host is named
+    assert c["p1"]["cores"] == 1 and c["p1"]["value"] > 0 and c["cores"] >= c["p1"]["cores"] and c["pinned"] in (True, False)
+    assert isinstance(c["cpu_model"], str) and c["cpu_model"]
 
 
 def test_gpus_2_really_runs_two_ranks():
     """`python bench.py --gpus 2` (no launcher): the parent starts two ranks; here both share device 0 and the collectives
     run over gloo (a one-GPU box), the code path is otherwise the N > 1 path of the driver."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-device0",
-                          "--steps", "2", "--warmup", "1", "--starts", "1024", "--rk4-steps", "1000"],
+                          "--steps", "2", "--warmup", "1", "--starts", "1024", "--rk4-steps", "1000", "--sweep-starts", "301"],
                          capture_output=True, text=True, timeout=900)
     d = _line(out)
+    # the sweep leg at N = 2: a FIXED total (odd: blocks of 151 + 150), every start reported once
+    assert d["sweep"]["n_gpus"] == 2 and d["sweep"]["total_starts"] == 301 and d["sweep"]["starts_per_gpu"] == 151
+    assert d["sweep"]["converged"] + d["sweep"]["stopped_by_round_limit"] >= 295
     assert d["n_gpus"] == 2 and d["ranks_reported"] == 2 and len(d["finite_jacobians"]) == 2
     assert d["finite_jacobians"] == [1024, 1024]
     assert d["config"]["trajectories_per_step_per_gpu"] == 1024 * 15

@@ -130,3 +130,41 @@ def test_multistart_from_a_fresh_thread_uses_the_context_device():
     th.start(); th.join()
     assert np.array_equal(got["z"], ref["z"]) and np.array_equal(got["info"], ref["info"])
     ctx.close()
+
+
+def test_chain_engine_out_of_memory_exits_cleanly():
+    """The engine's error exits: with the card's memory taken, the device-solver engine cannot place its 2 GB of
+    solver state -> SOCP_ERR_HIP, nothing leaked, the context's stream as it was and the context usable; the host-solver engine,
+    asked for speculative FD rows that no longer fit, drops them, retries and solves (no iterate depends on speculation)."""
+    import ctypes as C
+    import torch
+    from socp_amd import capi, sweep
+    ctx = capi.Context(capi.MODEL_GODDARD)
+    ctx.set_params(sweep.GODDARD_PARAMS)
+    ctx.set_step_number(10)
+    ctx.set_variant(capi.VARIANT_LANE_FAST)
+    assert sweep.goddard_multiple_shooting_problem(ctx, 6) == 85
+    P = 20000
+    Z0 = sweep.goddard_multiple_shooting_starts(ctx, sweep.goddard_starts(P, 0.05), 6)
+    L = capi.lib()
+    L.socp_ctx_get_stream.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    before = C.c_void_p()
+    assert L.socp_ctx_get_stream(ctx.h, C.byref(before)) == 0
+    free0, _total = torch.cuda.mem_get_info()
+    hog = torch.empty(free0 - (900 << 20), dtype=torch.uint8, device="cuda")          # leave ~0.9 GB
+    with pytest.raises(capi.SocpError) as e:
+        ctx.chains_solve(Z0, kind=capi.CHAIN_PLAIN, xtol=1e-8, solver=capi.SOLVER_DEVICE)     # needs 20000 x 100 KB of solver state
+    assert e.value.code == capi.ERR_HIP
+    after = C.c_void_p()
+    assert L.socp_ctx_get_stream(ctx.h, C.byref(after)) == 0 and after.value == before.value
+    assert np.all(np.isfinite(ctx.residual(Z0[0])))                                 # the context still works
+    # host solvers: the speculation cache (2 x 1.2 GB) does not fit either; the engine retries without it
+    r = ctx.chains_solve(Z0[:6000], kind=capi.CHAIN_PLAIN, xtol=1e-8, solver=capi.SOLVER_HOST, speculate=1)
+    assert np.all(r["info"] == 1) and r["stats"]["speculative_rounds"] == 0 and r["stats"]["jacobians_from_cache"] == 0
+    del hog
+    torch.cuda.empty_cache()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free1 >= free0 - (64 << 20)                                              # nothing of the failed call is still allocated
+    ok = ctx.chains_solve(Z0[:6000], kind=capi.CHAIN_PLAIN, xtol=1e-8, solver=capi.SOLVER_DEVICE)
+    assert np.array_equal(ok["z"], r["z"]) and np.array_equal(ok["nfev"], r["nfev"])
+    ctx.close()

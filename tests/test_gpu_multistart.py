@@ -68,3 +68,36 @@ def test_multiple_shooting_sweep_lands_on_the_cpu_solution(variant):
     err = np.max(np.abs(out["z"] - zg[None, :]), axis=1) / np.max(np.abs(zg))
     assert np.max(err) <= 1e-8, err.max()
     ctx.close()
+
+
+@pytest.mark.parametrize("mode,count", [("devices", 1), ("ranks", 2), ("ranks", 3)])
+def test_cpp_sweep_entry_points(tmp_path, mode, count):
+    """The C++ multi-GPU entry points (include/socp_solver.h) driven by a C++ program with no Python in it
+    (tests/cpp/sweep_flow.cpp): socp_sweep_solve with one device, and socp_sweep_solve_rank with 2 / 3 ranks emulated by threads
+    that gather through a user collective.  Every start's record equals the one the single-context engine returns, bit for bit,
+    in start order, whatever the sharding."""
+    import json
+    import os
+    import subprocess
+    from socp_amd import capi, sweep
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    P, steps = 37, 50
+    Z0 = sweep.goddard_starts(P, 1e-3)
+    Z0[5, 7:] *= 1.5
+    f = tmp_path / "starts.bin"
+    Z0.tofile(f)
+    exe = os.path.join(root, "socp_amd", "_build", "bin", "sweep_flow")
+    out = subprocess.run([exe, mode, str(count), str(f), str(P), str(steps)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    ctx = capi.Context(capi.MODEL_GODDARD)
+    ctx.set_params(sweep.GODDARD_PARAMS)
+    ctx.set_step_number(steps)
+    ctx.set_variant(capi.VARIANT_LANE_FAST)
+    sweep.goddard_single_shooting_problem(ctx)
+    want = ctx.chains_solve(Z0, kind=capi.CHAIN_PLAIN, xtol=1e-8)
+    assert np.array_equal(np.array(r["z"]), want["z"]) and r["info"] == list(want["info"]) and r["nfev"] == list(want["nfev"])
+    assert np.array_equal(np.array(r["fnorm"]), want["fnorm"])
+    if mode == "devices":
+        assert r["trajectories"] > P * 15
+    ctx.close()

@@ -59,6 +59,22 @@ def test_shard_is_a_partition():
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_c_abi_shard_is_the_same_partition():
+    """socp_sweep_shard (what the C++ multi-GPU entry points use) == socp_amd.sweep.shard."""
+    import ctypes as C
+    from socp_amd import capi
+    from socp_amd.sweep import shard
+    L = capi.lib()
+    L.socp_sweep_shard.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.socp_sweep_shard.restype = None
+    for P in (0, 1, 7, 8, 301, 4096, 65536):
+        for W in (1, 2, 3, 8, 16):
+            for r in range(W):
+                lo, hi = C.c_int(-1), C.c_int(-1)
+                L.socp_sweep_shard(P, r, W, C.byref(lo), C.byref(hi))
+                assert (lo.value, hi.value) == shard(P, r, W), (P, W, r)
+
+
 def test_two_rank_sweep_matches_single_process(tmp_path, built):
     P, world = 7, 2                      # odd: the shards differ in size (4 + 3)
     mp.spawn(_worker, args=(world, 29613, P, str(tmp_path)), nprocs=world, join=True)
