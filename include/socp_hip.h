@@ -125,7 +125,10 @@ int socp_integrate_batch_dev(socp_ctx *ctx, int B, const double *d_t0, const dou
 /* replaces: the observer form of odeTools::integrate (odeTools.cpp:103-123) used by the trace replay
  * (shooting.cpp:496-544, model.hpp:401-407): one trajectory, the state after every step kept.
  * dense: [cap][len], times: [cap]; row 0 = (t0, X0), row k = accumulated time and state after k
- * steps; *rows = steps + 1 (rows beyond cap are counted, not stored).  sw: NULL or 2 values. */
+ * steps; *rows = steps + 1 (rows beyond cap are counted, not stored).  sw: NULL or 2 values.
+ * Under SOCP_INT_DOPRI5 (the reference built with -D_USE_BOOST: odeTools.cpp:108, integrate_adaptive with the observer) the rows
+ * are the adaptive integrator's own accepted steps -- their number is only known afterwards: call again with cap >= *rows
+ * when *rows > cap. */
 int socp_integrate_dense(socp_ctx *ctx, double t0, double tf, const double *sw, const double *X0,
                          double *dense, double *times, int cap, int *rows);
 /* Same, also returning each row's two per-trajectory auxiliary scalars in aux[cap][2] (NULL: not wanted).  They

@@ -423,8 +423,6 @@ int socp_integrate_dense_aux(socp_ctx *c, double t0, double tf, const double *sw
 {
     if (!c) return SOCP_ERR_ARG;
     if (!X0 || !dense || !times || !rows || cap < 1) return fail(c, SOCP_ERR_ARG, "integrate_dense: bad argument");
-    if (c->P.integrator != SOCP_INT_RK4)
-        return fail(c, SOCP_ERR_UNSUPPORTED, "integrate_dense: dense output exists for the fixed-step integrator only");
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t S = c->S;
     HIP_TRY(c, c->s_in.reserve(sizeof(double) * S));

@@ -141,9 +141,11 @@ struct Lane {
 
     // `hook(t, X)` runs before every step and reports whether it rewrote X (the interceptor's chart change): the
     // FSAL derivative is then recomputed.  sw0/sw1 are references because such a hook may also change them.
-    template <class Hook = NoStepHook>
+    // `after(t, X)` sees the state at the end of every ACCEPTED step: the observer of the reference's adaptive integrate()
+    // (odeTools.cpp:103-123 with the Boost branch at :108 -- integrate_adaptive calls it at t0 and after each step).
+    template <class Hook = NoStepHook, class After = NoObserver>
     __device__ static __forceinline__ void integrate_dopri5(const ModelParams &P, const double &sw0, const double &sw1,
-                                                           double t0, double tf, double (&X)[S], Hook &&hook = Hook())
+                                                           double t0, double tf, double (&X)[S], Hook &&hook = Hook(), After &&after = After())
     {
         const double eps = 2.220446049250313e-16;
         double t = t0, h = (tf - t0) / P.step_nbr;
@@ -171,6 +173,7 @@ struct Lane {
                 }
 #pragma unroll
                 for (int i = 0; i < S; i++) { X[i] = xn[i]; k1[i] = kn[i]; }
+                after(t, X);
             }
             h = tf - t;
             have_k1 = false;
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, WPE))) vo
 // time t and state after k steps -- exactly what the reference's observer is shown.  Not hot.
 // A kCustomTraj model reports the rows its own ComputeTraj traces, with the two auxiliary scalars of each row in
 // aux[row][2] (may be null).
-template <class Mdl>
+template <class Mdl, int INTEG = 0>
 __global__ void traj_dense_kernel(ModelParams P, double t0, double tf, double sw0, double sw1,
                                   const double *__restrict__ X0, double *__restrict__ dense,
                                   double *__restrict__ times, int cap, int *__restrict__ rows, double *__restrict__ aux)
@@ -273,7 +276,7 @@ __global__ void traj_dense_kernel(ModelParams P, double t0, double tf, double sw
         for (int k = 0; k < S; k++) X[k] = X0[k];
         int r = 0;
         double a0 = sw0, a1 = sw1;
-        Mdl::template compute_traj<0>(P, a0, a1, t0, tf, X, [&](double t, const double (&Xr)[S], double b0, double b1) {
+        Mdl::template compute_traj<INTEG>(P, a0, a1, t0, tf, X, [&](double t, const double (&Xr)[S], double b0, double b1) {
             if (r < cap) {
 #pragma unroll
                 for (int k = 0; k < S; k++) dense[(long)r * S + k] = Xr[k];
@@ -297,20 +300,28 @@ __global__ void traj_dense_kernel(ModelParams P, double t0, double tf, double sw
     times[0] = t0;
     if (aux) { aux[0] = sw0; aux[1] = sw1; }
     int r = 1;
-    const double dt = (tf - t0) / P.step_nbr;
-    double t = t0;
-    int guard = P.step_nbr + 8;
-    while (t < (tf - dt / 2) && guard-- > 0) {
-        const double step = (t + dt > tf) ? (tf - t) : dt;
-        Lane<Mdl>::rk4(P, sw0, sw1, t, X, step);
-        t += dt;
+    auto keep = [&](double t, const double (&Xr)[S]) {
         if (r < cap) {
 #pragma unroll
-            for (int k = 0; k < S; k++) dense[(long)r * S + k] = X[k];
+            for (int k = 0; k < S; k++) dense[(long)r * S + k] = Xr[k];
             times[r] = t;
             if (aux) { aux[2 * r] = sw0; aux[2 * r + 1] = sw1; }
         }
         r++;
+    };
+    if constexpr (INTEG == 1) {
+        // the adaptive integrator's own steps: row k = time and state at the end of the k-th accepted step
+        Lane<Mdl>::integrate_dopri5(P, sw0, sw1, t0, tf, X, NoStepHook(), keep);
+    } else {
+        const double dt = (tf - t0) / P.step_nbr;
+        double t = t0;
+        int guard = P.step_nbr + 8;
+        while (t < (tf - dt / 2) && guard-- > 0) {
+            const double step = (t + dt > tf) ? (tf - t) : dt;
+            Lane<Mdl>::rk4(P, sw0, sw1, t, X, step);
+            t += dt;
+            keep(t, X);
+        }
     }
     *rows = r;
 }

@@ -117,12 +117,23 @@ hipError_t SOCP_CAT(dense_, SOCP_FLAVOUR)(int model_id, hipStream_t st, const Mo
                                           double sw0, double sw1, const double *X0, double *dense, double *times,
                                           int cap, int *rows, double *aux)
 {
-    if (model_id == 1)
-        hipLaunchKernelGGL(traj_dense_kernel<SOCP_GODDARD>, dim3(1), dim3(64), 0, st, P, t0, tf, sw0, sw1, X0, dense, times, cap, rows, aux);
-    else if (model_id == 3)
-        hipLaunchKernelGGL(traj_dense_kernel<SOCP_COVID>, dim3(1), dim3(64), 0, st, P, t0, tf, sw0, sw1, X0, dense, times, cap, rows, aux);
-    else
-        hipLaunchKernelGGL(traj_dense_kernel<SOCP_DINT>, dim3(1), dim3(64), 0, st, P, t0, tf, sw0, sw1, X0, dense, times, cap, rows, aux);
+#ifdef SOCP_HAVE_DOPRI5
+#define SOCP_DENSE_LAUNCH(MDL)                                                                                                              \
+    do {                                                                                                                                    \
+        if (P.integrator == 1) hipLaunchKernelGGL((traj_dense_kernel<MDL, 1>), dim3(1), dim3(64), 0, st, P, t0, tf, sw0, sw1, X0, dense, times, cap, rows, aux); \
+        else hipLaunchKernelGGL((traj_dense_kernel<MDL, 0>), dim3(1), dim3(64), 0, st, P, t0, tf, sw0, sw1, X0, dense, times, cap, rows, aux);               \
+    } while (0)
+#else
+#define SOCP_DENSE_LAUNCH(MDL)                                                                                                              \
+    do {                                                                                                                                    \
+        if (P.integrator == 1) return hipErrorInvalidValue;      /* the adaptive instantiations live in the reference-order translation unit */ \
+        hipLaunchKernelGGL((traj_dense_kernel<MDL, 0>), dim3(1), dim3(64), 0, st, P, t0, tf, sw0, sw1, X0, dense, times, cap, rows, aux);      \
+    } while (0)
+#endif
+    if (model_id == 1) SOCP_DENSE_LAUNCH(SOCP_GODDARD);
+    else if (model_id == 3) SOCP_DENSE_LAUNCH(SOCP_COVID);
+    else SOCP_DENSE_LAUNCH(SOCP_DINT);
+#undef SOCP_DENSE_LAUNCH
     return hipGetLastError();
 }
 

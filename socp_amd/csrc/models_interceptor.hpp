@@ -571,9 +571,10 @@ struct InterceptorT {
             if (ph == 1) stage = 0.0;
             obs(ta, X, stage, chart);
             if constexpr (INTEG == 1) {
+                // the observer sees the state after every accepted step (the last one ends at tb)
                 Lane<InterceptorT>::integrate_dopri5(P, stage, chart, ta, tb, X,
-                                                         [&](double, double (&Xc)[S]) { return set_chart(P, chart, Xc); });
-                obs(tb, X, stage, chart);
+                                                         [&](double, double (&Xc)[S]) { return set_chart(P, chart, Xc); },
+                                                         [&](double ts, const double (&Xs)[S]) { obs(ts, Xs, stage, chart); });
             } else {
                 const double dt = (tb - ta) / P.step_nbr;
                 double t = ta;

@@ -103,7 +103,8 @@ template <class Mdl>
 hipError_t dense(hipStream_t st, const ModelParams &P, double t0, double tf, double sw0, double sw1, const double *X0,
                  double *out, double *times, int cap, int *rows, double *aux)
 {
-    hipLaunchKernelGGL(traj_dense_kernel<Mdl>, dim3(1), dim3(64), 0, st, P, t0, tf, sw0, sw1, X0, out, times, cap, rows, aux);
+    if (P.integrator == 1) hipLaunchKernelGGL((traj_dense_kernel<Mdl, 1>), dim3(1), dim3(64), 0, st, P, t0, tf, sw0, sw1, X0, out, times, cap, rows, aux);
+    else hipLaunchKernelGGL((traj_dense_kernel<Mdl, 0>), dim3(1), dim3(64), 0, st, P, t0, tf, sw0, sw1, X0, out, times, cap, rows, aux);
     return hipGetLastError();
 }
 template <class Mdl>

@@ -158,15 +158,22 @@ void odeTools::integrate(modelStruct const &_model, odeVector &X, double const &
     if (!(dt == dt_model))
         throw std::runtime_error("odeTools::integrate: dt must equal (tf - t0)/DeviceStepNumber() for the device path");
     if (_model.m_isJac) throw std::runtime_error("odeTools::integrate: tracing the variational state is not supported");
-    if (AdaptiveIntegrator()) throw std::runtime_error("odeTools::integrate: trace replay is available with the fixed-step integrator only");
     socp_ctx *ctx = m->DeviceContext();
     const int S = (int)X.size();
-    const int cap = m->DeviceStepNumber() + 10;      // the device loop stops after at most stepNbr + 8 steps (integrator.hpp)
-    std::vector<double> dense((size_t)cap * S), times(cap);
+    // fixed step: the device loop stops after at most stepNbr + 8 steps (integrator.hpp); adaptive: the number of accepted steps is
+    // only known afterwards -- start with room for 512 and ask again when the trajectory took more
+    int cap = AdaptiveIntegrator() ? 512 : m->DeviceStepNumber() + 10;
+    std::vector<double> dense, times;
     int rows = 0;
-    if (socp_integrate_dense(ctx, t0, tf, nullptr, X.data(), dense.data(), times.data(), cap, &rows) != SOCP_OK)
-        throw std::runtime_error(std::string("odeTools::integrate: ") + socp_last_error(ctx));
-    if (rows > cap) throw std::runtime_error("odeTools::integrate: the device reported more rows than the step guard allows");
+    for (int attempt = 0; attempt < 2; attempt++) {
+        dense.assign((size_t)cap * S, 0.0);
+        times.assign(cap, 0.0);
+        if (socp_integrate_dense(ctx, t0, tf, nullptr, X.data(), dense.data(), times.data(), cap, &rows) != SOCP_OK)
+            throw std::runtime_error(std::string("odeTools::integrate: ") + socp_last_error(ctx));
+        if (rows <= cap) break;
+        if (!AdaptiveIntegrator()) throw std::runtime_error("odeTools::integrate: the device reported more rows than the step guard allows");
+        cap = rows;
+    }
     for (int k = 0; k < rows; k++) {
         odeVector row(dense.begin() + (size_t)k * S, dense.begin() + (size_t)(k + 1) * S);
         _observer(row, times[k]);

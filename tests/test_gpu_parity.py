@@ -375,3 +375,44 @@ def test_dopri5_fast_flavour_agrees_with_reference_order(gctx, gfast):
         out.append(c.integrate_batch(0.0, GODDARD_TF, X0))
         c.set_integrator(capi.INT_RK4)
     assert np.max(np.abs(out[0] - out[1]) / np.maximum(1.0, np.abs(out[0]))) < 1e-8
+
+
+@pytest.mark.parametrize("flavour", ["exact", "fast"])
+def test_dopri5_dense_output_is_the_integrators_own_steps(goracle, flavour):
+    """The observer form of the reference's adaptive integrate() (odeTools.cpp:103-123, Boost branch at :108): the trace of an
+    adaptive segment is the state at t0 and at the end of every ACCEPTED step.  Parity UNPINNED (no Boost
+    offline): checked by construction -- in the reference-order flavour the last row is the plain adaptive result bit for bit
+    (same arithmetic, same step-size decisions; the throughput flavour is contracted per kernel instantiation: rounding level),
+    the rows sit on the trajectory (a fine fixed-step solution integrated to each row's time) within 100 x tol, and the number of
+    steps is the restatement's (+-1: `pow` in the controller rounds differently on the device)."""
+    from socp_amd import capi
+    ctx = capi.Context(capi.MODEL_GODDARD)
+    ctx.set_variant(capi.VARIANT_LANE_EXACT if flavour == "exact" else capi.VARIANT_LANE_FAST)
+    for c in (ctx, goracle):
+        c.set_param("mu2", 1.0)
+        c.set_param("KD", 310.0)
+    ctx.set_step_number(10)
+    goracle.m.step_nbr = 10
+    X0 = goddard_costate_batch(3, 1e-3)[2]
+    for tol in (1e-6, 1e-9):
+        ctx.set_integrator(capi.INT_DOPRI5, tol)
+        times, dense = ctx.integrate_dense(0.0, GODDARD_TF, X0)
+        plain = ctx.integrate_batch(0.0, GODDARD_TF, X0[None, :])[0]
+        assert times[0] == 0.0 and np.array_equal(dense[0], X0)
+        assert times[-1] == GODDARD_TF
+        if flavour == "exact":
+            assert np.array_equal(dense[-1], plain)
+        else:
+            assert relerr(dense[-1][None, :], plain[None, :]) <= 1e-9
+        assert np.all(np.diff(times) > 0) and len(times) >= 4
+        _, accepted, _rej = goracle.traj_dopri5(0.0, X0, GODDARD_TF, tol)
+        assert abs((len(times) - 1) - accepted) <= 1
+        # a cap smaller than the trajectory: rows are counted, not stored, and the stored ones are the first ones
+        t_short, d_short = ctx.integrate_dense(0.0, GODDARD_TF, X0, cap=3)
+        assert len(t_short) == 3 and np.array_equal(d_short, dense[:3])
+        ctx.set_integrator(capi.INT_RK4)
+        ctx.set_step_number(20000)
+        fine = ctx.integrate_batch(np.zeros(len(times) - 1), times[1:], np.repeat(X0[None, :], len(times) - 1, axis=0))
+        ctx.set_step_number(10)
+        assert relerr(dense[1:], fine) <= 100 * tol
+    ctx.close()

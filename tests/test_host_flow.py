@@ -143,3 +143,44 @@ def test_flow_with_adaptive_integrator(tmp_path):
     stages = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
     assert out.returncode == 0 and stages[0]["info"] == 1, out.stderr
     assert rel(stages[0]["z"], g["z"]) <= 5e-2
+
+
+def test_trace_replay_of_an_adaptive_solve(tmp_path):
+    """shooting::Trace under the -D_USE_BOOST configuration (VERDICT r2 #4 / #8): the observer form of the adaptive integrate()
+    (odeTools.cpp:103-123) -- the trace of a segment is its first row plus one row per ACCEPTED step, so its length is the
+    integrator's business; every row is a state ON the solved trajectory (the fine fixed-step solution from the segment's node
+    to the row's time, to the text format's six digits), each segment ends where the next begins to the solver tolerance, and
+    the Hamiltonian column is constant along the trajectory (autonomous problem).  Parity of the adaptive integrator: unpinned."""
+    from oracle.oracle import Oracle, MODEL_GODDARD
+    g = SINGLE[(3, 1e-6)]
+    trace = tmp_path / "trace.dat"
+    zf = tmp_path / "z.txt"
+    zf.write_text(" ".join(repr(v) for v in g["init_z"]))
+    exe = os.path.join(BIN, "goddard_flow")
+    out = subprocess.run([exe, "stage", "3", "10", "1", "1e-8", str(zf), str(trace)], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, SOCP_VARIANT="exact", SOCP_FLOW_ADAPTIVE="1"))
+    assert out.returncode == 0, out.stderr
+    rec = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")][0]
+    assert rec["info"] == 1
+    z = np.array(rec["z"])
+    rows = np.loadtxt(trace)
+    assert rows.shape[1] == 20 and rows.shape[0] != 66 and rows.shape[0] >= 6 * 3
+    tf = z[84]
+    tl = [0.0 + i * (tf - 0.0) / 6 for i in range(7)]
+    starts = [k for k in range(len(rows)) if any(abs(rows[k, 0] - t) <= 1e-6 * max(1.0, abs(t)) for t in tl[:6]) and
+              (k == 0 or rows[k, 0] <= rows[k - 1, 0] + 1e-12)]
+    assert len(starts) == 6                                             # six segments, each opening at its node time
+    o = Oracle(MODEL_GODDARD, step_nbr=4000)
+    o.set_param("mu2", 0.2)
+    bounds = starts + [len(rows)]
+    for i in range(6):
+        seg = rows[bounds[i]:bounds[i + 1]]
+        X0 = z[14 * i:14 * (i + 1)]
+        assert np.all(np.abs(seg[0, 1:15] - X0) <= 1e-5 * np.abs(X0) + 1e-12)
+        assert np.all(np.diff(seg[:, 0]) > 0) and abs(seg[-1, 0] - tl[i + 1]) <= 1e-6
+        for row in seg[1:]:
+            want = o.traj(tl[i], X0, row[0])
+            # (the row's TIME is printed with six digits too: the state is compared where the fine solution is at that rounded time)
+            assert np.all(np.abs(row[1:15] - want) <= 5e-4 * np.abs(want) + 1e-6), (i, row[0])
+    H = rows[:, 18]
+    assert np.max(np.abs(H - H[0])) <= 1e-4 * max(1.0, abs(H[0]))
