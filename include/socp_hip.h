@@ -164,6 +164,11 @@ int socp_problem_num_nodes(const socp_ctx *ctx);   /* M + 1 of the problem set (
  * are those of socp_problem_set.  With d_params the Goddard control law is chosen per problem from its own mu2. */
 int socp_problem_set_blocks_dev(socp_ctx *ctx, const double *d_params, int stride, const double *d_time,
                                 const double *d_xnode);
+/* Goddard with d_params: a promise that EVERY parameter block has mu2 > 0 (the smooth control law of goddard.cpp:137-145), which
+ * lets the batch launches take the kernel specialised on that law (three waves per SIMD instead of two; with shared parameters
+ * the library sees mu2 itself).  Stays in force until socp_problem_set or a call with all_smooth = 0.  A wrong promise computes
+ * the smooth law for blocks that asked for the bang / singular / off law. */
+int socp_problem_blocks_all_smooth(socp_ctx *ctx, int all_smooth);
 /* host-pointer form of socp_residual_batch with per-row blocks (any of params / time / xnode may be NULL) */
 int socp_residual_batch_blocks(socp_ctx *ctx, int B, const double *Z, const double *params, int stride,
                                const double *time, const double *xnode, double *F);

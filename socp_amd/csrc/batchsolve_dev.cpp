@@ -83,6 +83,16 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
     blk.init(P, *opt, nparams, nodes, S, dim, params, shared_params, shared_sw, goal, time_prev, x_prev, time_goal, x_goal);
     const bool pp_params = blk.pp_params, pp_bound = blk.pp_bound;
     const int stride = blk.stride;
+    // Goddard chains with their own parameters: when every chain is on the smooth control law for the whole call (mu2 > 0 at its
+    // start and, if mu2 is the parameter being moved, at its goal), the launches may take the smooth-law kernels
+    if (pp_params && socp_ctx_model_id(ctx) == SOCP_MODEL_GODDARD) {
+        bool smooth = true;
+        for (int p = 0; p < P && smooth; p++) {
+            smooth = blk.pblock[(size_t)p * stride + 6] > 0;
+            if (smooth && kind == SOCP_CHAIN_PARAM && opt->param_index == 6) smooth = goal[p] > 0 && blk.rstart[p] > 0;
+        }
+        socp_problem_blocks_all_smooth(ctx, smooth ? 1 : 0);
+    }
 
     std::vector<socp::chains::ChainCore> ch(P);
     for (int p = 0; p < P; p++) {
@@ -275,6 +285,7 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
         advflag.assign(adv.size(), 0);
     }
     socp_problem_set_blocks_dev(ctx, nullptr, 0, nullptr, nullptr);
+    socp_problem_blocks_all_smooth(ctx, 0);
     socp_ctx_set_stream(ctx, main_stream, 0);
     (void)hipStreamSynchronize(fs);
     (void)hipStreamSynchronize(main_stream);

@@ -70,6 +70,7 @@ struct socp_ctx {
     // grow-only staging for the host-pointer entry points
     DevBuf s_t0, s_tf, s_sw, s_in, s_out, s_aux, s_var;
 
+    bool blocks_smooth_hint = false;  // socp_problem_blocks_all_smooth: every per-problem parameter block has mu2 > 0
     long long n_traj = 0, n_launch = 0;
     std::string err;
 };
@@ -607,7 +608,8 @@ int socp_problem_set(socp_ctx *c, int M, const int *mode_t, const int *mode_x, c
     c->pb.node_kind = di + off_kind; c->pb.lo = di + off_lo; c->pb.hi = di + off_hi;
     c->pb.ft_row = di + off_ft; c->pb.mode_x = di + off_mx;
     c->pb.time = dd; c->pb.xnode = dd + nI;
-    c->pb.pp_params = c->pb.pp_time = c->pb.pp_xnode = nullptr; c->pb.pp_stride = 0;   // a new problem starts without per-problem blocks
+    c->pb.pp_params = c->pb.pp_time = c->pb.pp_xnode = nullptr; c->pb.pp_stride = 0; c->pb.pp_smooth = 0;   // a new problem starts without per-problem blocks
+    c->blocks_smooth_hint = false;
     c->has_problem = true;
     return SOCP_OK;
 }
@@ -623,6 +625,16 @@ int socp_problem_set_blocks_dev(socp_ctx *c, const double *d_params, int stride,
     c->pb.pp_stride = d_params ? stride : 0;
     c->pb.pp_time = d_time;
     c->pb.pp_xnode = d_xnode;
+    c->pb.pp_smooth = (d_params && c->blocks_smooth_hint) ? 1 : 0;
+    return SOCP_OK;
+}
+
+int socp_problem_blocks_all_smooth(socp_ctx *c, int all_smooth)
+{
+    if (!c) return SOCP_ERR_ARG;
+    if (!c->has_problem) return fail(c, SOCP_ERR_ARG, "problem_blocks_all_smooth: no problem set");
+    c->blocks_smooth_hint = all_smooth != 0;
+    c->pb.pp_smooth = (c->pb.pp_params && c->blocks_smooth_hint) ? 1 : 0;
     return SOCP_OK;
 }
 

@@ -41,6 +41,10 @@ struct ProblemDev {
     const double *pp_time;
     const double *pp_xnode;
     int pp_stride;
+    // Goddard only: the caller guarantees that EVERY block of pp_params has mu2 > 0 (smooth control law, goddard.cpp:137-145), so
+    // the launch may take the smooth-law specialisation (156 instead of 254 VGPRs: three waves per SIMD instead of two).  The
+    // lock-step engine sets it once per call from its chains' parameters; 0 = unknown -> the general-law kernel.
+    int pp_smooth;
 };
 
 // the per-problem view of (P, pb) for problem q; every index is static so the blocks stay in registers

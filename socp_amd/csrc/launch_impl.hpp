@@ -30,24 +30,24 @@ namespace socp {
     } while (0)
 
 // model_id 1 = Goddard (smooth-law specialisation when mu2 > 0, parameter slot 6), 2 = double integrator
-// With per-problem parameter blocks the control law may differ between problems of one launch, so the Goddard
-// smooth-law specialisation (chosen from the SHARED mu2) is not used there.
+// With per-problem parameter blocks the control law may differ between problems of one launch: the Goddard smooth-law
+// specialisation is then taken only when the caller vouches for every block (ProblemDev::pp_smooth).
 #define SOCP_DISPATCH_MODELS(KERNEL, PP, SMOOTH_OK, GRID, LDS, ST, ...)                                  \
     do {                                                                                                \
-        if (model_id == 1 && (SMOOTH_OK) && P.p[6] > 0) SOCP_LAUNCH_MDL(KERNEL, SOCP_GODDARD_SMOOTH, PP, GRID, GRID, LDS, ST, __VA_ARGS__); \
+        if (model_id == 1 && (SMOOTH_OK)) SOCP_LAUNCH_MDL(KERNEL, SOCP_GODDARD_SMOOTH, PP, GRID, GRID, LDS, ST, __VA_ARGS__); \
         else if (model_id == 1) SOCP_LAUNCH_MDL(KERNEL, SOCP_GODDARD, PP, GRID, GRID, LDS, ST, __VA_ARGS__); \
         else if (model_id == 3) SOCP_LAUNCH_MDL(KERNEL, SOCP_COVID, PP, GRID, GRID, LDS, ST, __VA_ARGS__);  \
         else SOCP_LAUNCH_MDL(KERNEL, SOCP_DINT, PP, GRID, GRID, LDS, ST, __VA_ARGS__);                      \
     } while (0)
 // trajectory kernel (no shooting problem)
-#define SOCP_DISPATCH_HOT(KERNEL, GRID, ST, ...) SOCP_DISPATCH_MODELS(KERNEL, false, true, GRID, 0, ST, __VA_ARGS__)
+#define SOCP_DISPATCH_HOT(KERNEL, GRID, ST, ...) SOCP_DISPATCH_MODELS(KERNEL, false, P.p[6] > 0, GRID, 0, ST, __VA_ARGS__)
 // kernels that read a shooting problem `pb`: per-problem blocks select the PERPROB instantiation
 #define SOCP_DISPATCH_PB_LDS(KERNEL, GRID, LDS, ST, ...)                                                \
     do {                                                                                                \
         if (pb.pp_params || pb.pp_time || pb.pp_xnode)                                                  \
-            SOCP_DISPATCH_MODELS(KERNEL, true, pb.pp_params == nullptr, GRID, LDS, ST, __VA_ARGS__); \
+            SOCP_DISPATCH_MODELS(KERNEL, true, pb.pp_params ? pb.pp_smooth != 0 : P.p[6] > 0, GRID, LDS, ST, __VA_ARGS__); \
         else                                                                                            \
-            SOCP_DISPATCH_MODELS(KERNEL, false, true, GRID, LDS, ST, __VA_ARGS__);                \
+            SOCP_DISPATCH_MODELS(KERNEL, false, P.p[6] > 0, GRID, LDS, ST, __VA_ARGS__);                \
     } while (0)
 #define SOCP_DISPATCH_PB(KERNEL, GRID, ST, ...) SOCP_DISPATCH_PB_LDS(KERNEL, GRID, 0, ST, __VA_ARGS__)
 
