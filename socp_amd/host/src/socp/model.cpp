@@ -35,6 +35,8 @@ socp_ctx *model::DeviceContext() const
         throw std::runtime_error(std::string("model: ") + socp_last_error(deviceCtx_));
     if (socp_ctx_set_integrator(deviceCtx_, AdaptiveIntegrator() ? SOCP_INT_DOPRI5 : SOCP_INT_RK4, odeIntTol) != SOCP_OK)
         throw std::runtime_error(std::string("model: ") + socp_last_error(deviceCtx_));
+    if (deviceVariant_ >= 0 && socp_ctx_set_variant(deviceCtx_, deviceVariant_) != SOCP_OK)
+        throw std::runtime_error(std::string("model: ") + socp_last_error(deviceCtx_));
     const std::vector<real> sw = DeviceSwitchingTimes();
     socp_ctx_set_switching_times(deviceCtx_, sw.data(), (int)sw.size());
     return deviceCtx_;

@@ -68,6 +68,12 @@ public:
     virtual int DeviceStepNumber() const { return stepNbr; }
     // switching times the control law reads (goddard); empty otherwise
     virtual std::vector<real> DeviceSwitchingTimes() const { return std::vector<real>(); }
+    // arithmetic flavour of this model's device kernels: SOCP_VARIANT_AUTO (default: the reference operation order,
+    // bit-identical to the CPU path), SOCP_VARIANT_LANE_EXACT, or SOCP_VARIANT_LANE_FAST (restructured arithmetic, within
+    // north_star's 1e-8 of it, ~3.6x the throughput -- bench.py reports both).  Without a call the environment variable
+    // SOCP_VARIANT=exact|fast decides.  Takes effect at the next solve / evaluation.
+    void SetDeviceVariant(int variant) { deviceVariant_ = variant; }
+    int GetDeviceVariant() const { return deviceVariant_; }
     // lazily created device context with parameters, step number and switching times refreshed
     socp_ctx *DeviceContext() const;
     // evaluate Model / Control / Hamiltonian (SOCP_EVAL_*) of a device model at one point
@@ -76,6 +82,7 @@ public:
 private:
     model() {}
     mutable socp_ctx *deviceCtx_ = nullptr;
+    int deviceVariant_ = -1;            // -1: not chosen by the program (the context keeps its default / SOCP_VARIANT)
 };
 
 #endif

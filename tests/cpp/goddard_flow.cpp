@@ -111,6 +111,8 @@ int main(int argc, char **argv)
     my_shooting.SetPrecision(xtol);
 #ifndef SOCP_REFERENCE_BUILD
     my_shooting.SetJacobianDedup(dedup);
+    // the arithmetic flavour chosen BY THE PROGRAM (model::SetDeviceVariant) rather than by the SOCP_VARIANT environment variable
+    if (const char *fv = std::getenv("SOCP_FLOW_SET_VARIANT")) my_goddard.SetDeviceVariant(std::atoi(fv));
 #else
     (void)dedup;
 #endif
