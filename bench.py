@@ -168,7 +168,8 @@ def fd_rows_inputs(Z, count):
 def host_cpus():
     """(CPU model string, one logical CPU per PHYSICAL core among the CPUs this process may run on).  SURVEY 8d asks for the
     baseline on all physical cores, pinned: hyper-thread siblings are dropped, and a box that grants a share of its host
-    (the GPU boxes give 16 logical CPUs per GPU) is taken as granted."""
+    (the GPU boxes show all 256 logical CPUs of the host in the affinity mask and grant 16 of them through the cgroup CPU quota)
+    is taken as granted: the thread count is the quota.  Returns (model, cpus to pin to, quota or None)."""
     model = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -181,6 +182,20 @@ def host_cpus():
         allowed = sorted(os.sched_getaffinity(0))
     except AttributeError:
         allowed = list(range(os.cpu_count() or 1))
+    # a container's CPU share: the scheduler quota, not the affinity mask (the GPU boxes show 256 logical CPUs and grant 16)
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]                      # cgroup v2
+        if q != "max":
+            quota = int(q) / int(period)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())                    # cgroup v1
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
     seen, cores = set(), []
     for cpu in allowed:
         key = cpu
@@ -192,7 +207,9 @@ def host_cpus():
         if key not in seen:
             seen.add(key)
             cores.append(cpu)
-    return model, cores
+    if quota is not None:
+        cores = cores[:max(1, int(quota))]
+    return model, cores, quota
 
 
 def cpu_baseline(steps_rk4, Z, target_seconds):
@@ -200,7 +217,7 @@ def cpu_baseline(steps_rk4, Z, target_seconds):
     starts).  As SURVEY 8d prescribes: P = all physical cores of this process's CPU share AND P = 1, threads pinned one per
     core, best of 3 shorter samples (a box's first sample is regularly 20-40 % low: frequency ramp, cold caches), CPU named."""
     from oracle import oracle as orc
-    model, cores = host_cpus()
+    model, cores, quota = host_cpus()
 
     if orc.have_ref():
         ref = orc.Ref(orc.MODEL_GODDARD, step_nbr=steps_rk4)
@@ -220,7 +237,7 @@ def cpu_baseline(steps_rk4, Z, target_seconds):
         count, runs = best_of_3(P, 0.7 * target_seconds)
         count1, runs1 = best_of_3(1, 0.3 * target_seconds)
         return {"value": max(runs), "unit": "trajectories/s", "cores": P, "kind": "reference", "per_core": max(runs) / P,
-                "pinned": True, "cpu_model": model, "logical_cpus_allowed": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+                "pinned": True, "cpu_model": model, "cpu_quota": quota, "logical_cpus_allowed": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
                 "samples": runs,
                 "p1": {"value": max(runs1), "cores": 1, "samples": runs1, "trajectories_per_sample": count1},
                 "parallel_efficiency": max(runs) / (P * max(runs1)),

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, WPE))) vo
 // A kCustomTraj model reports the rows its own ComputeTraj traces, with the two auxiliary scalars of each row in
 // aux[row][2] (may be null).
 template <class Mdl, int INTEG = 0>
-__global__ void traj_dense_kernel(ModelParams P, double t0, double tf, double sw0, double sw1,
+__global__ __launch_bounds__(64) void traj_dense_kernel(ModelParams P, double t0, double tf, double sw0, double sw1,
                                   const double *__restrict__ X0, double *__restrict__ dense,
                                   double *__restrict__ times, int cap, int *__restrict__ rows, double *__restrict__ aux)
 {
