@@ -188,3 +188,29 @@ def test_auto_picks_the_device_for_large_sweeps_only():
     forced = ctx.chains_solve(Z0, kind=capi.CHAIN_PLAIN, xtol=1e-8, solver=capi.SOLVER_HOST)
     assert np.array_equal(forced["z"], big["z"]) and np.array_equal(forced["nfev"], big["nfev"])
     ctx.close()
+
+
+@pytest.mark.parametrize("M,order", [(64, 1), (64, 0), (90, 1)])
+def test_large_problems_on_the_device_solver(M, order):
+    """BASELINE config 3's layout (doubleIntegrator way-points, n = 13 M: 832 unknowns = 13 wavefronts per workgroup) and one
+    beyond the workgroup size (M = 90: n = 1170 > 1024 threads, so a thread owns more than one column and the LDS vectors
+    exceed 64 KB): a few chains, host solvers vs device solvers, bit for bit -- hybrj with the batched variational Jacobian and
+    hybrd with forward differences."""
+    from socp_amd import capi
+    ctx = capi.Context(capi.MODEL_DOUBLE_INTEGRATOR)
+    mode_t = [capi.FIXED] + [capi.FREE] * M
+    mode_x = np.zeros((M + 1, 6), dtype=np.int32)
+    mode_x[1:M, 3:6] = capi.CONTINUOUS
+    X = np.zeros((M + 1, 12))
+    X[:, 0] = 20.0 * np.arange(M + 1) / M
+    X[:M, 6:] = 0.001
+    tn = 60.0 * np.arange(M + 1) / M
+    n = ctx.problem_set(mode_t, mode_x, tn, X)
+    assert n == 13 * M
+    z = np.concatenate([X[:M].ravel(), tn[1:]])
+    rng = np.random.default_rng(M + order)
+    Z0 = np.tile(z, (3, 1))
+    Z0[:, 6:12] *= 1 + 0.1 * rng.uniform(-1, 1, (3, 6))
+    host, dev = both(ctx, Z0, kind=capi.CHAIN_PLAIN, xtol=1e-8, analytic_jac=bool(order), max_rounds=12)
+    assert np.all(np.isfinite(dev["z"]))
+    ctx.close()
