@@ -1,5 +1,8 @@
 // sweep_flow.cpp -- a C++ user of the multi-GPU sweep entry points (include/socp_solver.h): no Python, no torch.
 //   sweep_flow devices <ndev> <starts.bin> <P> <rk4_steps>     socp_sweep_solve: one process, ndev GPUs (a thread + a context each)
+//   sweep_flow samedev <ndev> <starts.bin> <P> <rk4_steps>     the same with every "device" = GPU 0 (a one-GPU box): exercises the threads, the
+//                                                               cloned contexts and the slicing of the per-chain arrays; here the chains are
+//                                                               KD continuations (SOCP_CHAIN_PARAM) with their own parameters and goals
 //   sweep_flow ranks   <world> <starts.bin> <P> <rk4_steps>    socp_sweep_solve_rank: `world` ranks emulated by threads that share
 //                                                               device 0, gathering through a user collective (here: shared memory
 //                                                               + a barrier; a real job passes ncclAllGather / MPI_Allgather)
@@ -76,7 +79,23 @@ int main(int argc, char **argv)
     double wall_ms = 0;
     long long trajectories = 0;
     int rc = SOCP_OK;
-    if (mode == "devices") {
+    if (mode == "samedev") {
+        // every chain: KD from 300 to its own goal 310 (1 + 0.01 p), continuation step 0.5 (shooting.cpp:695-778)
+        socp_ctx *proto = goddard_ctx(0, steps);
+        std::vector<int> devs(count, 0);
+        std::vector<double> params((size_t)P * 8), goal(P);
+        const double base[8] = {3.5, 7.0, 300.0, 500.0, 1.0, 1.0, 1.0, -1.0};
+        for (int p = 0; p < P; p++) { std::memcpy(&params[(size_t)p * 8], base, sizeof(base)); goal[p] = 310.0 * (1.0 + 0.01 * p); }
+        opt.kind = SOCP_CHAIN_PARAM; opt.param_index = 2; opt.step = 0.5; opt.step_min = 1e-12;
+        socp_sweep_stats st;
+        std::vector<double> pf(P), br(P);
+        rc = socp_sweep_solve(proto, devs.data(), count, P, &opt, Z0.data(), params.data(), goal.data(), nullptr, nullptr, nullptr, nullptr, Z.data(),
+                              info.data(), nfev.data(), nfev_total.data(), solves.data(), br.data(), pf.data(), fnorm.data(), &st);
+        wall_ms = st.wall_ms; trajectories = st.trajectories;
+        for (int p = 0; p < P && rc == SOCP_OK; p++)
+            if (info[p] == 1 && pf[p] != goal[p]) { std::fprintf(stderr, "chain %d ended at KD = %.17g, goal %.17g\n", p, pf[p], goal[p]); rc = SOCP_ERR_ARG; }
+        socp_ctx_destroy(proto);
+    } else if (mode == "devices") {
         socp_ctx *proto = goddard_ctx(0, steps);
         socp_sweep_stats st;
         rc = socp_sweep_solve(proto, nullptr, count, P, &opt, Z0.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, Z.data(), info.data(),
@@ -118,6 +137,8 @@ int main(int argc, char **argv)
     for (int p = 0; p < P; p++) std::printf("%s%d", p ? ", " : "", info[p]);
     std::printf("], \"nfev\": [");
     for (int p = 0; p < P; p++) std::printf("%s%d", p ? ", " : "", nfev[p]);
+    std::printf("], \"solves\": [");
+    for (int p = 0; p < P; p++) std::printf("%s%d", p ? ", " : "", solves[p]);
     std::printf("], \"fnorm\": [");
     for (int p = 0; p < P; p++) std::printf("%s%.17g", p ? ", " : "", fnorm[p]);
     std::printf("]}\n");

@@ -101,3 +101,34 @@ def test_cpp_sweep_entry_points(tmp_path, mode, count):
     if mode == "devices":
         assert r["trajectories"] > P * 15
     ctx.close()
+
+
+@pytest.mark.parametrize("ndev", [2, 3])
+def test_cpp_sweep_over_several_contexts_with_per_chain_arrays(tmp_path, ndev):
+    """socp_sweep_solve with ndev > 1 on a one-GPU box: every "device" is GPU 0, so what runs is the real thing minus the second
+    card -- a thread and a cloned context per block, the per-chain parameter and goal arrays sliced with the blocks, KD continuation
+    chains (two solves each) -- against the same chains through ONE context."""
+    import json
+    import os
+    import subprocess
+    from socp_amd import capi, sweep
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    P, steps = 23, 50
+    Z0 = sweep.goddard_starts(P, 1e-3)
+    f = tmp_path / "starts.bin"
+    Z0.tofile(f)
+    exe = os.path.join(root, "socp_amd", "_build", "bin", "sweep_flow")
+    out = subprocess.run([exe, "samedev", str(ndev), str(f), str(P), str(steps)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    ctx = capi.Context(capi.MODEL_GODDARD)
+    ctx.set_params(sweep.GODDARD_PARAMS)
+    ctx.set_step_number(steps)
+    ctx.set_variant(capi.VARIANT_LANE_FAST)
+    sweep.goddard_single_shooting_problem(ctx)
+    params = np.tile(np.array([3.5, 7.0, 300.0, 500.0, 1.0, 1.0, 1.0, -1.0]), (P, 1))
+    goal = 310.0 * (1.0 + 0.01 * np.arange(P))
+    want = ctx.chains_solve(Z0, kind=capi.CHAIN_PARAM, param_index=2, step=0.5, goal=goal, params=params, xtol=1e-8)
+    assert np.array_equal(np.array(r["z"]), want["z"]) and r["info"] == list(want["info"]) and r["nfev"] == list(want["nfev"])
+    assert r["solves"] == list(want["solves"]) and max(r["solves"]) >= 2
+    ctx.close()
