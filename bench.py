@@ -87,11 +87,15 @@ def parse_args(argv=None):
                     help="N = 1: only the headline timed region, roofline and cpu_baseline (no exact / parity / "
                          "single_problem / north_star_128 legs)")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-launched N > 1 job (0: pick a free one)")
-    ap.add_argument("--sweep-starts", type=int, default=65536,
+    ap.add_argument("--sweep-starts", type=int, default=None,
                     help="the `sweep` leg: a multi-start sweep of this many single-shooting starts IN TOTAL, sharded over the ranks "
-                         "(strong scaling: what north_star's \"near-linear to 8 GPUs on the multi-start sweep\" is about); 0 skips it")
+                         "(strong scaling: what north_star's \"near-linear to 8 GPUs on the multi-start sweep\" is about); default 65536 "
+                         "(0 = skip; --lean skips it unless a count is given)")
     ap.add_argument("--sweep-max-rounds", type=int, default=40, help="socp_chain_options.max_rounds of the sweep leg")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.sweep_starts is None:
+        args.sweep_starts = 0 if args.lean else 65536
+    return args
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -534,7 +538,7 @@ def main():
         recs = [rec.tolist()]
 
     sweep_rec = None
-    if args.sweep_starts > 0 and not args.lean:
+    if args.sweep_starts > 0:
         sweep_rec = sweep_leg(torch, dist, capi, args, world, rank, local_rank, dev, use_dist)
 
     status = 0

@@ -186,6 +186,11 @@ extern "C" int socp_chains_solve_ex(socp_ctx *ctx, int P, const socp_chain_optio
         }
         socp_problem_blocks_all_smooth(ctx, smooth ? 1 : 0);
     }
+    // ... a promise that ends with this call, whichever way it returns
+    struct SmoothPromise {
+        socp_ctx *c;
+        ~SmoothPromise() { socp_problem_blocks_all_smooth(c, 0); }
+    } smooth_promise{ctx};
 
     using clk = std::chrono::steady_clock;
     const clk::time_point t_begin = clk::now();
@@ -560,7 +565,6 @@ extern "C" int socp_chains_solve_ex(socp_ctx *ctx, int P, const socp_chain_optio
     long long rounds = 0;
     for (const Group &q : grp) rounds = std::max(rounds, q.rounds);
     socp_problem_set_blocks_dev(ctx, nullptr, 0, nullptr, nullptr);
-    socp_problem_blocks_all_smooth(ctx, 0);
     if (rc == SOCP_OK) {
         for (int p = 0; p < P; p++) {
             const Chain &c = ch[p];

@@ -93,6 +93,11 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
         }
         socp_problem_blocks_all_smooth(ctx, smooth ? 1 : 0);
     }
+    // ... a promise that ends with this call, whichever way it returns
+    struct SmoothPromise {
+        socp_ctx *c;
+        ~SmoothPromise() { socp_problem_blocks_all_smooth(c, 0); }
+    } smooth_promise{ctx};
 
     std::vector<socp::chains::ChainCore> ch(P);
     for (int p = 0; p < P; p++) {
@@ -285,7 +290,6 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
         advflag.assign(adv.size(), 0);
     }
     socp_problem_set_blocks_dev(ctx, nullptr, 0, nullptr, nullptr);
-    socp_problem_blocks_all_smooth(ctx, 0);
     socp_ctx_set_stream(ctx, main_stream, 0);
     (void)hipStreamSynchronize(fs);
     (void)hipStreamSynchronize(main_stream);

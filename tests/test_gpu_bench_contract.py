@@ -82,8 +82,10 @@ def test_rccl_code_path_with_one_rank():
     all_reduce(MAX) of the timing and all_gather of the result records on DEVICE tensors.  A one-GPU box cannot host two RCCL
     ranks, so this runs that exact code with a world of one (--force-dist); the two-rank plumbing is the gloo test above."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--lean", "--steps", "2", "--warmup", "1",
-                          "--starts", "1024", "--rk4-steps", "1000", "--cpu-seconds", "0"],
+                          "--starts", "1024", "--rk4-steps", "1000", "--cpu-seconds", "0", "--sweep-starts", "200"],
                          capture_output=True, text=True, timeout=900)
     d = _line(out)
+    # the sweep leg's barrier / all_reduce(MAX, SUM) / gather over RCCL too (a world of one)
+    assert d["sweep"]["total_starts"] == 200 and d["sweep"]["n_gpus"] == 1 and d["sweep"]["converged"] >= 195
     assert d["n_gpus"] == 1 and d["ranks_reported"] == 1 and d["finite_jacobians"] == [1024]
     assert abs(d["value"] - 1024 * 15 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
