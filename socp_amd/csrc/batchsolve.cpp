@@ -140,9 +140,11 @@ extern "C" int socp_chains_solve_ex(socp_ctx *ctx, int P, const socp_chain_optio
         }
         if (solver != SOCP_SOLVER_AUTO && solver != SOCP_SOLVER_HOST && solver != SOCP_SOLVER_DEVICE) return SOCP_ERR_ARG;
         if (solver == SOCP_SOLVER_AUTO) {
-            // the host side is the bottleneck of sweeps with n >= 32 (P factorisations of O(n^3) per refresh, P n^2 doubles over
-            // PCIe); at n = 14 the rounds are kernel latency and the host engine's speculative FD rows are what pays
-            solver = (n >= 32 && n <= 2048 && (double)P * n * n >= 2e6) ? SOCP_SOLVER_DEVICE : SOCP_SOLVER_HOST;
+            // The host side (P state machines advanced on <= 16 threads, P n^2 doubles over PCIe per Jacobian refresh) is the
+            // bottleneck from P n^2 ~ 1.6e6 up: 222 chains of n = 85, 25 of n = 253, 8192 of n = 14.  Measured at n = 14 (10^4
+            // steps, 40-round budget): 8192 starts 0.53 -> 0.49 s, 65 536 starts 0.91 -> 0.70 s.  Below that the rounds are kernel
+            // latency and the host engine's speculative FD rows save rounds (4096 starts: 65 rounds against 68).
+            solver = (n <= 2048 && (double)P * n * n >= 1.6e6) ? SOCP_SOLVER_DEVICE : SOCP_SOLVER_HOST;
             if (solver == SOCP_SOLVER_DEVICE) {
                 size_t free_b = 0, total_b = 0;
                 int prev = -1;
@@ -309,7 +311,7 @@ extern "C" int socp_chains_solve_ex(socp_ctx *ctx, int P, const socp_chain_optio
         // group 0 launches its Jacobians on the context's stream (as the engine always did); residual-type work on a second one
         if (g == 0) q.js = main_stream;
         else { ok = hipStreamCreateWithFlags(&q.js, hipStreamNonBlocking) == hipSuccess; q.own_js = ok; }
-        if (ok && overlap) { ok = hipStreamCreateWithFlags(&q.fs, hipStreamNonBlocking) == hipSuccess; q.own_fs = ok; }
+        if (ok && overlap) { ok = socp::chains::create_residual_stream(&q.fs) == hipSuccess; q.own_fs = ok; }
         else if (ok) q.fs = q.js;
     }
     auto release_streams = [&]() {

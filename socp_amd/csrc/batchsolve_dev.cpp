@@ -13,7 +13,7 @@
 //                  matrix on the way).  No Jacobian, factor or iterate ever crosses PCIe.
 //
 // The chain logic (continuation homotopy, bisection, per-chain parameter / boundary blocks) is the host engine's
-// (chains_common.hpp).  Not here: speculative FD rows and chain groups (they pay at n = 14, where this engine is not chosen).
+// (chains_common.hpp).  Not here: speculative FD rows and chain groups (they pay in small sweeps of small problems, which AUTO leaves to the host engine).
 #include "../../include/socp_hip.h"
 #include "../../include/socp_solver.h"
 
@@ -133,7 +133,7 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
                              dXF.alloc(sizeof(double) * nodes * S * P) && dXJ.alloc(sizeof(double) * nodes * S * P) &&
                              hTF.alloc(sizeof(double) * nodes * P) && hTJ.alloc(sizeof(double) * nodes * P) &&
                              hXF.alloc(sizeof(double) * nodes * S * P) && hXJ.alloc(sizeof(double) * nodes * S * P);
-    if (ok) ok = hipStreamCreateWithFlags(&fs, hipStreamNonBlocking) == hipSuccess;
+    if (ok) ok = socp::chains::create_residual_stream(&fs) == hipSuccess;
     if (!ok) { (void)hipGetLastError(); if (fs) (void)hipStreamDestroy(fs); return SOCP_ERR_HIP; }
     pool.states = static_cast<State *>(dStates.p);
     pool.ws = dWs.d();

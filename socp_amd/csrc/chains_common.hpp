@@ -7,6 +7,8 @@
 #include <cstring>
 #include <vector>
 
+#include <hip/hip_runtime.h>
+
 #include "../../include/socp_hip.h"
 #include "../../include/socp_solver.h"
 
@@ -114,6 +116,21 @@ inline bool after_solve(const socp_chain_options &opt, Blocks &blk, int p, Chain
     blk.set(p, c.b);                                          // the reference also moves Rdata / the boundary data on the failing exit
     if (!running) { c.finished = true; return false; }
     return true;
+}
+
+// The stream of a round's residual-type work.  A round's residual launch and Jacobian launch must run CONCURRENTLY (each is one
+// trajectory latency long).  HIP multiplexes streams of one priority onto a few hardware queues in creation order, so in a process
+// that holds other streams two of ours can land on the same queue and serialise (measured inside bench.py: 40 rounds took 0.90 s
+// instead of 0.64 s of launches).  Streams of another priority come from their own queue pool; the residual work is the small,
+// latency-critical part of a round, so it gets the high-priority one.
+inline hipError_t create_residual_stream(hipStream_t *st)
+{
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least &&
+        hipStreamCreateWithPriority(st, hipStreamNonBlocking, greatest) == hipSuccess)
+        return hipSuccess;
+    (void)hipGetLastError();
+    return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
 }
 
 inline int validate(const socp_chain_options *opt, int nparams, const double *goal, const double *time_prev, const double *x_prev,

@@ -171,8 +171,8 @@ def test_nan_start_round_limit_and_refusals():
 
 
 def test_auto_picks_the_device_for_large_sweeps_only():
-    """socp_chain_options.solver = AUTO: the host engine (with its speculative FD rows) at n = 14, the device engine from
-    n >= 32 and P n^2 >= 2e6 -- visible in the stats: the device engine never forms Jacobians from cached rows."""
+    """socp_chain_options.solver = AUTO: the host engine (with its speculative FD rows) for small sweeps, the device engine from
+    P n^2 >= 1.6e6 -- visible in the stats: the device engine never forms Jacobians from cached rows."""
     from socp_amd import capi, sweep
     ctx = capi.Context(capi.MODEL_GODDARD)
     ctx.set_params(sweep.GODDARD_PARAMS)
