@@ -211,8 +211,27 @@ def host_cpus():
         if key not in seen:
             seen.add(key)
             cores.append(cpu)
-    if quota is not None:
-        cores = cores[:max(1, int(quota))]
+    if quota is not None and len(cores) > int(quota):
+        # Which of the host's cores to pin to: a GPU box is one tenant of a shared host, and every tenant that pinned to "the first
+        # 16" would share them (seen: 1111 against 1853 trajectories/s on otherwise identical boxes).  Take the physical cores that
+        # were least busy over the last 0.2 s.
+        def busy():
+            out = {}
+            for line in open("/proc/stat"):
+                if line.startswith("cpu") and line[3].isdigit():
+                    f = line.split()
+                    v = [int(x) for x in f[1:]]
+                    out[int(f[0][3:])] = (sum(v), v[3] + (v[4] if len(v) > 4 else 0))       # total, idle + iowait
+            return out
+        try:
+            a = busy()
+            time.sleep(0.2)
+            b = busy()
+            load = {c: 1.0 - (b[c][1] - a[c][1]) / max(1, b[c][0] - a[c][0]) for c in cores if c in a and c in b}
+            cores = sorted(cores, key=lambda c: (round(load.get(c, 1.0), 2), c))
+        except (OSError, ValueError, IndexError):
+            pass
+        cores = sorted(cores[:max(1, int(quota))])
     return model, cores, quota
 
 
