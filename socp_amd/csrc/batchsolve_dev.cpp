@@ -148,6 +148,7 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
 
     // (re)start the chains in `list` from their rows of hX (list order) -- they then need an advance
     std::vector<int> adv, advflag, reqF, reqJ, done, restart;
+    const bool blocked_factor = socp::devsolver::blocked_factor_applies(n);
     int adv_jac = 0;                     // the first adv_jac entries of `adv` are chains whose pending request was a Jacobian
     auto start_chains = [&](const std::vector<int> &list) {
         if (list.empty()) return;
@@ -177,6 +178,7 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
             hip_ok(hipMemcpyAsync(dList.p, hList.p, sizeof(int) * count, hipMemcpyHostToDevice, main_stream));
             hip_ok(hipMemcpyAsync(dFlags.p, hFlags.p, sizeof(int) * count, hipMemcpyHostToDevice, main_stream));
             // the chains that have just received a Jacobian come first in the list (adv_jac of them) and go in their own launch
+            if (adv_jac > 0 && blocked_factor) hip_ok(socp::devsolver::launch_factor(main_stream, pool, dList.i(), adv_jac));
             hip_ok(socp::devsolver::launch_advance(main_stream, pool, dList.i(), adv_jac, dFlags.i(), true));
             hip_ok(socp::devsolver::launch_advance(main_stream, pool, dList.i() + adv_jac, count - adv_jac, dFlags.i() + adv_jac, false));
             adv_jac = 0;

@@ -37,6 +37,24 @@ __global__ __launch_bounds__(MAXT) void advance_kernel(Config c, State *states, 
     }
 }
 
+// The factor work of problems that have just received a Jacobian, blocked through LDS (solver_dev.hpp: factor_blocked): ONE
+// wavefront per problem, a thread per column of the 64-column block in hand; LDS = (8 + 64) n doubles.  Leaves A = Q, r, qtf,
+// diag(R), the column norms and the "singular" flag in the problem's workspace / state; the advance kernel then skips its own
+// factorisation (State::pad).
+__global__ __launch_bounds__(64) void factor_kernel(Config c, State *states, double *ws, long ws_stride, const int *__restrict__ list, int count)
+{
+    extern __shared__ double lds[];
+    BlockExec ex;
+    for (int b = blockIdx.x; b < count; b += gridDim.x) {
+        const int p = list[b];
+        Work w(ws + (long)p * ws_stride, c.n, c.ld, lds);
+        const bool sing = factor_blocked(ex, c.n, c.ld, w, lds, lds + (long)c.n * kPanel);
+        __syncthreads();
+        if (threadIdx.x == 0) { states[p].sing = sing ? 1 : 0; states[p].pad = 1; }
+        __syncthreads();
+    }
+}
+
 __global__ void gather_eval_kernel(Config c, const State *states, double *ws, long ws_stride, const int *__restrict__ list, double *__restrict__ dst)
 {
     const int p = list[blockIdx.x];
@@ -143,6 +161,33 @@ hipError_t launch_advance(hipStream_t st, const PoolDev &pool, const int *d_list
     else if (threads <= 512) SOCP_LAUNCH_ADVANCE(512);
     else SOCP_LAUNCH_ADVANCE(1024);
 #undef SOCP_LAUNCH_ADVANCE
+    return hipGetLastError();
+}
+
+// Whether the refreshes of this pool go through the blocked factor kernel.  OFF by default (SOCP_SOLVER_BLOCKED_MIN_N=<n> turns
+// it on from that size up, where panel + block fit a CU's LDS: n <= 284): it removes the re-reads -- one read and one write of
+// the trailing matrix per panel of 8 reflectors instead of three passes per reflector -- but a CU's LDS holds ONE 64-column
+// block at n = 253, i.e. one wavefront per CU, and a lone wavefront cannot hide the latency of its own LDS reads and of the
+// dependent FP64 adds of an order-preserving dot product.  Measured, 2048 problems of n = 253: 142 ms of solver kernels
+// against 102 ms in place (256 problems: 20.3 against 18.8 ms); n = 127: 37 against 29 ms; n = 85: 65 against 58 ms.  The
+// in-place form streams 200 x the algorithmic bytes but does it with 8192 wavefronts in flight, at cache + HBM bandwidth.
+bool blocked_factor_applies(int n)
+{
+    const char *e = std::getenv("SOCP_SOLVER_BLOCKED_MIN_N");        // read at every call: tests switch it within one process
+    const long min_n = e ? std::atol(e) : 0L;
+    return min_n > 0 && n >= min_n && (size_t)blocked_lds_doubles(n) * sizeof(double) <= 160 * 1024;
+}
+
+hipError_t launch_factor(hipStream_t st, const PoolDev &pool, const int *d_list, int count)
+{
+    if (count <= 0) return hipSuccess;
+    const size_t lds_bytes = (size_t)blocked_lds_doubles(pool.cfg.n) * sizeof(double);
+    if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
+    if (lds_bytes > 65536) {
+        static const hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void *>(factor_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (raised != hipSuccess) return raised;
+    }
+    hipLaunchKernelGGL(factor_kernel, dim3(count), dim3(64), lds_bytes, st, pool.cfg, pool.states, pool.ws, pool.ws_stride, d_list, count);
     return hipGetLastError();
 }
 

@@ -49,17 +49,18 @@ struct State {
     int phase, iter, ncsuc, ncfail, nslow1, nslow2, nfev, njev, info, jeval, sing;
     int req;           // Request left pending by the last advance
     int eval_sel;      // RQ_FVEC: 0 -> evaluate at x, result to fvec; 1 -> evaluate at wa2 (trial point), result to wa4
-    int pad;
+    int pad;           // 1: the Jacobian in A has already been factorised by the factor kernel (sing holds its flag)
     double delta, xnorm, fnorm, pnorm;
 };
 
 constexpr int kVectors = 16;
-SOCP_HD long ws_doubles(int n, int ld) { return (((long)n * ld + (long)n * (n + 1) / 2 + (long)kVectors * n) + 7) / 8 * 8; }
+SOCP_HD long ws_doubles(int n, int ld) { return (((long)n * ld + (long)n * (n + 1) + (long)kVectors * n) + 7) / 8 * 8; }
 SOCP_HD int ld_for(int n) { return (n + 1 + 7) / 8 * 8; }
 
 // views into one problem's workspace
 struct Work {
     double *A, *r, *x, *fvec, *diag, *qtf, *wa1, *wa2, *wa3, *wa4;
+    double *V;       // the Householder vectors of the last factorisation, packed: v_k at V + row_off(n, k), n - k entries (factor_blocked)
     // eight "fast" vectors of n doubles for what every thread reads again and again (a column or row in hand, rotation
     // tables, copies whose norm is taken): LDS on the device, the tail of the workspace otherwise
     double *f[8];
@@ -69,9 +70,11 @@ struct Work {
         double *v = r + (long)n * (n + 1) / 2;
         x = v; fvec = v + n; diag = v + 2 * n; qtf = v + 3 * n; wa1 = v + 4 * n; wa2 = v + 5 * n; wa3 = v + 6 * n; wa4 = v + 7 * n;
 #if defined(__HIP_DEVICE_COMPILE__)
+        V = v + 16 * n;
         double *fb = fast;                                   // always LDS on the device: a select between an LDS and a global pointer
                                                              // would make every access to the fast vectors a FLAT one
 #else
+        V = v + 16 * n;
         double *fb = fast ? fast : v + 8 * n;
 #endif
         for (int k = 0; k < 8; k++) f[k] = fb + (long)k * n;
@@ -179,6 +182,48 @@ SOCP_HD void axpy_run(double *a, long stride, const double *v, int lo, int hi, d
         for (int u = 0; u < kBatch; u++) a[(long)(i + u) * stride] = av[u] - temp * vv[u];
     }
     for (; i < hi; i++) a[(long)i * stride] -= temp * v[i];
+}
+
+// the same with the vector v strided too (a column of a panel held row-major in LDS)
+SOCP_HD double dot_run2(const double *v, long vs, const double *a, long as, int lo, int hi, double sum)
+{
+    int i = lo;
+    for (; i + kBatch <= hi; i += kBatch) {
+        double av[kBatch], vv[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; u++) { av[u] = a[(long)(i + u) * as]; vv[u] = v[(long)(i + u) * vs]; }
+#pragma unroll
+        for (int u = 0; u < kBatch; u++) sum += vv[u] * av[u];
+    }
+    for (; i < hi; i++) sum += v[(long)i * vs] * a[(long)i * as];
+    return sum;
+}
+SOCP_HD void axpy_run2(double *a, long as, const double *v, long vs, int lo, int hi, double temp)
+{
+    int i = lo;
+    for (; i + kBatch <= hi; i += kBatch) {
+        double av[kBatch], vv[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; u++) { av[u] = a[(long)(i + u) * as]; vv[u] = v[(long)(i + u) * vs]; }
+#pragma unroll
+        for (int u = 0; u < kBatch; u++) a[(long)(i + u) * as] = av[u] - temp * vv[u];
+    }
+    for (; i < hi; i++) a[(long)i * as] -= temp * v[(long)i * vs];
+}
+
+// dst[i * ds] = src[i * ss] for i = lo .. hi - 1, sixteen loads in flight (a lone wavefront has nothing else to hide them behind)
+SOCP_HD void copy_run(double *dst, long ds, const double *src, long ss, int lo, int hi)
+{
+    constexpr int kCopy = 16;
+    int i = lo;
+    for (; i + kCopy <= hi; i += kCopy) {
+        double t[kCopy];
+#pragma unroll
+        for (int u = 0; u < kCopy; u++) t[u] = src[(long)(i + u) * ss];
+#pragma unroll
+        for (int u = 0; u < kCopy; u++) dst[(long)(i + u) * ds] = t[u];
+    }
+    for (; i < hi; i++) dst[(long)i * ds] = src[(long)i * ss];
 }
 
 // One sweep of r1mpyq over a row a[0 .. n - 1] (contiguous): for j = n - 2 .. 0 (first = true: rotations of the first sweep of
@@ -293,6 +338,125 @@ SOCP_HD bool factor(const E &ex, int n, int ld, Work &w)
                 const double temp = sum / piv;
                 axpy_run(A + j, ld, v, k, n, temp);
             }
+        }
+        ex.sync();
+    }
+    return sing;
+}
+
+// The same factor work with the matrix taken through LDS in blocks (for problems whose matrix does not stay on chip: the
+// in-place form streams it ~2n/3 times -- 0.26 GB per refresh at n = 253 against 1.3 MB of algorithmic bytes).  Right-looking in
+// panels of kPanel reflectors: the panel's columns are factorised in a small LDS buffer Pn[n][kPanel]; every later column --
+// 64 at a time, each thread its own, in an LDS block Bk[n][kBlock] -- then goes through the panel's reflectors in order and is
+// written back once.  A column still meets the reflectors in the order 0, 1, 2, ..., each as one dot product and one axpy over
+// its rows in the order of the rows: the numbers are those of factor() (and of MINPACK).  The packed Householder vectors are kept
+// (w.V) and qform is done the same way from them: a block of Q's columns starts as the identity in LDS and goes through the
+// reflectors k = j, j - 1, ..., 0.  One block read and one write per PANEL instead of three passes over the trailing matrix per
+// REFLECTOR.  Meant for a workgroup of ONE wavefront (a thread per column of a block); correct for any executor.
+constexpr int kPanel = 8;
+constexpr int kBlock = 64;
+SOCP_HD long blocked_lds_doubles(int n) { return (long)n * (kPanel + kBlock); }
+
+template <class E>
+SOCP_HD bool factor_blocked(const E &ex, int n, int ld, Work &w, double *Pn, double *Bk)
+{
+    double *A = w.A, *rdiag = w.wa1, *acnorm = w.wa2, *V = w.V;
+    SOCP_PAR_FOR(j, 0, n) acnorm[j] = enorm(n, A + j, ld);
+    SOCP_PAR_FOR(i, 0, n) A[(long)i * ld + n] = w.fvec[i];
+    ex.sync();
+    unsigned skip = 0;                                       // bit t: reflector j0 + t of the panel in hand is the identity
+    for (int j0 = 0; j0 < n; j0 += kPanel) {
+        const int np = (n - j0 < kPanel) ? n - j0 : kPanel, rows = n - j0;
+        // ---- the panel: columns j0 .. j0 + np - 1, rows j0 .. n - 1, factorised among themselves in LDS
+        SOCP_PAR_FOR(e, 0, rows * np) { const int i = j0 + e / np, t = e - (e / np) * np; Pn[(long)i * kPanel + t] = A[(long)i * ld + j0 + t]; }
+        ex.sync();
+        for (int t = 0; t < np; t++) {
+            const int j = j0 + t;
+            double ajnorm = enorm(n - j, Pn + (long)j * kPanel + t, kPanel);
+            if (ajnorm != 0 && Pn[(long)j * kPanel + t] < 0) ajnorm = -ajnorm;
+            skip = (ajnorm == 0) ? (skip | (1u << t)) : (skip & ~(1u << t));
+            ex.sync();                                       // everyone has the norm before the column is scaled
+            if (ajnorm != 0) {
+                SOCP_PAR_FOR(i, j, n) {
+                    double val = Pn[(long)i * kPanel + t] / ajnorm;
+                    if (i == j) val += 1;
+                    Pn[(long)i * kPanel + t] = val;
+                }
+            }
+            if (ex.tid == 0) rdiag[j] = -ajnorm;
+            ex.sync();
+            if (ajnorm != 0) {
+                const double piv = Pn[(long)j * kPanel + t];
+                SOCP_PAR_FOR(t2, t + 1, np) {
+                    const double sum = dot_run2(Pn + t, kPanel, Pn + t2, kPanel, j, n, 0.0);
+                    axpy_run2(Pn + t2, kPanel, Pn + t, kPanel, j, n, sum / piv);
+                }
+            }
+            ex.sync();
+        }
+        // the finished panel goes home (its upper part is R's, its lower part the vectors) and the vectors are packed
+        SOCP_PAR_FOR(e, 0, rows * np) {
+            const int i = j0 + e / np, t = e - (e / np) * np;
+            const double val = Pn[(long)i * kPanel + t];
+            A[(long)i * ld + j0 + t] = val;
+            if (i >= j0 + t) V[row_off(n, j0 + t) + (i - j0 - t)] = val;
+        }
+        // ---- every later column (and fvec's, column n): through the panel's reflectors, 64 columns at a time, a thread per column
+        for (int c0 = j0 + np; c0 <= n; c0 += kBlock) {
+            const int bw = (n + 1 - c0 < kBlock) ? n + 1 - c0 : kBlock;
+            SOCP_PAR_FOR(c, 0, bw) {
+                double *col = Bk + c;                        // this thread's column: rows j0 .. n - 1 at col[(i - j0) * kBlock]
+                copy_run(col - (long)j0 * kBlock, kBlock, A + c0 + c, ld, j0, n);
+                for (int t = 0; t < np; t++) {
+                    if (skip & (1u << t)) continue;
+                    const int j = j0 + t;
+                    const double sum = dot_run2(Pn + t, kPanel, col - (long)j0 * kBlock, kBlock, j, n, 0.0);
+                    axpy_run2(col - (long)j0 * kBlock, kBlock, Pn + t, kPanel, j, n, sum / Pn[(long)j * kPanel + t]);
+                }
+                copy_run(A + c0 + c, ld, col - (long)j0 * kBlock, kBlock, j0, n);
+            }
+        }
+        ex.sync();                                           // the next panel reads columns other threads have just written
+    }
+    SOCP_PAR_FOR(i, 0, n) w.qtf[i] = A[(long)i * ld + n];
+    for (int i = 0; i < n; i++) {
+        const long off = row_off(n, i);
+        SOCP_PAR_FOR(k, i, n) w.r[off + (k - i)] = (k == i) ? rdiag[i] : A[(long)i * ld + k];
+    }
+    bool sing = false;
+    for (int j = 0; j < n; j++) if (rdiag[j] == 0) sing = true;
+    ex.sync();
+    // ---- qform from the packed vectors: column j of Q is e_j pushed through the reflectors j, j - 1, ..., 0
+    for (int c0 = 0; c0 < n; c0 += kBlock) {
+        const int bw = (n - c0 < kBlock) ? n - c0 : kBlock, jtop = c0 + bw - 1;
+        SOCP_PAR_FOR(c, 0, bw) {
+            double *col = Bk + c;
+            for (int i = 0; i < n; i++) col[(long)i * kBlock] = (i == c0 + c) ? 1.0 : 0.0;
+        }
+        for (int k1 = jtop; k1 >= 0; k1 -= kPanel) {
+            const int np = (k1 + 1 < kPanel) ? k1 + 1 : kPanel, klo = k1 - np + 1;
+            ex.sync();                                       // the previous panel of vectors is no longer read
+            for (int t = 0; t < np; t++) {
+                const int k = klo + t;
+                const double *vk = V + row_off(n, k);
+                SOCP_PAR_FOR(i, k, n) Pn[(long)i * kPanel + t] = vk[i - k];
+            }
+            ex.sync();
+            SOCP_PAR_FOR(c, 0, bw) {
+                double *col = Bk + c;
+                const int j = c0 + c;
+                for (int k = k1; k >= klo; k--) {
+                    if (k > j) continue;                     // column j starts at reflector j
+                    const int t = k - klo;
+                    const double piv = Pn[(long)k * kPanel + t];
+                    if (piv == 0) continue;
+                    const double sum = dot_run2(Pn + t, kPanel, col, kBlock, k, n, 0.0);
+                    axpy_run2(col, kBlock, Pn + t, kPanel, k, n, sum / piv);
+                }
+            }
+        }
+        SOCP_PAR_FOR(c, 0, bw) {
+            copy_run(A + c0 + c, ld, Bk + c, kBlock, 0, n);
         }
         ex.sync();
     }
@@ -497,6 +661,7 @@ struct Machine {
     State s;
     Work w;
     double *fast_matrix = nullptr;   // device: an LDS buffer of n * ld doubles for the factor work (null: work in place)
+    double *blocked_panel = nullptr, *blocked_block = nullptr;   // buffers of factor_blocked (the host simulation's way to run it)
     SOCP_HD Machine(const E &e, const Config &cfg, State &state, double *base, double *fast_vectors = nullptr)
         : ex(e), c(cfg), st(state), s(state), w(base, cfg.n, cfg.ld, fast_vectors) {}
 
@@ -527,7 +692,13 @@ struct Machine {
         const int n = c.n;
         if (c.analytic) s.njev += 1; else s.nfev += n;
         bool sing;
-        if (fast_matrix) {
+        if (s.pad) {
+            // the factor kernel (kernels_solver.hip: factor_blocked on this problem) has been here: A = Q, r, qtf, wa1, wa2 are in place
+            sing = s.sing != 0;
+            s.pad = 0;
+        } else if (blocked_panel) {
+            sing = factor_blocked(ex, n, c.ld, w, blocked_panel, blocked_block);
+        } else if (fast_matrix) {
             // the refresh streams its matrix ~2n/3 times: do that on a copy in LDS, bring Q back once
             double *const home = w.A;
             const long len = (long)n * c.ld;

@@ -23,6 +23,10 @@ hipError_t launch_start(hipStream_t st, const PoolDev &pool, const int *d_list, 
 // advance the state machines of list[0 .. count); d_flags[k] (may be null = 0): what the pending evaluation returned.
 // factor_phase: every problem of the list has just received a Jacobian (its advance is a factorisation)
 hipError_t launch_advance(hipStream_t st, const PoolDev &pool, const int *d_list, int count, const int *d_flags, bool factor_phase);
+// the Jacobian refresh of list[0 .. count) through the LDS-blocked factor kernel (one wavefront per problem); the following
+// launch_advance(..., factor_phase = true) then finds the factors in place.  blocked_factor_applies: whether to use it for size n
+bool blocked_factor_applies(int n);
+hipError_t launch_factor(hipStream_t st, const PoolDev &pool, const int *d_list, int count);
 // dst[k][n] = the point problem list[k] asked to be evaluated (x, or the trial point)
 hipError_t launch_gather_eval(hipStream_t st, const PoolDev &pool, const int *d_list, int count, double *d_dst);
 // the residual of that evaluation back into the problem (fvec, or the trial residual)

@@ -26,7 +26,7 @@ def sim(tmp_path_factory):
                            os.path.join(ROOT, "tests", "tools", "solver_sim.cpp")])
     L = C.CDLL(so)
     L.sim_solve.argtypes = [C.c_int, _dp, _dp, C.c_double, C.c_int, C.c_double, C.c_double, C.c_int, FCN, JAC,
-                            C.POINTER(C.c_int), C.POINTER(C.c_int), _dp, _dp, _dp, _dp]
+                            C.POINTER(C.c_int), C.POINTER(C.c_int), _dp, _dp, _dp, _dp, C.c_int]
     return L
 
 
@@ -43,7 +43,7 @@ def fd_jacobian(f, x, fvec, epsfcn):
     return J
 
 
-def sim_solve(L, f, jac, x0, xtol, factor, analytic, epsfcn=1e-15, maxfev=10000, abort_after=None):
+def sim_solve(L, f, jac, x0, xtol, factor, analytic, epsfcn=1e-15, maxfev=10000, abort_after=None, blocked=0):
     n = len(x0)
     x = np.array(x0, dtype=np.float64)
     out = dict(fvec=np.zeros(n), fjac=np.zeros((n, n)), r=np.zeros(n * (n + 1) // 2), qtf=np.zeros(n), diag=np.zeros(n))
@@ -64,7 +64,7 @@ def sim_solve(L, f, jac, x0, xtol, factor, analytic, epsfcn=1e-15, maxfev=10000,
     d = lambda a: a.ctypes.data_as(_dp)  # noqa: E731
     nfev, njev = C.c_int(0), C.c_int(0)
     info = L.sim_solve(n, d(x), d(out["fvec"]), xtol, maxfev, epsfcn, factor, int(analytic), FCN(_f), JAC(_j), C.byref(nfev), C.byref(njev),
-                       d(out["fjac"]), d(out["r"]), d(out["qtf"]), d(out["diag"]))
+                       d(out["fjac"]), d(out["r"]), d(out["qtf"]), d(out["diag"]), int(blocked))
     out.update(x=x, info=info, nfev=nfev.value, njev=njev.value)
     return out
 
@@ -92,10 +92,12 @@ def test_device_iteration_equals_host_hybrj(sim):
     assert dev["njev"] == host["njev"] >= 1
 
 
-@pytest.mark.parametrize("n", [1, 2, 7, 33, 130])
-def test_sizes_and_random_systems(sim, n):
-    """Mildly nonlinear random systems across the vector-length boundaries of the device layout (ld = n + 1 rounded up to 8):
-    many Jacobian refreshes, Broyden updates with zero and non-zero rotations, singular trial factors."""
+@pytest.mark.parametrize("blocked", [0, 1])
+@pytest.mark.parametrize("n", [1, 2, 7, 8, 9, 33, 63, 64, 65, 130])
+def test_sizes_and_random_systems(sim, n, blocked):
+    """Mildly nonlinear random systems across the vector-length boundaries of the device layout (ld = n + 1 rounded up to 8; panels
+    of 8 reflectors and blocks of 64 columns in the blocked factorisation): many Jacobian refreshes, Broyden updates with zero
+    and non-zero rotations, singular trial factors.  blocked = 1: the refreshes go through factor_blocked."""
     rng = np.random.default_rng(n)
     A = rng.normal(size=(n, n)) + 3 * np.eye(n)
     b = rng.normal(size=n)
@@ -105,7 +107,7 @@ def test_sizes_and_random_systems(sim, n):
     x0 = rng.normal(size=n)
     for xtol in (1e-8, 1e-13):
         host = capi.hybrd(f, x0.copy(), xtol=xtol, epsfcn=1e-15, fdjac=lambda x, fv, e: fd_jacobian(f, x, fv, e))
-        dev = sim_solve(sim, f, None, x0, xtol, 1.0, analytic=False)
+        dev = sim_solve(sim, f, None, x0, xtol, 1.0, analytic=False, blocked=blocked)
         same(dev, host)
 
 
@@ -126,6 +128,7 @@ def test_failure_paths_are_the_host_ones(sim):
     dev = sim_solve(sim, flat, None, x0, 1e-8, 1.0, analytic=False)
     same(dev, host)
     assert dev["info"] in (4, 5)
+    same(sim_solve(sim, flat, None, x0, 1e-8, 1.0, analytic=False, blocked=1), host)          # identity reflectors in the blocked form
 
     def nanny(x):
         f = broyden_tri(x)

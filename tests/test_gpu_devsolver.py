@@ -214,3 +214,47 @@ def test_large_problems_on_the_device_solver(M, order):
     host, dev = both(ctx, Z0, kind=capi.CHAIN_PLAIN, xtol=1e-8, analytic_jac=bool(order), max_rounds=12)
     assert np.all(np.isfinite(dev["z"]))
     ctx.close()
+
+
+@pytest.mark.parametrize("case", ["n14", "n85", "n127", "n253"])
+def test_blocked_factor_kernel_changes_no_bit(case):
+    """The LDS-blocked factor kernel (one wavefront per problem; panels of 8 reflectors, 64-column blocks: solver_dev.hpp
+    factor_blocked) against the in-place factorisation inside the advance kernel and against the host solvers: identical chains.
+    The switch is by size (n >= 128); here it is forced on (SOCP_SOLVER_BLOCKED_MIN_N=1) and off (=0) for sizes on both sides."""
+    from socp_amd import capi, sweep
+    if case == "n253":
+        ctx = capi.Context(capi.MODEL_INTERCEPTOR)
+        ctx.set_variant(capi.VARIANT_LANE_FAST)
+        n, z = sweep.interceptor_config5_problem(ctx)
+        ctx.set_integrator(capi.INT_DOPRI5, 1e-11)
+        rng = np.random.default_rng(9)
+        Z0 = np.tile(z, (5, 1))
+        Z0[:, 6:12] *= 1 + 1e-3 * rng.uniform(-1, 1, (5, 6))
+        kw = dict(kind=capi.CHAIN_PLAIN, xtol=1e-9)
+    else:
+        ctx = capi.Context(capi.MODEL_GODDARD)
+        ctx.set_params(sweep.GODDARD_PARAMS)
+        ctx.set_step_number(10)
+        ctx.set_variant(capi.VARIANT_LANE_FAST)
+        if case == "n14":
+            sweep.goddard_single_shooting_problem(ctx)
+            Z0 = sweep.goddard_starts(40, 3e-3)
+        else:
+            M = 6 if case == "n85" else 9
+            sweep.goddard_multiple_shooting_problem(ctx, M)
+            Z0 = sweep.goddard_multiple_shooting_starts(ctx, sweep.goddard_starts(24, 0.05), M)
+        kw = dict(kind=capi.CHAIN_PLAIN, xtol=1e-10)
+    old = os.environ.get("SOCP_SOLVER_BLOCKED_MIN_N")
+    try:
+        os.environ["SOCP_SOLVER_BLOCKED_MIN_N"] = "1"
+        host, blocked = both(ctx, Z0, **kw)
+        os.environ["SOCP_SOLVER_BLOCKED_MIN_N"] = "0"
+        inplace = ctx.chains_solve(Z0, solver=capi.SOLVER_DEVICE, **kw)
+    finally:
+        if old is None:
+            os.environ.pop("SOCP_SOLVER_BLOCKED_MIN_N", None)
+        else:
+            os.environ["SOCP_SOLVER_BLOCKED_MIN_N"] = old
+    for k in KEYS:
+        assert np.array_equal(blocked[k], inplace[k], equal_nan=True), k
+    ctx.close()

@@ -14,13 +14,14 @@ extern "C" {
 typedef int (*sim_fcn)(int n, const double *x, double *fvec);
 typedef int (*sim_jac)(int n, const double *x, const double *fvec, double *fjac_colmajor);
 
-// returns info; outputs as hybrd leaves them (fjac = Q column-major, r packed by rows)
+// returns info; outputs as hybrd leaves them (fjac = Q column-major, r packed by rows).  blocked != 0: the Jacobian refreshes go
+// through factor_blocked (panels + column blocks) instead of factor
 int sim_solve(int n, double *x, double *fvec, double xtol, int maxfev, double epsfcn, double factor, int analytic, sim_fcn fcn, sim_jac jac,
-              int *nfev, int *njev, double *fjac, double *r, double *qtf, double *diag)
+              int *nfev, int *njev, double *fjac, double *r, double *qtf, double *diag, int blocked)
 {
     Config c;
     c.n = n; c.ld = ld_for(n); c.maxfev = maxfev; c.mode = 1; c.analytic = analytic; c.xtol = xtol; c.epsfcn = epsfcn; c.factor = factor;
-    std::vector<double> ws((size_t)ws_doubles(n, c.ld), 0.0), J((size_t)n * n);
+    std::vector<double> ws((size_t)ws_doubles(n, c.ld), 0.0), J((size_t)n * n), lds((size_t)blocked_lds_doubles(n), 0.0);
     State st;
     std::memset(&st, 0, sizeof(st));
     SerialExec ex;
@@ -28,7 +29,11 @@ int sim_solve(int n, double *x, double *fvec, double xtol, int maxfev, double ep
     Work w(ws.data(), n, c.ld);
     int flag = 0;
     for (;;) {
-        { Machine<SerialExec> m(ex, c, st, ws.data()); m.advance(flag); }
+        {
+            Machine<SerialExec> m(ex, c, st, ws.data());
+            if (blocked) { m.blocked_panel = lds.data(); m.blocked_block = lds.data() + (size_t)n * kPanel; }
+            m.advance(flag);
+        }
         if (st.req == RQ_DONE) break;
         if (st.req == RQ_FVEC) {
             flag = fcn(n, st.eval_sel ? w.wa2 : w.x, st.eval_sel ? w.wa4 : w.fvec);
