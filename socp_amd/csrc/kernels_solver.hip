@@ -22,8 +22,13 @@ __global__ void start_kernel(Config c, State *states, double *ws, long ws_stride
 // blockIdx.x + gridDim.x, ... one after the other (the grid may be capped, launch_advance).
 // MAXT: the workgroup size the instantiation is built for -- without it the compiler budgets registers for 1024 threads
 // (128 VGPRs) and spills the rest of this large function to scratch.
+#ifdef SOCP_SOLVER_WAVES          // A/B: cap the registers so that this many wavefronts fit a SIMD (the compiler then spills)
+#define SOCP_SOLVER_OCCUPANCY __attribute__((amdgpu_waves_per_eu(SOCP_SOLVER_WAVES, SOCP_SOLVER_WAVES)))
+#else
+#define SOCP_SOLVER_OCCUPANCY
+#endif
 template <int MAXT>
-__global__ __launch_bounds__(MAXT) void advance_kernel(Config c, State *states, double *ws, long ws_stride, const int *__restrict__ list,
+__global__ __launch_bounds__(MAXT) SOCP_SOLVER_OCCUPANCY void advance_kernel(Config c, State *states, double *ws, long ws_stride, const int *__restrict__ list,
                                                        const int *__restrict__ flags, int count, int lds_matrix_doubles)
 {
     extern __shared__ double lds[];
