@@ -92,9 +92,15 @@ def parse_args(argv=None):
                          "(strong scaling: what north_star's \"near-linear to 8 GPUs on the multi-start sweep\" is about); default 65536 "
                          "(0 = skip; --lean skips it unless a count is given)")
     ap.add_argument("--sweep-max-rounds", type=int, default=40, help="socp_chain_options.max_rounds of the sweep leg")
+    ap.add_argument("--sweep-large-starts", type=int, default=None,
+                    help="the `sweep_large` leg: the same sweep with this many starts in total (default 8 x --sweep-starts): enough "
+                         "that one GPU is throughput-bound, so the strong-scaling curve is not flattened by the per-round trajectory "
+                         "latency the 65 536-start leg runs into; 0 skips it")
     args = ap.parse_args(argv)
     if args.sweep_starts is None:
         args.sweep_starts = 0 if args.lean else 65536
+    if args.sweep_large_starts is None:
+        args.sweep_large_starts = 0 if args.lean else 8 * args.sweep_starts
     return args
 
 
@@ -441,7 +447,7 @@ def north_star_128(capi, device, rk4_steps, cpu_traj_per_s):
     return out
 
 
-def sweep_leg(torch, dist, capi, args, world, rank, local_rank, dev, use_dist):
+def sweep_leg(torch, dist, capi, args, world, rank, local_rank, dev, use_dist, total=None):
     """BASELINE config 4 at N GPUs as STRONG scaling: a fixed total of --sweep-starts independent starts of the n = 14 single-shooting
     problem (1e4 RK4 steps, full Newton solves in lock-step, throughput flavour, round budget --sweep-max-rounds), sharded in
     contiguous blocks (socp_amd/sweep.py), no data-path exchange, one all_gather of the result records.  Wall time = barrier to
@@ -452,8 +458,13 @@ def sweep_leg(torch, dist, capi, args, world, rank, local_rank, dev, use_dist):
     ctx.set_step_number(args.rk4_steps)
     ctx.set_variant(capi.VARIANT_LANE_FAST)
     sweep.goddard_single_shooting_problem(ctx)
-    total = args.sweep_starts
-    Z0 = sweep.goddard_starts(total, 1e-3)
+    total = args.sweep_starts if total is None else total
+    base = min(total, max(args.sweep_starts, 1))
+    Z0 = sweep.goddard_starts(base, 1e-3)
+    if total > base:
+        # the large leg: the SURVEY 8d table repeated, block b with its costates moved by 1e-7 b (distinct starts, same basin)
+        reps = -(-total // base)
+        Z0 = np.concatenate([Z0 * np.concatenate([np.ones(7), np.full(7, 1.0 + 1e-7 * b)])[None, :] for b in range(reps)])[:total]
     stats = {}
 
     def solve_block(Zb):
@@ -556,9 +567,11 @@ def main():
     else:
         recs = [rec.tolist()]
 
-    sweep_rec = None
+    sweep_rec = sweep_large_rec = None
     if args.sweep_starts > 0:
         sweep_rec = sweep_leg(torch, dist, capi, args, world, rank, local_rank, dev, use_dist)
+    if args.sweep_large_starts > 0:
+        sweep_large_rec = sweep_leg(torch, dist, capi, args, world, rank, local_rank, dev, use_dist, total=args.sweep_large_starts)
 
     status = 0
     if rank == 0:
@@ -599,6 +612,8 @@ def main():
         }
         if sweep_rec is not None:
             out["sweep"] = sweep_rec
+        if sweep_large_rec is not None:
+            out["sweep_large"] = sweep_large_rec
         if ranks_seen != list(range(world)):
             sys.stderr.write("bench.py: records of ranks %s, expected 0..%d\n" % (ranks_seen, world - 1))
             status = 1

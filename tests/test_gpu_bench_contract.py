@@ -55,6 +55,8 @@ def test_bench_line_contract():
     sw = d["sweep"]
     assert sw["scaling"] == "strong" and sw["total_starts"] == 2048 and sw["n_gpus"] == 1 and sw["converged"] >= 2030
     assert abs(sw["solves_per_s"] - 2048 / sw["wall_s"]) <= 1e-6 * sw["solves_per_s"] and sw["trajectories"] > 2048 * 15
+    big = d["sweep_large"]
+    assert big["total_starts"] == 8 * 2048 and big["scaling"] == "strong" and big["converged"] >= 8 * 2030
     # CPU baseline as SURVEY 8d asks: one thread and all cores, pinned; the host is named
     assert c["p1"]["cores"] == 1 and c["p1"]["value"] > 0 and c["cores"] >= c["p1"]["cores"] and c["pinned"] in (True, False)
     assert isinstance(c["cpu_model"], str) and c["cpu_model"]
