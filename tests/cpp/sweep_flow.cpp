@@ -3,6 +3,7 @@
 //   sweep_flow samedev <ndev> <starts.bin> <P> <rk4_steps>     the same with every "device" = GPU 0 (a one-GPU box): exercises the threads, the
 //                                                               cloned contexts and the slicing of the per-chain arrays; here the chains are
 //                                                               KD continuations (SOCP_CHAIN_PARAM) with their own parameters and goals
+//   sweep_flow ranksdev <world> ...                            the same with the collective on DEVICE buffers (gather_on_device = 1)
 //   sweep_flow ranks   <world> <starts.bin> <P> <rk4_steps>    socp_sweep_solve_rank: `world` ranks emulated by threads that share
 //                                                               device 0, gathering through a user collective (here: shared memory
 //                                                               + a barrier; a real job passes ncclAllGather / MPI_Allgather)
@@ -19,6 +20,16 @@
 
 #include "socp_hip.h"
 #include "socp_solver.h"
+
+#include <dlfcn.h>
+// device-buffer form of the collective (what an RCCL job passes).  The program links no HIP itself: hipMemcpy is taken from the
+// runtime libsocp_hip.so has already loaded.  kind: 1 = host to device, 2 = device to host
+typedef int (*hip_memcpy_fn)(void *dst, const void *src, size_t bytes, int kind);
+static int hipMemcpy(void *dst, const void *src, size_t bytes, int kind)
+{
+    static hip_memcpy_fn fn = reinterpret_cast<hip_memcpy_fn>(dlsym(RTLD_DEFAULT, "hipMemcpy"));
+    return fn ? fn(dst, src, bytes, kind) : 1;
+}
 
 static socp_ctx *goddard_ctx(int device, int steps)
 {
@@ -61,6 +72,16 @@ static int thread_allgather(void *user, const double *send, long count, double *
     else g.cv.wait(lk, [&]() { return g.generation != gen; });
     std::memcpy(recv, g.buf.data(), sizeof(double) * count * g.world);
     return 0;
+}
+
+// the same collective on DEVICE buffers (gather_on_device = 1), staged through the host the way a test without RCCL can
+static int thread_allgather_dev(void *user, const double *send, long count, double *recv)
+{
+    RankGather *rg = static_cast<RankGather *>(user);
+    std::vector<double> hs(count), hr((size_t)count * rg->g->world);
+    if (hipMemcpy(hs.data(), send, sizeof(double) * count, 2) != 0) return 1;
+    if (thread_allgather(user, hs.data(), count, hr.data()) != 0) return 1;
+    return hipMemcpy(recv, hr.data(), sizeof(double) * hr.size(), 1) != 0;
 }
 
 int main(int argc, char **argv)
@@ -114,7 +135,9 @@ int main(int argc, char **argv)
                 socp_ctx *c = goddard_ctx(0, steps);
                 RankGather rg{&g, r};
                 socp_chain_stats st;
-                rcs[r] = socp_sweep_solve_rank(c, r, count, P, &opt, Z0.data(), thread_allgather, &rg, 0, Zr[r].data(), Ir[r].data(), Nr[r].data(),
+                const bool on_device = mode == "ranksdev";
+                rcs[r] = socp_sweep_solve_rank(c, r, count, P, &opt, Z0.data(), on_device ? thread_allgather_dev : thread_allgather, &rg, on_device ? 1 : 0,
+                                               Zr[r].data(), Ir[r].data(), Nr[r].data(),
                                                nullptr, nullptr, Fr[r].data(), &st);
                 socp_ctx_destroy(c);
             });

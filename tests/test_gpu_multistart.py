@@ -70,7 +70,7 @@ def test_multiple_shooting_sweep_lands_on_the_cpu_solution(variant):
     ctx.close()
 
 
-@pytest.mark.parametrize("mode,count", [("devices", 1), ("ranks", 2), ("ranks", 3)])
+@pytest.mark.parametrize("mode,count", [("devices", 1), ("ranks", 2), ("ranks", 3), ("ranksdev", 2)])
 def test_cpp_sweep_entry_points(tmp_path, mode, count):
     """The C++ multi-GPU entry points (include/socp_solver.h) driven by a C++ program with no Python in it
     (tests/cpp/sweep_flow.cpp): socp_sweep_solve with one device, and socp_sweep_solve_rank with 2 / 3 ranks emulated by threads
