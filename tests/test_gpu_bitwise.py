@@ -124,6 +124,75 @@ def test_unmodified_reference_program_reports_success(tmp_path):
     assert oks == ["1", "1", "1", "1"], out.stdout
 
 
+def _run_dropin(tmp_path, prog):
+    exe = os.path.join(ROOT, "oracle", "_ref", "dropin", "bin", prog)
+    if not os.path.exists(exe):
+        pytest.skip("drop-in binary not built (needs the reference tree: scripts/dropin_build.sh)")
+    work = tmp_path / "a" / "b"
+    work.mkdir(parents=True)
+    for m in ("goddard", "doubleIntegrator", "covid19", "interceptor"):
+        (tmp_path / "trace" / m).mkdir(parents=True)
+    out = subprocess.run([exe], cwd=work, input="\n", capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-2000:])
+    return out.stdout
+
+
+def _printed_solutions(stdout):
+    """The `SOL :` lines of the double-integrator programs: (nCallFunc, nCallJac) when printed, tf and the six costates."""
+    import re
+    sols = []
+    for line in stdout.splitlines():
+        if "SOL :" not in line:
+            continue
+        calls = re.search(r"nCallFunc = (\d+), nCallJac = (\d+)", line)
+        vals = [float(v) for v in re.findall(r"(?:tf|p_\w+) = ([-+0-9.eE]+)", line)]
+        sols.append((None if calls is None else (int(calls.group(1)), int(calls.group(2))), np.array(vals)))
+    return sols
+
+
+def test_unmodified_double_integrator_programs_print_the_cpu_solutions(tmp_path, built):
+    """The reference's tests/testDoubleIntegrator.cpp and testDoubleIntegrator_WP.cpp, compiled unchanged against the mirror
+    (hybrj over the device's variational Jacobian): every solve returns 1, the printed call counts are MINPACK's on the CPU path
+    ((30, 4) and (58, 5): SURVEY 6's (32,4) / (60,5) are SciPy's count, two more) and the printed tf / costates are the CPU
+    path's (the same flows over the oracle, tests/flow_oracle.py) in every digit the programs print."""
+    from flow_oracle import dint_basic_flow, dint_wp_flow
+    out = _run_dropin(tmp_path, "testDoubleIntegrator")
+    assert out.count("Algo returned 1") == 3, out
+    sols = _printed_solutions(out)
+    cpu = dint_basic_flow("socp", 1)
+    assert len(sols) == 3 and sols[0][0] == (cpu[0]["nfev"], cpu[0]["njev"]) == (30, 4)
+    for (calls, vals), want in zip(sols, cpu):
+        z = want["z"]
+        ref = np.concatenate([[z[12]], z[6:12]])
+        assert np.array_equal(vals, [float("%.6g" % v) for v in ref]), (vals, ref)       # the digits std::cout prints, all of them
+    trace = np.loadtxt(tmp_path / "trace" / "doubleIntegrator" / "trace.dat")
+    assert trace.ndim == 2 and trace.shape[0] > 10 and np.all(np.isfinite(trace)) and np.all(np.diff(trace[:, 0]) >= 0)
+
+    out = _run_dropin(tmp_path / "wp", "testDoubleIntegrator_WP")
+    assert "Algo returned 1" in out and "OK = 1" in out, out
+    sols = _printed_solutions(out)
+    cpu = dint_wp_flow("socp", 1)
+    assert len(sols) == 1 and sols[0][0] == (cpu[1]["nfev"], cpu[1]["njev"]) == (58, 5)
+    z = cpu[1]["z"]
+    assert np.array_equal(sols[0][1], [float("%.6g" % v) for v in np.concatenate([[z[24]], z[6:12]])])
+
+
+@pytest.mark.parametrize("prog,solves,trace_files", [("testCovid19", 3, ["covid19/trace.dat"]),
+                                                     ("testInterceptor", 3, ["interceptor/trace_S1.dat", "interceptor/trace_S2.dat",
+                                                                             "interceptor/trace_S3.dat"])])
+def test_unmodified_covid_and_interceptor_programs_report_success(tmp_path, prog, solves, trace_files):
+    """tests/testCovid19.cpp (M = 20, 1000 steps, two data continuations) and tests/testInterceptor.cpp (three scenarios, parameter
+    continuation; fixed-step RK4 as the reference ships without _USE_BOOST), compiled unchanged: OK = 1 for every solve and the
+    trace files they write are complete (finite, time non-decreasing within the file's segments)."""
+    out = _run_dropin(tmp_path, prog)
+    oks = [l.split("OK =")[1].split(",")[0].strip() for l in out.splitlines() if "OK =" in l]
+    assert oks == ["1"] * solves, out
+    for f in trace_files:
+        t = np.loadtxt(tmp_path / "trace" / f)
+        assert t.ndim == 2 and t.shape[0] > 50 and np.all(np.isfinite(t)), f
+        assert t[0, 0] <= t[-1, 0]
+
+
 def test_degenerate_states_take_the_plain_division_path_and_still_match(built):
     """Shared-denominator division (models_exact.hpp: Den) is used only for denominators within 2^-400..2^400;
     zero speed, zero p_v and states scaled by 10^+-150 go through plain IEEE division -- and must equal the CPU
