@@ -192,7 +192,8 @@ int socp_sweep_solve(const struct socp_ctx *proto, const int *devices, int ndev,
                      double *param_final, double *fnorm, socp_sweep_stats *stats);
 
 /* ONE process PER GPU (the layout of an MPI / RCCL job): rank `rank` of `world` solves its block on `ctx` and the records
- * {Zout[n], fnorm, info, nfev_last, nfev_total, solves} (n + 5 doubles per start) of all ranks are gathered with the caller's
+ * {Zout[n], fnorm, info, nfev_last, nfev_total, solves} (n + 5 doubles per start, + one status double per rank: a rank whose
+ * solve failed still enters the collective and every rank returns that failure) of all ranks are gathered with the caller's
  * collective: gather(user, send, count, recv) must behave like an all-gather of `count` doubles per rank into
  * recv[world][count] -- ncclAllGather(send, recv, count, ncclDouble, comm, stream) + a stream synchronise, MPI_Allgather, or
  * a copy when world = 1 (INTEGRATION.md shows the RCCL form; this library does not link a communication library itself).

@@ -90,37 +90,47 @@ extern "C" int socp_sweep_solve_rank(socp_ctx *ctx, int rank, int world, int P, 
     socp_sweep_shard(P, rank, world, &lo, &hi);
     const int mine = hi - lo, kmax = (P + world - 1) / world;             // equal-size records: short blocks are padded by one row
     const int W = n + 5;
-    std::vector<double> z((size_t)mine * n), fn(mine, 0.0), send((size_t)kmax * W, 0.0), recv((size_t)world * kmax * W, 0.0);
+    // a rank's message: kmax records + its own status, so that a rank whose solve failed still takes part in the collective
+    // (the others would wait for it for ever) and EVERY rank returns the failure
+    const long count = (long)kmax * W + 1;
+    std::vector<double> z((size_t)mine * n), fn(mine, 0.0), send((size_t)count, 0.0), recv((size_t)world * count, 0.0);
     std::vector<int> inf(mine, 0), nl(mine, 0), nt(mine, 0), so(mine, 0);
     const int rc = socp_chains_solve(ctx, mine, opt, Z0 + (size_t)lo * n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, z.data(), inf.data(),
                                      nl.data(), nt.data(), so.data(), nullptr, nullptr, fn.data(), stats);
-    if (rc != SOCP_OK) return rc;
-    for (int k = 0; k < mine; k++) {
+    send[(size_t)count - 1] = rc;
+    for (int k = 0; k < mine && rc == SOCP_OK; k++) {
         double *rec = &send[(size_t)k * W];
         std::memcpy(rec, &z[(size_t)k * n], sizeof(double) * n);
         rec[n] = fn[k]; rec[n + 1] = inf[k]; rec[n + 2] = nl[k]; rec[n + 3] = nt[k]; rec[n + 4] = so[k];
     }
-    const long count = (long)kmax * W;
     int grc = 0;
     if (gather_on_device) {
-        if (hipSetDevice(socp_ctx_device(ctx)) != hipSuccess) return SOCP_ERR_HIP;
+        int prev = -1;
+        if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(socp_ctx_device(ctx)) != hipSuccess) return SOCP_ERR_HIP;
         double *dsend = nullptr, *drecv = nullptr;
-        if (hipMalloc(&dsend, sizeof(double) * (count ? count : 1)) != hipSuccess) return SOCP_ERR_HIP;
-        if (hipMalloc(&drecv, sizeof(double) * (count ? count : 1) * world) != hipSuccess) { (void)hipFree(dsend); return SOCP_ERR_HIP; }
-        bool ok = hipMemcpy(dsend, send.data(), sizeof(double) * count, hipMemcpyHostToDevice) == hipSuccess;
+        bool ok = hipMalloc(&dsend, sizeof(double) * count) == hipSuccess && hipMalloc(&drecv, sizeof(double) * count * world) == hipSuccess &&
+                  hipMemcpy(dsend, send.data(), sizeof(double) * count, hipMemcpyHostToDevice) == hipSuccess;
+        // (an allocation failure here leaves the other ranks waiting: nothing this rank could still send)
         if (ok) grc = gather(user, dsend, count, drecv);
         ok = ok && grc == 0 && hipMemcpy(recv.data(), drecv, sizeof(double) * count * world, hipMemcpyDeviceToHost) == hipSuccess;
-        (void)hipFree(dsend); (void)hipFree(drecv);
+        if (dsend) (void)hipFree(dsend);
+        if (drecv) (void)hipFree(drecv);
+        (void)hipSetDevice(prev);
         if (!ok) return grc != 0 ? SOCP_ERR_ARG : SOCP_ERR_HIP;
     } else {
         grc = gather(user, send.data(), count, recv.data());
         if (grc != 0) return SOCP_ERR_ARG;
     }
+    if (rc != SOCP_OK) return rc;
+    for (int r = 0; r < world; r++) {
+        const int theirs = (int)recv[(size_t)(r + 1) * count - 1];
+        if (theirs != SOCP_OK) return theirs;                                 // another rank failed: no table to report
+    }
     for (int r = 0; r < world; r++) {
         int a = 0, b = 0;
         socp_sweep_shard(P, r, world, &a, &b);
         for (int k = 0; k < b - a; k++) {
-            const double *rec = &recv[((size_t)r * kmax + k) * W];
+            const double *rec = &recv[(size_t)r * count + (size_t)k * W];
             std::memcpy(Zout + (size_t)(a + k) * n, rec, sizeof(double) * n);
             if (fnorm) fnorm[a + k] = rec[n];
             info[a + k] = (int)rec[n + 1];
