@@ -15,6 +15,7 @@
 #include <dlfcn.h>
 
 #include <map>
+#include <mutex>
 
 #include "../../include/socp_plugin.h"
 #include "launch.hpp"
@@ -77,10 +78,17 @@ struct socp_ctx {
 
 namespace {
 
+// Registered plugin models.  Contexts keep a pointer to their entry (map nodes do not move; an id registered twice keeps its
+// node); registration and look-up may come from different threads.
 std::map<int, ModelLaunchers> &plugins()
 {
     static std::map<int, ModelLaunchers> table;
     return table;
+}
+std::mutex &plugins_lock()
+{
+    static std::mutex m;
+    return m;
 }
 
 int fail(socp_ctx *c, int code, const std::string &msg)
@@ -167,6 +175,7 @@ int socp_ctx_create(socp_ctx **out, int model_id, int device)
     *out = nullptr;
     const ModelLaunchers *vt = nullptr;
     if (model_id >= SOCP_PLUGIN_ID_MIN) {
+        std::lock_guard<std::mutex> guard(plugins_lock());
         auto it = plugins().find(model_id);
         if (it != plugins().end()) vt = &it->second;
     }
@@ -804,6 +813,7 @@ int socp_register_model(int model_id, const void *table, int table_bytes)
     if (t->abi != kPluginAbi || t->dim < 1 || 2 * t->dim > 64 || t->nparams < 0 || t->nparams > kMaxParams || t->default_step_nbr < 1 ||
         !t->traj || !t->residual || !t->fdjac || !t->fdrows || !t->dense || !t->eval)
         return fail(nullptr, SOCP_ERR_ARG, "register_model: malformed launch table");
+    std::lock_guard<std::mutex> guard(plugins_lock());
     plugins()[model_id] = *t;
     return SOCP_OK;
 }

@@ -1,6 +1,7 @@
 // kernels_solver.hip -- the Powell hybrid iteration of many small problems on the device (solver_dev.hpp): one workgroup per
 // problem.  MUST be compiled with -ffp-contract=off: every iterate has to equal the host solver's (minpack.cpp) bit for bit.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 
 #include "solver_launch.hpp"
@@ -116,6 +117,21 @@ __global__ void scatter_jac_kernel(Config c, double *ws, long ws_stride, const i
     }
 }
 
+// More than 64 KB of dynamic LDS needs the kernel's limit raised -- on the CURRENT device's copy of the kernel, so the fact is
+// remembered per device (socp_sweep_solve drives several devices from one process).
+template <auto Kernel>
+hipError_t raise_lds_limit()
+{
+    static std::atomic<unsigned long long> raised{0};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 64 && ((raised.load(std::memory_order_acquire) >> dev) & 1ull)) return hipSuccess;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess && dev < 64) raised.fetch_or(1ull << dev, std::memory_order_release);
+    return e;
+}
+
 }  // namespace
 
 int threads_for(int n)
@@ -153,8 +169,7 @@ hipError_t launch_advance(hipStream_t st, const PoolDev &pool, const int *d_list
 #define SOCP_LAUNCH_ADVANCE(MAXT)                                                                                                          \
     do {                                                                                                                                   \
         if (lds_bytes > 65536) {                                                                                                           \
-            static const hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void *>(advance_kernel<MAXT>),                     \
-                                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                  \
+            const hipError_t raised = raise_lds_limit<advance_kernel<MAXT>>();                                                             \
             if (raised != hipSuccess) return raised;                                                                                       \
         }                                                                                                                                  \
         hipLaunchKernelGGL(advance_kernel<MAXT>, dim3(grid), dim3(threads), lds_bytes, st, pool.cfg, pool.states, pool.ws, pool.ws_stride, \
@@ -189,7 +204,7 @@ hipError_t launch_factor(hipStream_t st, const PoolDev &pool, const int *d_list,
     const size_t lds_bytes = (size_t)blocked_lds_doubles(pool.cfg.n) * sizeof(double);
     if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
     if (lds_bytes > 65536) {
-        static const hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void *>(factor_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        const hipError_t raised = raise_lds_limit<factor_kernel>();
         if (raised != hipSuccess) return raised;
     }
     hipLaunchKernelGGL(factor_kernel, dim3(count), dim3(64), lds_bytes, st, pool.cfg, pool.states, pool.ws, pool.ws_stride, d_list, count);
