@@ -154,6 +154,12 @@ SOCP_HD long row_off(int n, int i) { return (long)i * n - (long)i * (i - 1) / 2;
 #define SOCP_SOLVER_BATCH 8
 #endif
 constexpr int kBatch = SOCP_SOLVER_BATCH;
+// ... and for the sweeps that hold three operands per entry (rotate_row, axpy_dot_run): with 8 the solver kernel needs 170
+// registers, two more than three wavefronts per SIMD leave it
+#ifndef SOCP_SOLVER_BATCH3
+#define SOCP_SOLVER_BATCH3 6
+#endif
+constexpr int kBatch3 = SOCP_SOLVER_BATCH3;
 
 // sum + sum_{i = lo}^{hi - 1} v[i] * a[i * stride], added in the order of i
 SOCP_HD double dot_run(const double *v, const double *a, long stride, int lo, int hi, double sum)
@@ -232,18 +238,18 @@ SOCP_HD double rotate_row(double *a, const double *c, const double *s, int n, do
 {
     if (first) {
         int j = n - 2;
-        for (; j - kBatch + 1 >= 0; j -= kBatch) {
-            double av[kBatch], cv[kBatch], sv[kBatch];
+        for (; j - kBatch3 + 1 >= 0; j -= kBatch3) {
+            double av[kBatch3], cv[kBatch3], sv[kBatch3];
 #pragma unroll
-            for (int u = 0; u < kBatch; u++) { av[u] = a[j - u]; cv[u] = c[j - u]; sv[u] = s[j - u]; }
+            for (int u = 0; u < kBatch3; u++) { av[u] = a[j - u]; cv[u] = c[j - u]; sv[u] = s[j - u]; }
 #pragma unroll
-            for (int u = 0; u < kBatch; u++) {
+            for (int u = 0; u < kBatch3; u++) {
                 const double temp = cv[u] * av[u] - sv[u] * an;
                 an = sv[u] * av[u] + cv[u] * an;
                 av[u] = temp;
             }
 #pragma unroll
-            for (int u = 0; u < kBatch; u++) a[j - u] = av[u];
+            for (int u = 0; u < kBatch3; u++) a[j - u] = av[u];
         }
         for (; j >= 0; j--) {
             const double aj = a[j];
@@ -253,18 +259,18 @@ SOCP_HD double rotate_row(double *a, const double *c, const double *s, int n, do
         }
     } else {
         int j = 0;
-        for (; j + kBatch <= n - 1; j += kBatch) {
-            double av[kBatch], cv[kBatch], sv[kBatch];
+        for (; j + kBatch3 <= n - 1; j += kBatch3) {
+            double av[kBatch3], cv[kBatch3], sv[kBatch3];
 #pragma unroll
-            for (int u = 0; u < kBatch; u++) { av[u] = a[j + u]; cv[u] = c[j + u]; sv[u] = s[j + u]; }
+            for (int u = 0; u < kBatch3; u++) { av[u] = a[j + u]; cv[u] = c[j + u]; sv[u] = s[j + u]; }
 #pragma unroll
-            for (int u = 0; u < kBatch; u++) {
+            for (int u = 0; u < kBatch3; u++) {
                 const double temp = cv[u] * av[u] + sv[u] * an;
                 an = -sv[u] * av[u] + cv[u] * an;
                 av[u] = temp;
             }
 #pragma unroll
-            for (int u = 0; u < kBatch; u++) a[j + u] = av[u];
+            for (int u = 0; u < kBatch3; u++) a[j + u] = av[u];
         }
         for (; j < n - 1; j++) {
             const double aj = a[j];
@@ -276,42 +282,122 @@ SOCP_HD double rotate_row(double *a, const double *c, const double *s, int n, do
     return an;
 }
 
+// One reflector's axpy and the NEXT reflector's dot product in one sweep over a column (a[i * stride]):
+//   a[i] -= temp * v[i]            for i = lo  .. hi - 1     (reflector in hand)
+//   returns sum_{i = dlo}^{hi - 1} u[i] * a[i] (the new a where both ranges overlap), added in the order of i, from 0.0
+// |lo - dlo| <= 1 in both users: qrfac's next reflector starts one row further down (dlo = lo + 1), qform's one row further up
+// (dlo = lo - 1).  The entries are produced in the order the dot product consumes them, so every number is the one the two
+// separate sweeps (axpy_run, then dot_run) give -- and the column crosses the memory system once instead of twice.
+SOCP_HD double axpy_dot_run(double *a, long stride, const double *v, const double *u, int lo, int dlo, int hi, double temp)
+{
+    double sum = 0.0;
+    int i = (lo < dlo) ? lo : dlo;
+    const int both = (lo < dlo) ? dlo : lo;
+    for (; i < both && i < hi; i++) {
+        if (i >= lo) a[(long)i * stride] -= temp * v[i];     // (qrfac) a row of R: no part in the next dot product
+        else sum += u[i] * a[(long)i * stride];              // (qform) a row the reflector in hand does not reach
+    }
+    for (; i + kBatch3 <= hi; i += kBatch3) {
+        double av[kBatch3], vv[kBatch3], uv[kBatch3];
+#pragma unroll
+        for (int q = 0; q < kBatch3; q++) { av[q] = a[(long)(i + q) * stride]; vv[q] = v[i + q]; uv[q] = u[i + q]; }
+#pragma unroll
+        for (int q = 0; q < kBatch3; q++) av[q] = av[q] - temp * vv[q];
+#pragma unroll
+        for (int q = 0; q < kBatch3; q++) a[(long)(i + q) * stride] = av[q];
+#pragma unroll
+        for (int q = 0; q < kBatch3; q++) sum += uv[q] * av[q];
+    }
+    for (; i < hi; i++) {
+        const double t = a[(long)i * stride] - temp * v[i];
+        a[(long)i * stride] = t;
+        sum += u[i] * t;
+    }
+    return sum;
+}
+
 // One Jacobian refresh's factor work: qrfac (no pivoting) with Q^T fvec riding along as column n, R packed by rows, qform in
 // place.  In: A[i][j] = J(i, j), fvec.  Out: A = Q (row-major), r, qtf, rdiag (wa1), acnorm (wa2); returns "singular".
 // A column's norm is a serial chain over its entries: the column is first copied to a fast vector by all threads at once (one
 // strided load each) and the chain then runs on that copy -- on the matrix itself it would be n dependent trips to memory.
+//
+// Two sweeps over the trailing matrix per reflector instead of three (dot, then axpy = read + read/write): while a column
+// takes reflector j's axpy it already accumulates its dot product with reflector j + 1 (axpy_dot_run).  That needs v_{j+1}
+// BEFORE the sweep, so column j + 1 runs one step ahead: all threads together give it reflector j (one entry each), its norm
+// and scaling follow as before, and the sweep then covers the columns from j + 2 on.  A column still meets the reflectors in
+// the order 0, 1, 2, ..., each as the same dot product and the same axpy over its rows in the order of the rows.
 template <class E>
 SOCP_HD bool factor(const E &ex, int n, int ld, Work &w)
 {
-    double *A = w.A, *rdiag = w.wa1, *acnorm = w.wa2, *col = w.f[0], *v = w.f[1];
+    double *A = w.A, *rdiag = w.wa1, *acnorm = w.wa2, *col = w.f[0];
+    double *va = w.f[1], *vb = w.f[2];                       // the reflector in hand, the next one (they swap every step)
+    double *sums = w.f[3];                                   // sums[k], k = 0 .. n: column k's dot product with the reflector in hand
+                                                             // (n + 1 entries: runs one into w.f[4], unused here)
     SOCP_PAR_FOR(j, 0, n) acnorm[j] = enorm(n, A + j, ld);
     SOCP_PAR_FOR(i, 0, n) A[(long)i * ld + n] = w.fvec[i];
+    SOCP_PAR_FOR(i, 0, n) col[i] = A[(long)i * ld];
     ex.sync();
-    for (int j = 0; j < n; j++) {
-        SOCP_PAR_FOR(i, j, n) col[i] = A[(long)i * ld + j];
-        ex.sync();
-        // finish reflector j on its column (every thread computes the same norm from the same fast copy)
-        double ajnorm = enorm(n - j, col + j);
-        if (ajnorm != 0 && col[j] < 0) ajnorm = -ajnorm;
-        if (ajnorm != 0) {
-            SOCP_PAR_FOR(i, j, n) {
+    // reflector 0 from column 0 as it stands, and every later column's dot product with it
+    bool cur = false;
+    {
+        double ajnorm = enorm(n, col);
+        if (ajnorm != 0 && col[0] < 0) ajnorm = -ajnorm;
+        cur = ajnorm != 0;
+        if (cur) {
+            SOCP_PAR_FOR(i, 0, n) {
                 double t = col[i] / ajnorm;
-                if (i == j) t += 1;
-                A[(long)i * ld + j] = t;
-                v[i] = t;
+                if (i == 0) t += 1;
+                A[(long)i * ld] = t;
+                va[i] = t;
             }
         }
-        if (ex.tid == 0) rdiag[j] = -ajnorm;
+        if (ex.tid == 0) rdiag[0] = -ajnorm;
         ex.sync();
-        if (ajnorm != 0) {
-            const double piv = v[j];
-            SOCP_PAR_FOR(k, j + 1, n + 1) {                  // the later columns, and fvec's column
-                const double sum = dot_run(v, A + k, ld, j, n, 0.0);
-                const double temp = sum / piv;
-                axpy_run(A + k, ld, v, j, n, temp);
+        if (cur) SOCP_PAR_FOR(k, 1, n + 1) sums[k] = dot_run(va, A + k, ld, 0, n, 0.0);
+        ex.sync();
+    }
+    for (int j = 0; j < n; j++) {
+        // in hand: va = v_j (if cur), sums[k] = v_j . a_k for k > j
+        const double piv = cur ? va[j] : 1.0;
+        const int c1 = j + 1;                                // the column that runs ahead (c1 = n: fvec's column, never a reflector)
+        bool next = false;
+        if (cur) {
+            const double temp = sums[c1] / piv;
+            SOCP_PAR_FOR(i, j, n) {
+                const double t = A[(long)i * ld + c1] - temp * va[i];
+                A[(long)i * ld + c1] = t;
+                col[i] = t;
             }
+        } else if (c1 < n) {
+            SOCP_PAR_FOR(i, c1, n) col[i] = A[(long)i * ld + c1];
         }
         ex.sync();
+        if (c1 < n) {
+            double ajnorm = enorm(n - c1, col + c1);
+            if (ajnorm != 0 && col[c1] < 0) ajnorm = -ajnorm;
+            next = ajnorm != 0;
+            if (next) {
+                SOCP_PAR_FOR(i, c1, n) {
+                    double t = col[i] / ajnorm;
+                    if (i == c1) t += 1;
+                    A[(long)i * ld + c1] = t;
+                    vb[i] = t;
+                }
+            }
+            if (ex.tid == 0) rdiag[c1] = -ajnorm;
+            ex.sync();
+        }
+        // the columns from j + 2 on (and fvec's): reflector j's axpy, reflector j + 1's dot product
+        if (cur && next) {
+            SOCP_PAR_FOR(k, j + 2, n + 1) sums[k] = axpy_dot_run(A + k, ld, va, vb, j, c1, n, sums[k] / piv);
+        } else if (cur) {
+            SOCP_PAR_FOR(k, j + 2, n + 1) axpy_run(A + k, ld, va, j, n, sums[k] / piv);
+        } else if (next) {
+            SOCP_PAR_FOR(k, j + 2, n + 1) sums[k] = dot_run(vb, A + k, ld, c1, n, 0.0);
+        }
+        ex.sync();
+        double *const t = va; va = vb; vb = t;
+        cur = next;
     }
     SOCP_PAR_FOR(i, 0, n) w.qtf[i] = A[(long)i * ld + n];
     // R by rows: row i = [rdiag[i], A(i, i+1 .. n-1)]
@@ -324,22 +410,38 @@ SOCP_HD bool factor(const E &ex, int n, int ld, Work &w)
     ex.sync();
     for (int j = 0; j < n; j++) if (col[j] == 0) sing = true;
     // qform, MINPACK's in-place order: the strict upper triangle is cleared, then for k = n-1 .. 0 column k's Householder
-    // vector moves out, the column becomes e_k and the columns j >= k go through reflector k
+    // vector moves out, the column becomes e_k and the columns j >= k go through reflector k.  Fused the same way: while the
+    // columns j >= k take reflector k's axpy they accumulate their dot product with reflector k - 1, whose vector is simply
+    // column k - 1 as stored (no reflector of this sweep touches it before its turn).
     for (int i = 0; i < n; i++)
         SOCP_PAR_FOR(j, i + 1, n) A[(long)i * ld + j] = 0;
+    SOCP_PAR_FOR(i, n - 1, n) { va[i] = A[(long)i * ld + n - 1]; A[(long)i * ld + n - 1] = 1.0; }
+    ex.sync();
+    cur = va[n - 1] != 0;
+    if (cur) SOCP_PAR_FOR(jc, n - 1, n) sums[jc] = dot_run(va, A + jc, ld, n - 1, n, 0.0);
     ex.sync();
     for (int k = n - 1; k >= 0; k--) {
-        SOCP_PAR_FOR(i, k, n) { v[i] = A[(long)i * ld + k]; A[(long)i * ld + k] = (i == k) ? 1.0 : 0.0; }
-        ex.sync();
-        const double piv = v[k];
-        if (piv != 0) {
-            SOCP_PAR_FOR(j, k, n) {
-                const double sum = dot_run(v, A + j, ld, k, n, 0.0);
-                const double temp = sum / piv;
-                axpy_run(A + j, ld, v, k, n, temp);
+        // in hand: va = v_k (rows k .. n-1), sums[jc] = v_k . q_jc for jc >= k (if cur)
+        const double piv = cur ? va[k] : 1.0;
+        bool next = false;
+        if (k > 0) {
+            SOCP_PAR_FOR(i, k - 1, n) { vb[i] = A[(long)i * ld + k - 1]; A[(long)i * ld + k - 1] = (i == k - 1) ? 1.0 : 0.0; }
+            ex.sync();
+            next = vb[k - 1] != 0;
+        }
+        if (cur && next) {
+            SOCP_PAR_FOR(jc, k - 1, n) {
+                if (jc == k - 1) sums[jc] = dot_run(vb, A + jc, ld, k - 1, n, 0.0);              // the new e_{k-1}: reflector k does not reach it
+                else sums[jc] = axpy_dot_run(A + jc, ld, va, vb, k, k - 1, n, sums[jc] / piv);
             }
+        } else if (cur) {
+            SOCP_PAR_FOR(jc, k, n) axpy_run(A + jc, ld, va, k, n, sums[jc] / piv);
+        } else if (next) {
+            SOCP_PAR_FOR(jc, k - 1, n) sums[jc] = dot_run(vb, A + jc, ld, k - 1, n, 0.0);
         }
         ex.sync();
+        double *const t = va; va = vb; vb = t;
+        cur = next;
     }
     return sing;
 }

@@ -130,6 +130,19 @@ def test_failure_paths_are_the_host_ones(sim):
     assert dev["info"] in (4, 5)
     same(sim_solve(sim, flat, None, x0, 1e-8, 1.0, analytic=False, blocked=1), host)          # identity reflectors in the blocked form
 
+    # zero columns anywhere: first, in the middle, two in a row, next to last (the fused factor sweeps have a path for "no
+    # reflector in hand" and one for "no next reflector")
+    for dead in ((0,), (4,), (4, 5), (8,), (0, 1, 9)):
+        def holes(x, dead=dead):
+            y = x.copy()
+            y[list(dead)] = -1.0                                 # those unknowns do not enter
+            f = broyden_tri(y)
+            return f
+        jac = lambda x, fv, e, g=holes: fd_jacobian(g, x, fv, e)  # noqa: E731
+        host = capi.hybrd(holes, x0.copy(), xtol=1e-8, epsfcn=1e-15, fdjac=jac)
+        same(sim_solve(sim, holes, None, x0, 1e-8, 1.0, analytic=False), host)
+        same(sim_solve(sim, holes, None, x0, 1e-8, 1.0, analytic=False, blocked=1), host)
+
     def nanny(x):
         f = broyden_tri(x)
         f[3] = np.nan
