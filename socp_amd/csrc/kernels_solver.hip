@@ -165,7 +165,29 @@ hipError_t launch_advance(hipStream_t st, const PoolDev &pool, const int *d_list
     const unsigned grid = (unsigned)((cap > 0 && cap < count) ? cap : count);
     const size_t lds_bytes = vector_bytes + (lds_matrix ? matrix_bytes : 0);
     if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;           // n > 2560: the caller keeps such problems on the host
-    const int threads = threads_for(n);
+    int threads = threads_for(n);
+    {
+        // Workgroup size.  The iteration is the same for any size (a thread then owns several columns; same numbers).  Launches of
+        // problems with a fresh Jacobian keep a thread per column: the factor sweeps are bandwidth, and fewer threads per problem
+        // measured 20-25 % slower.  The other launches (trial steps: dogleg, Broyden update -- latency chains with a barrier per
+        // step) shrink their workgroups when the launch does not fit the chip at full size, so that every problem is resident at
+        // once instead of queueing behind a workgroup that mostly waits at barriers: measured 5-9 % of the solver time of
+        // 4096 x (n = 85 / 127) and 2048 x (n = 253); a launch that fits keeps the full size (256 x (n = 253) is 5 % slower at 64).
+        // SOCP_SOLVER_THREADS_FACTOR / SOCP_SOLVER_THREADS_TRIAL (multiples of 64) override both (A/B, tests).
+        const char *e = std::getenv(factor_phase ? "SOCP_SOLVER_THREADS_FACTOR" : "SOCP_SOLVER_THREADS_TRIAL");
+        const long want = e ? std::atol(e) : 0L;
+        if (want >= 64 && want % 64 == 0) {
+            if (want < threads) threads = (int)want;
+        } else if (!factor_phase && threads > 64) {
+            int dev = 0, cus = 0;
+            if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) {
+                const long slots = (long)cus * 4 * 3;                        // wavefronts resident at this kernel's register count
+                const long waves = slots / count;                            // ... per problem, if all are to be resident
+                const int fit = (int)(waves < 1 ? 1 : waves) * 64;
+                if (fit < threads) threads = fit;
+            }
+        }
+    }
 #define SOCP_LAUNCH_ADVANCE(MAXT)                                                                                                          \
     do {                                                                                                                                   \
         if (lds_bytes > 65536) {                                                                                                           \

@@ -258,3 +258,52 @@ def test_blocked_factor_kernel_changes_no_bit(case):
     for k in KEYS:
         assert np.array_equal(blocked[k], inplace[k], equal_nan=True), k
     ctx.close()
+
+
+@pytest.mark.parametrize("case", ["n85", "n127", "n253"])
+def test_workgroup_size_changes_no_bit(case, monkeypatch):
+    """The solver launches may use fewer threads than columns (a thread then owns several columns; the trial-step launches do so
+    by themselves when a launch does not fit the chip at full size, kernels_solver.hip: launch_advance): one wavefront per problem
+    forced for both kinds of launch, and two, against the default size and against the host solvers -- identical chains."""
+    from socp_amd import capi, sweep
+    if case == "n253":
+        ctx = capi.Context(capi.MODEL_INTERCEPTOR)
+        ctx.set_variant(capi.VARIANT_LANE_FAST)
+        n, z = sweep.interceptor_config5_problem(ctx)
+        ctx.set_integrator(capi.INT_DOPRI5, 1e-11)
+        rng = np.random.default_rng(11)
+        Z0 = np.tile(z, (5, 1))
+        Z0[:, 6:12] *= 1 + 1e-3 * rng.uniform(-1, 1, (5, 6))
+        kw = dict(kind=capi.CHAIN_PLAIN, xtol=1e-9)
+    else:
+        ctx = capi.Context(capi.MODEL_GODDARD)
+        ctx.set_params(sweep.GODDARD_PARAMS)
+        ctx.set_step_number(10)
+        ctx.set_variant(capi.VARIANT_LANE_FAST)
+        M = 6 if case == "n85" else 9
+        sweep.goddard_multiple_shooting_problem(ctx, M)
+        Z0 = sweep.goddard_multiple_shooting_starts(ctx, sweep.goddard_starts(24, 0.05), M)
+        kw = dict(kind=capi.CHAIN_PLAIN, xtol=1e-10)
+    host, dev = both(ctx, Z0, **kw)
+    for threads in ("64", "128"):
+        monkeypatch.setenv("SOCP_SOLVER_THREADS_FACTOR", threads)
+        monkeypatch.setenv("SOCP_SOLVER_THREADS_TRIAL", threads)
+        small = ctx.chains_solve(Z0, solver=capi.SOLVER_DEVICE, **kw)
+        for k in KEYS:
+            assert np.array_equal(small[k], dev[k], equal_nan=True), (k, threads)
+    ctx.close()
+
+
+def test_trial_launches_that_exceed_the_chip_shrink_their_workgroups():
+    """4096 problems of n = 85 at two wavefronts each do not fit the chip's 3072 resident wavefronts: the trial-step launches then
+    run one wavefront per problem (launch_advance's rule, no switch set).  Same chains as the host solvers, bit for bit."""
+    from socp_amd import capi, sweep
+    ctx = capi.Context(capi.MODEL_GODDARD)
+    ctx.set_params(sweep.GODDARD_PARAMS)
+    ctx.set_step_number(10)
+    ctx.set_variant(capi.VARIANT_LANE_FAST)
+    sweep.goddard_multiple_shooting_problem(ctx, 6)
+    Z0 = sweep.goddard_multiple_shooting_starts(ctx, sweep.goddard_starts(4096, 0.05), 6)
+    host, dev = both(ctx, Z0, kind=capi.CHAIN_PLAIN, xtol=1e-10)
+    assert np.sum(dev["info"] == 1) >= 4000
+    ctx.close()
