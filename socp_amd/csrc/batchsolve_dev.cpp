@@ -317,6 +317,16 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
                              "total %.1f ms; %lld rounds, %lld Jacobians, %lld solver restarts; %d threads per problem, %.1f MB of solver state\n",
                      t_setup, t_adv, t_eval, t_host, ms_since(t_begin), rounds, jac_launched, restarts, socp::devsolver::threads_for(n),
                      1e-6 * sizeof(double) * pool.ws_stride * P);
+    if (trace) {
+        unsigned long long pf[16];
+        if (socp::devsolver::read_profile(pf, true) == hipSuccess && (pf[0] | pf[4] | pf[6]))
+            std::fprintf(stderr, "[socp_chains/device] solver phases, clock ticks of thread 0 summed over problems (a -DSOCP_SOLVER_PROFILE build): trial head %llu, "
+                                 "Q^T w %llu, r1updt %llu, r1mpyq %llu, dogleg %llu, step tail %llu, factor %llu, Jacobian tail %llu\n",
+                         pf[0], pf[1], pf[2], pf[3], pf[4], pf[5], pf[6], pf[7]);
+        if (pf[9] | pf[11])
+            std::fprintf(stderr, "[socp_chains/device] inside the factor work: set-up %llu; qrfac: column ahead %llu, its norm and scaling %llu, sweep %llu; "
+                                 "R, clearing %llu; qform %llu\n", pf[8], pf[9], pf[10], pf[11], pf[12], pf[13]);
+    }
     if (stats) {
         stats->rounds = rounds; stats->jacobians_launched = jac_launched; stats->jacobians_from_cache = 0;
         stats->speculative_rounds = 0; stats->restarts = restarts; stats->wall_ms = ms_since(t_begin);

@@ -233,6 +233,24 @@ hipError_t launch_factor(hipStream_t st, const PoolDev &pool, const int *d_list,
     return hipGetLastError();
 }
 
+// -DSOCP_SOLVER_PROFILE: the per-phase tick totals of solver_dev.hpp's Prof (zeros otherwise); reset = start a new measurement
+hipError_t read_profile(unsigned long long out[16], bool reset)
+{
+    for (int k = 0; k < 16; k++) out[k] = 0;
+#ifdef SOCP_SOLVER_PROFILE
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 16);
+    if (e != hipSuccess) return e;
+    if (reset) {
+        const unsigned long long zero[16] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_prof), zero, sizeof(zero));
+    }
+    return e;
+#else
+    (void)reset;
+    return hipSuccess;
+#endif
+}
+
 hipError_t launch_gather_eval(hipStream_t st, const PoolDev &pool, const int *d_list, int count, double *d_dst)
 {
     if (count <= 0) return hipSuccess;

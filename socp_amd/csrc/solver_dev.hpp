@@ -94,10 +94,38 @@ struct SerialExec {
     SOCP_HD void sync() const {}
 };
 
+// Development aid (-DSOCP_SOLVER_PROFILE, device only): thread 0 of every workgroup adds the clock ticks between marks to
+// per-phase totals (kernels_solver.hip: read_profile; printed with SOCP_MULTISTART_TRACE).  Compiled out otherwise.
+#if defined(SOCP_SOLVER_PROFILE) && defined(__HIPCC__)
+__device__ unsigned long long g_prof[16];
+#endif
+#if defined(SOCP_SOLVER_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+struct Prof {
+    unsigned long long t;
+    __device__ Prof() : t(clock64()) {}
+    __device__ void mark(int slot, int tid)
+    {
+        const unsigned long long now = clock64();
+        if (tid == 0) atomicAdd(&g_prof[slot], now - t);
+        t = now;
+    }
+};
+#else
+struct Prof {
+    SOCP_HD void mark(int, int) {}
+};
+#endif
+enum { PF_TRIAL_HEAD = 0, PF_QTW = 1, PF_R1UPDT = 2, PF_R1MPYQ = 3, PF_DOGLEG = 4, PF_STEP_TAIL = 5, PF_FACTOR = 6, PF_JAC_TAIL = 7 };
+
 // Elements are dealt out by ABSOLUTE index: element i belongs to thread i mod nt whatever the loop bounds are.  r1updt relies
 // on it (a thread keeps "its" w[i] and s(., i) across rotation steps without a barrier), and a thread re-visits the same
 // columns of A from reflector to reflector.
-SOCP_HD int par_first(int lo, int tid, int nt) { return lo + ((tid - lo % nt) + nt) % nt; }
+SOCP_HD int par_first(int lo, int tid, int nt)
+{
+    const int m = (lo < nt) ? lo : lo % nt;                  // (one division at most, none in the common case n <= nt)
+    const int d = tid - m;
+    return lo + (d < 0 ? d + nt : d);
+}
 #define SOCP_PAR_FOR(i, lo, hi) for (int i = par_first((lo), ex.tid, ex.nt); i < (hi); i += ex.nt)
 
 constexpr double kEpsMch = DBL_EPSILON;
@@ -109,6 +137,31 @@ SOCP_HD double enorm(int n, const double *x, long stride = 1)
     const double rdwarf = 3.834e-20, rgiant = 1.304e19;
     double s1 = 0, s2 = 0, s3 = 0, x1max = 0, x3max = 0;
     const double agiant = rgiant / (double)n;
+    // The usual case first, without a branch in the loop: every entry in the middle range or exactly zero.  Then s1 = s3 = 0,
+    // x3max = 0, s2 is the plain sum of squares in the order of i (a zero adds +0.0: no change) and the closing formula
+    // sqrt(s2 (1 + (x3max / s2) (x3max s3))) is sqrt(s2) exactly.  The general loop below has four bodies with a division each
+    // behind data-dependent branches; on the device they cost ~350 cycles per entry, this ~40.
+    {
+        bool plain = true;
+        double sq = 0;
+        int i = 0;
+        for (; i + 8 <= n; i += 8) {                         // eight entries fetched together: the chain is the additions only
+            double xv[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) xv[q] = fabs(x[(long)(i + q) * stride]);
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                plain = plain & (((xv[q] > rdwarf) & (xv[q] < agiant)) | (xv[q] == 0));
+                sq += xv[q] * xv[q];
+            }
+        }
+        for (; i < n; i++) {
+            const double xabs = fabs(x[(long)i * stride]);
+            plain = plain & (((xabs > rdwarf) & (xabs < agiant)) | (xabs == 0));
+            sq += xabs * xabs;
+        }
+        if (plain) return sqrt(sq);                          // = sqrt(sq (1 + (0 / sq) (0 0))), and 0 sqrt(0) when sq = 0
+    }
     for (int i = 0; i < n; i++) {
         const double xabs = fabs(x[(long)i * stride]);
         if (xabs > rdwarf && xabs < agiant) {
@@ -173,6 +226,36 @@ SOCP_HD double dot_run(const double *v, const double *a, long stride, int lo, in
         for (int u = 0; u < kBatch; u++) sum += vv[u] * av[u];
     }
     for (; i < hi; i++) sum += v[i] * a[(long)i * stride];
+    return sum;
+}
+
+// sum + a[lo] + a[lo + 1] + ... + a[hi - 1], added in that order
+SOCP_HD double sum_run(const double *a, int lo, int hi, double sum)
+{
+    int i = lo;
+    for (; i + kBatch <= hi; i += kBatch) {
+        double av[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; u++) av[u] = a[i + u];
+#pragma unroll
+        for (int u = 0; u < kBatch; u++) sum += av[u];
+    }
+    for (; i < hi; i++) sum += a[i];
+    return sum;
+}
+
+// sum + v[lo] c + v[lo + 1] c + ... (every product formed: c = 0 still turns a NaN or an infinity in v into a NaN)
+SOCP_HD double dot_const_run(const double *v, double c, int lo, int hi, double sum)
+{
+    int i = lo;
+    for (; i + kBatch <= hi; i += kBatch) {
+        double vv[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; u++) vv[u] = v[i + u];
+#pragma unroll
+        for (int u = 0; u < kBatch; u++) sum += vv[u] * c;
+    }
+    for (; i < hi; i++) sum += v[i] * c;
     return sum;
 }
 
@@ -327,8 +410,9 @@ SOCP_HD double axpy_dot_run(double *a, long stride, const double *v, const doubl
 // and scaling follow as before, and the sweep then covers the columns from j + 2 on.  A column still meets the reflectors in
 // the order 0, 1, 2, ..., each as the same dot product and the same axpy over its rows in the order of the rows.
 template <class E>
-SOCP_HD bool factor(const E &ex, int n, int ld, Work &w)
+SOCP_HD bool factor(const E &ex, int n, int ld, Work &w, Prof *pf = nullptr)
 {
+#define SOCP_PF(slot) do { if (pf) pf->mark((slot), ex.tid); } while (0)
     double *A = w.A, *rdiag = w.wa1, *acnorm = w.wa2, *col = w.f[0];
     double *va = w.f[1], *vb = w.f[2];                       // the reflector in hand, the next one (they swap every step)
     double *sums = w.f[3];                                   // sums[k], k = 0 .. n: column k's dot product with the reflector in hand
@@ -356,6 +440,7 @@ SOCP_HD bool factor(const E &ex, int n, int ld, Work &w)
         if (cur) SOCP_PAR_FOR(k, 1, n + 1) sums[k] = dot_run(va, A + k, ld, 0, n, 0.0);
         ex.sync();
     }
+    SOCP_PF(8);
     for (int j = 0; j < n; j++) {
         // in hand: va = v_j (if cur), sums[k] = v_j . a_k for k > j
         const double piv = cur ? va[j] : 1.0;
@@ -372,6 +457,7 @@ SOCP_HD bool factor(const E &ex, int n, int ld, Work &w)
             SOCP_PAR_FOR(i, c1, n) col[i] = A[(long)i * ld + c1];
         }
         ex.sync();
+        SOCP_PF(9);
         if (c1 < n) {
             double ajnorm = enorm(n - c1, col + c1);
             if (ajnorm != 0 && col[c1] < 0) ajnorm = -ajnorm;
@@ -387,6 +473,7 @@ SOCP_HD bool factor(const E &ex, int n, int ld, Work &w)
             if (ex.tid == 0) rdiag[c1] = -ajnorm;
             ex.sync();
         }
+        SOCP_PF(10);
         // the columns from j + 2 on (and fvec's): reflector j's axpy, reflector j + 1's dot product
         if (cur && next) {
             SOCP_PAR_FOR(k, j + 2, n + 1) sums[k] = axpy_dot_run(A + k, ld, va, vb, j, c1, n, sums[k] / piv);
@@ -396,6 +483,7 @@ SOCP_HD bool factor(const E &ex, int n, int ld, Work &w)
             SOCP_PAR_FOR(k, j + 2, n + 1) sums[k] = dot_run(vb, A + k, ld, c1, n, 0.0);
         }
         ex.sync();
+        SOCP_PF(11);
         double *const t = va; va = vb; vb = t;
         cur = next;
     }
@@ -420,6 +508,7 @@ SOCP_HD bool factor(const E &ex, int n, int ld, Work &w)
     cur = va[n - 1] != 0;
     if (cur) SOCP_PAR_FOR(jc, n - 1, n) sums[jc] = dot_run(va, A + jc, ld, n - 1, n, 0.0);
     ex.sync();
+    SOCP_PF(12);
     for (int k = n - 1; k >= 0; k--) {
         // in hand: va = v_k (rows k .. n-1), sums[jc] = v_k . q_jc for jc >= k (if cur)
         const double piv = cur ? va[k] : 1.0;
@@ -430,19 +519,29 @@ SOCP_HD bool factor(const E &ex, int n, int ld, Work &w)
             next = vb[k - 1] != 0;
         }
         if (cur && next) {
-            SOCP_PAR_FOR(jc, k - 1, n) {
-                if (jc == k - 1) sums[jc] = dot_run(vb, A + jc, ld, k - 1, n, 0.0);              // the new e_{k-1}: reflector k does not reach it
-                else sums[jc] = axpy_dot_run(A + jc, ld, va, vb, k, k - 1, n, sums[jc] / piv);
-            }
+            // column k - 1 is the new e_{k-1}, which reflector k does not reach: its dot product with v_{k-1} runs on the vector
+            // alone (1.0 and 0.0 as the column's entries, every product formed) by all threads alike -- one thread on a path
+            // of its own would hold its whole wavefront back for the length of a second sweep
+            double odd = 0.0;
+            odd += vb[k - 1] * 1.0;
+            odd = dot_const_run(vb, 0.0, k, n, odd);
+            if (ex.tid == (k - 1) % ex.nt) sums[k - 1] = odd;
+            SOCP_PAR_FOR(jc, k, n) sums[jc] = axpy_dot_run(A + jc, ld, va, vb, k, k - 1, n, sums[jc] / piv);
         } else if (cur) {
             SOCP_PAR_FOR(jc, k, n) axpy_run(A + jc, ld, va, k, n, sums[jc] / piv);
         } else if (next) {
-            SOCP_PAR_FOR(jc, k - 1, n) sums[jc] = dot_run(vb, A + jc, ld, k - 1, n, 0.0);
+            double odd = 0.0;                                // (column k - 1 as above: on the vector alone)
+            odd += vb[k - 1] * 1.0;
+            odd = dot_const_run(vb, 0.0, k, n, odd);
+            if (ex.tid == (k - 1) % ex.nt) sums[k - 1] = odd;
+            SOCP_PAR_FOR(jc, k, n) sums[jc] = dot_run(vb, A + jc, ld, k - 1, n, 0.0);
         }
         ex.sync();
         double *const t = va; va = vb; vb = t;
         cur = next;
     }
+    SOCP_PF(13);
+#undef SOCP_PF
     return sing;
 }
 
@@ -581,9 +680,17 @@ SOCP_HD void dogleg(const E &ex, int n, Work &w, double delta)
         const int j = n - k;
         jj -= k;
         double *row = (k & 1) ? w.f[2] : w.f[1];            // (no run-time index into the pointer table: it would go to scratch)
-        SOCP_PAR_FOR(i, j, n) row[i] = r[jj + (i - j)];
+        // the products r(j, i) x[i] are formed by the threads that fetch the row, all at once -- except the one with x[j + 1],
+        // which thread 0 stored after the last barrier: that entry travels as it is and is multiplied after this one.  The chain
+        // every thread then runs is additions only, in the order of i, of the same rounded products.
+        SOCP_PAR_FOR(i, j, n) {
+            const double rv = r[jj + (i - j)];
+            row[i] = (i >= j + 2) ? rv * xl[i] : rv;
+        }
         ex.sync();                                           // the row, qtb, and the x[j + 1] thread 0 stored before arriving here
-        const double sum = dot_run(row, xl, 1, j + 1, n, 0.0);
+        double sum = 0.0;
+        if (j + 1 < n) sum += row[j + 1] * xl[j + 1];
+        sum = sum_run(row, j + 2, n, sum);
         double temp = row[j];
         if (temp == 0) {
             long l = j;
@@ -762,6 +869,7 @@ struct Machine {
     State &st;                 // in global memory; `s` is this thread's copy
     State s;
     Work w;
+    Prof prof;
     double *fast_matrix = nullptr;   // device: an LDS buffer of n * ld doubles for the factor work (null: work in place)
     double *blocked_panel = nullptr, *blocked_block = nullptr;   // buffers of factor_blocked (the host simulation's way to run it)
     SOCP_HD Machine(const E &e, const Config &cfg, State &state, double *base, double *fast_vectors = nullptr)
@@ -774,7 +882,9 @@ struct Machine {
     SOCP_HD void request_trial()
     {
         const int n = c.n;
+        prof.mark(15, ex.tid);
         dogleg(ex, n, w, s.delta);
+        prof.mark(PF_DOGLEG, ex.tid);
         double *sc = w.f[0];
         SOCP_PAR_FOR(j, 0, n) {
             const double p = -w.wa1[j];
@@ -787,6 +897,7 @@ struct Machine {
         if (s.iter == 1) s.delta = min_of(s.delta, s.pnorm);
         s.phase = PH_TRIAL;
         s.req = RQ_FVEC; s.eval_sel = 1;
+        prof.mark(PF_STEP_TAIL, ex.tid);
     }
 
     SOCP_HD void after_jacobian()
@@ -812,7 +923,9 @@ struct Machine {
             SOCP_PAR_FOR(e, 0, (int)len) home[e] = fast_matrix[e];
             ex.sync();
         } else {
-            sing = factor(ex, n, c.ld, w);
+            prof.mark(15, ex.tid);
+            sing = factor(ex, n, c.ld, w, &prof);
+            prof.mark(PF_FACTOR, ex.tid);
         }
         if (s.iter == 1) {
             if (c.mode != 2) SOCP_PAR_FOR(j, 0, n) w.diag[j] = (w.wa2[j] == 0) ? 1.0 : w.wa2[j];
@@ -827,6 +940,7 @@ struct Machine {
         ex.sync();
         if (c.mode != 2) SOCP_PAR_FOR(j, 0, n) w.diag[j] = max_of(w.diag[j], w.wa2[j]);
         ex.sync();
+        prof.mark(PF_JAC_TAIL, ex.tid);
     }
 
     SOCP_HD void after_trial()
@@ -878,6 +992,7 @@ struct Machine {
         if (s.ncfail == 2) { request_jac(); return; }
 
         // Broyden rank-1 update of (Q, R, Q^T f): v -> f4, u -> f5 (r1updt's inputs)
+        prof.mark(PF_TRIAL_HEAD, ex.tid);
         const double pnorm = s.pnorm;
         SOCP_PAR_FOR(j, 0, n) {
             const double sum = dot_run(f4c, w.A + j, c.ld, 0, n, 0.0);
@@ -886,8 +1001,11 @@ struct Machine {
             if (ratio >= p0001) w.qtf[j] = sum;
         }
         ex.sync();
+        prof.mark(PF_QTW, ex.tid);
         s.sing = r1updt(ex, n, w) ? 1 : 0;
+        prof.mark(PF_R1UPDT, ex.tid);
         r1mpyq_all(ex, n, c.ld, w);
+        prof.mark(PF_R1MPYQ, ex.tid);
         s.jeval = 0;
         request_trial();
     }

@@ -26,6 +26,7 @@ hipError_t launch_advance(hipStream_t st, const PoolDev &pool, const int *d_list
 // the Jacobian refresh of list[0 .. count) through the LDS-blocked factor kernel (one wavefront per problem); the following
 // launch_advance(..., factor_phase = true) then finds the factors in place.  blocked_factor_applies: whether to use it for size n
 bool blocked_factor_applies(int n);
+hipError_t read_profile(unsigned long long out[16], bool reset);   // -DSOCP_SOLVER_PROFILE builds: per-phase clock totals
 hipError_t launch_factor(hipStream_t st, const PoolDev &pool, const int *d_list, int count);
 // dst[k][n] = the point problem list[k] asked to be evaluated (x, or the trial point)
 hipError_t launch_gather_eval(hipStream_t st, const PoolDev &pool, const int *d_list, int count, double *d_dst);
