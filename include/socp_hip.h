@@ -98,6 +98,11 @@ int socp_ctx_set_variant(socp_ctx *ctx, int variant);
 int socp_ctx_set_stream(socp_ctx *ctx, void *hip_stream, int use_own);
 /* the stream launches currently go to (the context's own stream or the one given to socp_ctx_set_stream) */
 int socp_ctx_get_stream(const socp_ctx *ctx, void **hip_stream);
+/* a second stream owned by the context (non-blocking, highest priority where the device has priorities: its own hardware
+ * queue, so that work on it overlaps work on the context's stream).  Created on the first call -- that takes ~6 ms, which is
+ * why the lock-step engines keep it instead of creating one per call -- and destroyed with the context.  Nothing is ever
+ * enqueued on it by the context itself: the engines (socp_chains_solve, socp_multistart_solve) use it while they run. */
+int socp_ctx_aux_stream(socp_ctx *ctx, void **hip_stream);
 int socp_ctx_synchronize(socp_ctx *ctx);
 int socp_ctx_dims(const socp_ctx *ctx, int *dim, int *state_len, int *state_len_jac);
 int socp_ctx_control_dim(const socp_ctx *ctx);

@@ -3,7 +3,7 @@
 # (variants live in socp_amd/_build/variants/; each is copied over the library before its runs -- on the GPU box's scratch copy)
 export SOCP_MULTISTART_TRACE=1
 out=gpurun_out/$1; shift; mkdir -p $out
-run() { tag=$1; shift; "$@" > $out/$tag.json 2> $out/$tag.trace; echo "$tag: $(python3 -c "import json; r=json.load(open('$out/$tag.json')); print(round(r['wall_s'],4), r['converged'])") | $(grep 'set-up' $out/$tag.trace | sed 's/.*set-up/set-up/' | cut -c1-140)"; }
+run() { tag=$1; shift; "$@" > $out/$tag.json 2> $out/$tag.trace; echo "$tag: $(python3 -c "import json; r=json.load(open('$out/$tag.json')); print(round(r['wall_s'],4), r['converged'])") | $(grep 'set-up [0-9]' $out/$tag.trace | tail -1 | sed 's/.*set-up/set-up/' | cut -c1-140)"; }
 for so in "$@"; do
   v=$(basename $so .so)
   cp $so socp_amd/_build/libsocp_hip.so

@@ -89,6 +89,7 @@ def lib():
         L.socp_ctx_set_switching_times.argtypes = [_vp, _dp, C.c_int]
         L.socp_ctx_set_variant.argtypes = [_vp, C.c_int]
         L.socp_ctx_set_stream.argtypes = [_vp, _vp, C.c_int]
+        L.socp_ctx_aux_stream.argtypes = [_vp, C.POINTER(C.c_void_p)]
         L.socp_ctx_dims.argtypes = [_vp, _ip, _ip, _ip]
         L.socp_ctx_control_dim.argtypes = [_vp]
         L.socp_ctx_device.argtypes = [_vp]
@@ -194,6 +195,12 @@ class Context:
             raise SocpError(rc, self.L.socp_last_error(self.h).decode())
 
     # -- configuration
+    def aux_stream(self):
+        """The context's second stream (socp_ctx_aux_stream): created on the first call (~6 ms), then kept."""
+        st = C.c_void_p()
+        self._chk(self.L.socp_ctx_aux_stream(self.h, C.byref(st)))
+        return st.value
+
     def has_variational(self):
         return self.L.socp_ctx_has_variational(self.h) == 1
 

@@ -311,12 +311,17 @@ extern "C" int socp_chains_solve_ex(socp_ctx *ctx, int P, const socp_chain_optio
         // group 0 launches its Jacobians on the context's stream (as the engine always did); residual-type work on a second one
         if (g == 0) q.js = main_stream;
         else { ok = hipStreamCreateWithFlags(&q.js, hipStreamNonBlocking) == hipSuccess; q.own_js = ok; }
-        if (ok && overlap) { ok = socp::chains::create_residual_stream(&q.fs) == hipSuccess; q.own_fs = ok; }
+        if (ok && overlap && g == 0) {
+            void *aux = nullptr;                             // the context's own second stream (kept across calls)
+            ok = socp_ctx_aux_stream(ctx, &aux) == SOCP_OK;
+            q.fs = static_cast<hipStream_t>(aux);
+        } else if (ok && overlap) { ok = socp::chains::create_residual_stream(&q.fs) == hipSuccess; q.own_fs = ok; }
         else if (ok) q.fs = q.js;
     }
     auto release_streams = [&]() {
         for (Group &q : grp) {
             if (q.own_fs && q.fs) { (void)hipStreamSynchronize(q.fs); (void)hipStreamDestroy(q.fs); }
+            else if (q.fs && q.fs != q.js) (void)hipStreamSynchronize(q.fs);      // the context's second stream: left idle, not destroyed
             if (q.own_js && q.js) { (void)hipStreamSynchronize(q.js); (void)hipStreamDestroy(q.js); }
             q.fs = q.js = nullptr;
         }

@@ -35,20 +35,35 @@ namespace {
 using socp::devsolver::PoolDev;
 using socp::devsolver::State;
 
-struct Pinned {
+// The engine's buffers: ONE device allocation and ONE pinned host allocation, carved into aligned pieces (thirty-odd separate
+// hipMalloc / hipHostMalloc calls were 5 of the 6-8 ms a call spent before its first launch).
+struct Arena {
+    char *base = nullptr;
+    size_t used = 0, cap = 0;
+    bool pinned = false;
+    static size_t pad(size_t bytes) { return (bytes + 255) / 256 * 256; }
+    size_t plan(size_t bytes) { const size_t at = used; used += pad(bytes ? bytes : 8); return at; }
+    bool alloc(bool host)
+    {
+        pinned = host;
+        cap = used ? used : 256;
+        void *p = nullptr;
+        const hipError_t e = host ? hipHostMalloc(&p, cap, hipHostMallocDefault) : hipMalloc(&p, cap);
+        base = static_cast<char *>(p);
+        return e == hipSuccess;
+    }
+    ~Arena() { if (base) (void)(pinned ? hipHostFree(base) : hipFree(base)); }
+};
+struct Piece {
+    size_t at = 0;
     void *p = nullptr;
-    bool alloc(size_t bytes) { return hipHostMalloc(&p, bytes ? bytes : 8, hipHostMallocDefault) == hipSuccess; }
-    ~Pinned() { if (p) (void)hipHostFree(p); }
+    void plan(Arena &a, size_t bytes) { at = a.plan(bytes); }
+    void bind(const Arena &a) { p = a.base + at; }
     double *d() const { return static_cast<double *>(p); }
     int *i() const { return static_cast<int *>(p); }
 };
-struct Dev {
-    void *p = nullptr;
-    bool alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8) == hipSuccess; }
-    ~Dev() { if (p) (void)hipFree(p); }
-    double *d() const { return static_cast<double *>(p); }
-    int *i() const { return static_cast<int *>(p); }
-};
+using Pinned = Piece;
+using Dev = Piece;
 
 }  // namespace
 
@@ -122,19 +137,33 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
 
     Dev dWs, dStates, dList, dFlags, dListF, dListJ, dX, dF, dJx, dJf, dJ, dRes, dPF, dTF, dXF, dPJ, dTJ, dXJ;
     Pinned hStates, hList, hFlags, hListF, hListJ, hX, hRes, hPF, hTF, hXF, hPJ, hTJ, hXJ;
-    bool ok = dWs.alloc(sizeof(double) * pool.ws_stride * P) && dStates.alloc(sizeof(State) * P) && dList.alloc(sizeof(int) * P) &&
-              dFlags.alloc(sizeof(int) * P) && dListF.alloc(sizeof(int) * P) && dListJ.alloc(sizeof(int) * P) && dX.alloc(rowB * P) &&
-              dF.alloc(rowB * P) && dJx.alloc(rowB * P) && dJf.alloc(rowB * P) && dJ.alloc(jacB * jlaunch) && dRes.alloc(2 * rowB * P) &&
-              hStates.alloc(sizeof(State) * P) && hList.alloc(sizeof(int) * P) && hFlags.alloc(sizeof(int) * P) &&
-              hListF.alloc(sizeof(int) * P) && hListJ.alloc(sizeof(int) * P) && hX.alloc(rowB * P) && hRes.alloc(2 * rowB * P);
-    if (ok && pp_params) ok = dPF.alloc(sizeof(double) * stride * P) && dPJ.alloc(sizeof(double) * stride * P) &&
-                              hPF.alloc(sizeof(double) * stride * P) && hPJ.alloc(sizeof(double) * stride * P);
-    if (ok && pp_bound) ok = dTF.alloc(sizeof(double) * nodes * P) && dTJ.alloc(sizeof(double) * nodes * P) &&
-                             dXF.alloc(sizeof(double) * nodes * S * P) && dXJ.alloc(sizeof(double) * nodes * S * P) &&
-                             hTF.alloc(sizeof(double) * nodes * P) && hTJ.alloc(sizeof(double) * nodes * P) &&
-                             hXF.alloc(sizeof(double) * nodes * S * P) && hXJ.alloc(sizeof(double) * nodes * S * P);
-    if (ok) ok = socp::chains::create_residual_stream(&fs) == hipSuccess;
-    if (!ok) { (void)hipGetLastError(); if (fs) (void)hipStreamDestroy(fs); return SOCP_ERR_HIP; }
+    Arena dev_arena, host_arena;
+    {
+        const size_t intsB = sizeof(int) * P, parB = sizeof(double) * stride * P, timeB = sizeof(double) * nodes * P, nodeB = timeB * S;
+        struct { Piece *piece; size_t bytes; bool host; } plan[] = {
+            {&dWs, sizeof(double) * pool.ws_stride * P, false}, {&dStates, sizeof(State) * P, false}, {&dList, intsB, false},
+            {&dFlags, intsB, false}, {&dListF, intsB, false}, {&dListJ, intsB, false}, {&dX, rowB * P, false}, {&dF, rowB * P, false},
+            {&dJx, rowB * P, false}, {&dJf, rowB * P, false}, {&dJ, jacB * jlaunch, false}, {&dRes, 2 * rowB * P, false},
+            {&dPF, pp_params ? parB : 0, false}, {&dPJ, pp_params ? parB : 0, false}, {&dTF, pp_bound ? timeB : 0, false},
+            {&dTJ, pp_bound ? timeB : 0, false}, {&dXF, pp_bound ? nodeB : 0, false}, {&dXJ, pp_bound ? nodeB : 0, false},
+            {&hStates, sizeof(State) * P, true}, {&hList, intsB, true}, {&hFlags, intsB, true}, {&hListF, intsB, true},
+            {&hListJ, intsB, true}, {&hX, rowB * P, true}, {&hRes, 2 * rowB * P, true}, {&hPF, pp_params ? parB : 0, true},
+            {&hPJ, pp_params ? parB : 0, true}, {&hTF, pp_bound ? timeB : 0, true}, {&hTJ, pp_bound ? timeB : 0, true},
+            {&hXF, pp_bound ? nodeB : 0, true}, {&hXJ, pp_bound ? nodeB : 0, true}};
+        for (auto &e : plan) e.piece->plan(e.host ? host_arena : dev_arena, e.bytes);
+        const double t0 = ms_since(t_begin);
+        bool ok = dev_arena.alloc(false);
+        const double t1 = ms_since(t_begin);
+        ok = ok && host_arena.alloc(true);
+        const double t2 = ms_since(t_begin);
+        void *aux = nullptr;
+        if (ok) ok = socp_ctx_aux_stream(ctx, &aux) == SOCP_OK;              // the context's second stream (created on its first use: ~6 ms)
+        fs = static_cast<hipStream_t>(aux);
+        if (trace) std::fprintf(stderr, "[socp_chains/device] set-up: host tables %.2f ms, device arena (%.1f MB) %.2f ms, pinned arena (%.1f MB) %.2f ms, stream %.2f ms\n",
+                                t0, 1e-6 * dev_arena.cap, t1 - t0, 1e-6 * host_arena.cap, t2 - t1, ms_since(t_begin) - t2);
+        if (!ok) { (void)hipGetLastError(); return SOCP_ERR_HIP; }
+        for (auto &e : plan) e.piece->bind(e.host ? host_arena : dev_arena);
+    }
     pool.states = static_cast<State *>(dStates.p);
     pool.ws = dWs.d();
     State *hS = static_cast<State *>(hStates.p);
@@ -291,11 +320,11 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
         adv_jac = kJ;
         advflag.assign(adv.size(), 0);
     }
+    const clk::time_point t_loop_end = clk::now();
     socp_problem_set_blocks_dev(ctx, nullptr, 0, nullptr, nullptr);
     socp_ctx_set_stream(ctx, main_stream, 0);
     (void)hipStreamSynchronize(fs);
     (void)hipStreamSynchronize(main_stream);
-    (void)hipStreamDestroy(fs);
 
     if (rc == SOCP_OK) {
         for (int p = 0; p < P; p++) {
@@ -312,6 +341,7 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
         }
     }
     if (trace && round_limit_hit) std::fprintf(stderr, "[socp_chains/device] round limit %d reached: the chains still solving were stopped\n", opt->max_rounds);
+    if (trace) std::fprintf(stderr, "[socp_chains/device] after the last round %.2f ms\n", ms_since(t_loop_end));
     if (trace)
         std::fprintf(stderr, "[socp_chains/device] set-up %.1f ms, solver kernels + state read-back %.1f ms, evaluation launches %.1f ms, host chain logic %.1f ms, "
                              "total %.1f ms; %lld rounds, %lld Jacobians, %lld solver restarts; %d threads per problem, %.1f MB of solver state\n",

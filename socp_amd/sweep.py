@@ -179,6 +179,16 @@ def interceptor_config5_problem(ctx, M=21):
     return n, np.concatenate([X[:M].ravel(), [tf]])
 
 
+def warm_up(ctx, args, solve_first):
+    """What a process pays ONCE, kept out of the timed solve like the context and the problem set-up: the context's second stream
+    (~6 ms) and the first launch of every kernel the engine uses (code-object load, ~9 ms) -- through a solve of the first
+    --warmup starts (0: none; the timed call then includes both).  Returns the trajectory counter to subtract."""
+    ctx.aux_stream()
+    if args.warmup > 0:
+        solve_first(min(args.warmup, args.starts))
+    return ctx.counters()[0]
+
+
 def interceptor_sweep(args, torch, dist, capi, world, rank, local_rank, dev, record_fd):
     ctx = capi.Context(capi.MODEL_INTERCEPTOR, device=local_rank)
     ctx.set_variant(capi.VARIANT_LANE_FAST if args.variant == "fast" else capi.VARIANT_LANE_EXACT)
@@ -201,13 +211,18 @@ def interceptor_sweep(args, torch, dist, capi, world, rank, local_rank, dev, rec
         stats.update(r["stats"])
         r["rounds"] = r["stats"]["rounds"]
         return r
+    c0 = warm_up(ctx, args, lambda k: solve_block(Z0[:k]))
+    stats.clear()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     table, local = run_sweep(Z0, solve_block, dist if world > 1 else None, dev)
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
     wall = time.perf_counter() - t0
-    traj = torch.tensor([float(ctx.counters()[0])], dtype=torch.float64, device=dev)
+    traj = torch.tensor([float(ctx.counters()[0] - c0)], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(traj)
     if rank == 0:
@@ -215,6 +230,7 @@ def interceptor_sweep(args, torch, dist, capi, world, rank, local_rank, dev, rec
         conv = table[info == 1, :n]
         record = json.dumps({"sweep": "interceptor_config5_M21_n%d_%s" % (n, "rk4" if args.fixed_step else "dopri5_tol%g" % args.ode_tol),
                              "starts": args.starts, "eps": eps, "n_gpus": world, "variant": args.variant, "solver": args.solver, "xtol": args.xtol, "wall_s": wall,
+                             "warmup_starts": args.warmup,
                              "converged": int(np.sum(info == 1)), "info_histogram": {str(k): int(np.sum(info == k)) for k in np.unique(info)},
                              "solution_spread_rel": float(np.max(np.abs(conv - np.median(conv, axis=0))) / np.max(np.abs(conv))) if len(conv) else None,
                              "solves_per_s": args.starts / wall, "trajectories": int(traj.item()), "trajectories_per_s": traj.item() / wall,
@@ -252,6 +268,8 @@ def main():
     ap.add_argument("--max-rounds", type=int, default=0, help="socp_chain_options.max_rounds: stop chains still solving after "
                     "that many launch rounds (info = -3); 0 = no limit")
     ap.add_argument("--speculate", type=int, default=-1, help="socp_chain_options.speculate: -1 auto, 0 never, 1 always")
+    ap.add_argument("--warmup", type=int, default=8, help="starts of one untimed solve before the timed one (what a process pays once: the "
+                    "context's second stream ~6 ms, first-launch code-object loads ~9 ms); 0: the timed call includes them")
     ap.add_argument("--solver", choices=["auto", "host", "device"], default="auto", help="socp_chain_options.solver: where the chains' "
                     "hybrd state machines run (auto: on the device from n >= 32 and P n^2 >= 2e6)")
     args = ap.parse_args()
@@ -309,10 +327,6 @@ def main():
         Z0 = Zfull
     n_unknown = Z0.shape[1]
 
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
     stats = {}
 
     solver = {"auto": capi.SOLVER_AUTO, "host": capi.SOLVER_HOST, "device": capi.SOLVER_DEVICE}[args.solver]
@@ -327,12 +341,25 @@ def main():
         stats["solves"] = int(np.sum(r["solves"]))
         r["rounds"] = r["stats"]["rounds"]
         return r
+    lo_w, hi_w = shard(args.starts, rank, world)
+
+    def warm(k):
+        # the first k starts of this rank's block through the same call (continuation chains: with their own goals / parameters)
+        if chain_kw is not None:
+            return ctx.chains_solve(Z0[lo_w:lo_w + k], goal=goals[lo_w:lo_w + k], params=params[lo_w:lo_w + k], xtol=args.xtol, solver=solver, **chain_kw)
+        return ctx.chains_solve(Z0[lo_w:lo_w + k], kind=capi.CHAIN_PLAIN, xtol=args.xtol, speculate=args.speculate, max_rounds=args.max_rounds, solver=solver)
+    c0 = warm_up(ctx, args, warm)
+    stats.clear()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
     table, local = run_sweep(Z0, solve_block, dist if world > 1 else None, dev)
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
     wall = time.perf_counter() - t0
-    traj = torch.tensor([float(ctx.counters()[0])], dtype=torch.float64, device=dev)
+    traj = torch.tensor([float(ctx.counters()[0] - c0)], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(traj)
     if rank == 0:
@@ -346,7 +373,7 @@ def main():
                           "continuation": None if chain_kw is None else {"parameter": "KD", "from": 0.0, "goal": args.kd_goal, "goal_spread": args.kd_spread, "step": args.step},
                           "engine_rank0": stats,
                           "starts": args.starts, "eps": eps, "n_gpus": world, "solver": args.solver,
-                          "rk4_steps": args.rk4_steps, "variant": args.variant, "xtol": args.xtol, "wall_s": wall, "max_rounds": args.max_rounds,
+                          "rk4_steps": args.rk4_steps, "variant": args.variant, "xtol": args.xtol, "wall_s": wall, "warmup_starts": args.warmup, "max_rounds": args.max_rounds,
                           "converged": int(np.sum(info == 1)), "info_histogram": {str(k): int(np.sum(info == k)) for k in np.unique(info)},
                           "trajectories": int(traj.item()), "trajectories_per_s": traj.item() / wall,
                           "solves_per_s": args.starts / wall, "rounds_rank0": int(local["rounds"]),
