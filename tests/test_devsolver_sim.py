@@ -160,3 +160,78 @@ def test_failure_paths_are_the_host_ones(sim):
     dev = sim_solve(sim, broyden_tri, None, x0, 1e-8, 1.0, analytic=False, abort_after=4)
     assert host["info"] == -1 and dev["info"] == -7          # the callback's own negative value becomes info (shooting.cpp:873)
     assert np.array_equal(dev["x"], host["x"]) and np.array_equal(dev["fvec"], host["fvec"])
+
+
+def _minpack_enorm(x):
+    """MINPACK's enorm, statement for statement (SURVEY App. A lists it; minpack.cpp: enorm) in numpy float64 scalars = IEEE doubles
+    (division by zero and NaN comparisons as in C)."""
+    f = np.float64
+    n = len(x)
+    rdwarf, rgiant = f(3.834e-20), f(1.304e19)
+    s1 = s2 = s3 = x1max = x3max = f(0.0)
+    agiant = rgiant / f(n)
+    with np.errstate(all="ignore"):
+        for v in x:
+            xabs = np.abs(f(v))
+            if xabs > rdwarf and xabs < agiant:
+                s2 = s2 + xabs * xabs
+            elif xabs <= rdwarf:
+                if xabs > x3max:
+                    q = x3max / xabs
+                    s3 = f(1.0) + s3 * (q * q)
+                    x3max = xabs
+                elif xabs != 0:
+                    q = xabs / x3max
+                    s3 = s3 + q * q
+            else:
+                if xabs > x1max:
+                    q = x1max / xabs
+                    s1 = f(1.0) + s1 * (q * q)
+                    x1max = xabs
+                else:
+                    q = xabs / x1max
+                    s1 = s1 + q * q
+        if s1 != 0:
+            return float(x1max * np.sqrt(s1 + (s2 / x1max) / x1max))
+        if s2 != 0:
+            if s2 >= x3max:
+                return float(np.sqrt(s2 * (f(1.0) + (x3max / s2) * (x3max * s3))))
+            return float(np.sqrt(x3max * ((s2 / x3max) + (x3max * s3))))
+        return float(x3max * np.sqrt(s3))
+
+
+def test_norm_usual_case_and_general_case_are_minpacks(sim):
+    """enorm's branch-free usual case (every entry in the middle range or zero: a plain sum of squares) must be MINPACK's number
+    bit for bit, and anything else must fall through to the three-accumulator loop: lengths across the 8-entry batches, zeros,
+    dwarfs, giants, mixtures, strided input."""
+    sim.sim_enorm.restype = C.c_double
+    sim.sim_enorm.argtypes = [C.c_int, _dp, C.c_long]
+    rng = np.random.default_rng(7)
+    cases = []
+    for n in (1, 2, 7, 8, 9, 15, 16, 17, 64, 85, 253):
+        x = rng.normal(size=n) * 10.0 ** rng.integers(-6, 7, size=n)
+        cases.append(x)
+        z = x.copy(); z[rng.integers(0, n, size=max(1, n // 3))] = 0.0
+        cases.append(z)
+        cases.append(np.zeros(n))
+        t = x.copy(); t[rng.integers(0, n)] = 1e-25                     # one dwarf: the general loop
+        cases.append(t)
+        g = x.copy(); g[rng.integers(0, n)] = 3e19                      # one giant
+        cases.append(g)
+        cases.append(rng.normal(size=n) * 1e-30)                        # all dwarfs
+        cases.append(rng.normal(size=n) * 1e25)                         # all giants
+        m = x.copy(); m[0] = 1e-22; m[-1] = -7e20
+        cases.append(m)
+    for x in cases:
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        got = sim.sim_enorm(len(x), x.ctypes.data_as(_dp), 1)
+        want = _minpack_enorm(x)
+        assert got == want or (np.isnan(got) and np.isnan(want)), (len(x), got, want)
+    # strided (a matrix column) and non-finite entries
+    A = np.ascontiguousarray(rng.normal(size=(9, 12)))
+    assert sim.sim_enorm(9, A[:, 5:].ctypes.data_as(_dp), 12) == _minpack_enorm(A[:, 5])
+    for bad in (np.nan, np.inf):
+        x = rng.normal(size=11); x[4] = bad
+        got = sim.sim_enorm(11, x.ctypes.data_as(_dp), 1)
+        want = _minpack_enorm(x)
+        assert (np.isnan(got) and np.isnan(want)) or got == want, (bad, got, want)

@@ -168,3 +168,34 @@ def test_chain_engine_out_of_memory_exits_cleanly():
     ok = ctx.chains_solve(Z0, kind=capi.CHAIN_PLAIN, xtol=1e-8, solver=capi.SOLVER_DEVICE)
     assert np.array_equal(ok["z"], r["z"]) and np.array_equal(ok["nfev"], r["nfev"])
     ctx.close()
+
+
+def test_context_second_stream_is_created_once_and_left_alone():
+    """socp_ctx_aux_stream: the same stream on every call, not the context's launch stream; the lock-step engines use it while they
+    run and put the context back on its own stream; a cloned context has its own."""
+    from socp_amd import capi, sweep
+    ctx = capi.Context(capi.MODEL_GODDARD)
+    L = capi.lib()
+    L.socp_ctx_get_stream.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    main = C.c_void_p()
+    assert L.socp_ctx_get_stream(ctx.h, C.byref(main)) == 0
+    a, b = ctx.aux_stream(), ctx.aux_stream()
+    assert a == b and a is not None and a != main.value
+    ctx.set_params(sweep.GODDARD_PARAMS)
+    ctx.set_step_number(20)
+    ctx.set_variant(capi.VARIANT_LANE_FAST)
+    sweep.goddard_single_shooting_problem(ctx)
+    Z0 = sweep.goddard_starts(16, 1e-3)
+    for solver in (capi.SOLVER_HOST, capi.SOLVER_DEVICE):
+        r = ctx.chains_solve(Z0, kind=capi.CHAIN_PLAIN, xtol=1e-8, solver=solver)
+        assert np.all(r["info"] == 1)
+        now = C.c_void_p()
+        assert L.socp_ctx_get_stream(ctx.h, C.byref(now)) == 0 and now.value == main.value
+        assert ctx.aux_stream() == a
+    L.socp_ctx_clone.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+    twin = C.c_void_p()
+    assert L.socp_ctx_clone(ctx.h, 0, C.byref(twin)) == 0
+    st = C.c_void_p()
+    assert L.socp_ctx_aux_stream(twin, C.byref(st)) == 0 and st.value not in (None, a)
+    assert L.socp_ctx_destroy(twin) == 0
+    ctx.close()

@@ -11,6 +11,9 @@
 using namespace socp::devsolver;
 
 extern "C" {
+// the device solver's norm (its branch-free usual case and the general three-accumulator loop behind it)
+double sim_enorm(int n, const double *x, long stride) { return enorm(n, x, stride); }
+
 typedef int (*sim_fcn)(int n, const double *x, double *fvec);
 typedef int (*sim_jac)(int n, const double *x, const double *fvec, double *fjac_colmajor);
 
