@@ -153,3 +153,46 @@ def test_config5_sweep_at_256_starts(variant):
     alone = ctx.chains_solve(Z0[100:101], kind=capi.CHAIN_PLAIN, xtol=1e-9, speculate=0)
     assert alone["nfev"][0] == r["nfev"][100] and np.array_equal(alone["z"][0], r["z"][100])
     ctx.close()
+
+
+@pytest.mark.parametrize("variant", ["exact", "fast"])
+def test_full_batch_properties_that_need_no_oracle(variant):
+    """BASELINE's full size (13 107 starts x 15 rows = 196 605 trajectories of 10^4 RK4 steps: one bench step) is beyond what the CPU
+    oracle finishes in a test, so the batch is checked through properties that do not depend on its size:
+      * lanes are independent -- the rows of a shuffled batch are the shuffled rows, bit for bit (no lane reads a neighbour's data,
+        nothing depends on where in the grid a trajectory runs);
+      * composition -- 0 -> tf in 10^4 steps equals 0 -> tf/2 -> tf in 5000 + 5000 steps of the same dt (tf/2 and dt are exact
+        binary halves) to rounding (1e-10): the step loop carries no hidden state besides (t, X).  Not bit for bit, and rightly so: the
+        reference's loop accumulates t += dt (odeTools.cpp:136-145), 5000 additions of dt stop a rounding error short of tf/2 and
+        the loop then takes one more step of that size -- which the single call does not take in the middle;
+      * an interval that is empty or runs backwards leaves every state as it is, bit for bit -- the reference's `while (t < tf)`
+        never enters (odeTools.cpp:136);
+      * the rows sampled against the oracle in bench.py's parity leg are rows of this same launch."""
+    from socp_amd import capi, sweep
+    ctx = capi.Context(capi.MODEL_GODDARD)
+    ctx.set_params(sweep.GODDARD_PARAMS)
+    ctx.set_variant(capi.VARIANT_LANE_FAST if variant == "fast" else capi.VARIANT_LANE_EXACT)
+    P = 13107 if variant == "fast" else 4096                 # the reference-order flavour runs at 0.28 of the rate: a third of the batch
+    Z0 = sweep.goddard_starts(P, 1e-3)
+    z_rows = np.repeat(Z0, 15, axis=0)                       # 15 rows per start, as an FD batch has (here: identical copies + jitter)
+    rng = np.random.default_rng(3)
+    z_rows[:, 7:] *= 1.0 + 1e-6 * rng.uniform(-1, 1, (len(z_rows), 7))
+    B = len(z_rows)
+    tf = 0.2
+    t0 = np.zeros(B)
+    ctx.set_step_number(10000)
+    X1 = ctx.integrate_batch(t0, np.full(B, tf), z_rows)
+    assert np.all(np.isfinite(X1))
+    perm = rng.permutation(B)
+    X1p = ctx.integrate_batch(t0, np.full(B, tf), z_rows[perm])
+    assert np.array_equal(X1p, X1[perm])
+    ctx.set_step_number(5000)
+    Xh = ctx.integrate_batch(t0, np.full(B, tf / 2), z_rows)
+    X2 = ctx.integrate_batch(np.full(B, tf / 2), np.full(B, tf), Xh)
+    scale = np.max(np.abs(X1), axis=0)
+    assert np.max(np.abs(X2 - X1) / scale) <= 1e-10             # (observed 1e-12: one rounding-size step, carried through 5000 more)
+    ctx.set_step_number(10000)
+    Xb = ctx.integrate_batch(np.full(B, tf), t0, X1)
+    assert np.array_equal(Xb, X1)
+    assert np.array_equal(ctx.integrate_batch(np.full(B, tf), np.full(B, tf), X1), X1)
+    ctx.close()
