@@ -119,8 +119,8 @@ typedef struct socp_chain_options {
                                  means), SOCP_SOLVER_HOST, SOCP_SOLVER_DEVICE.  DEVICE: one workgroup per chain runs MINPACK's qrfac /
                                  qform / dogleg / r1updt / r1mpyq in HBM with the per-column operation order of the host code, so
                                  every iterate, nfev and info is the host solver's, bit for bit; Jacobians never cross PCIe.  AUTO
-                                 picks DEVICE where the host side is the bottleneck (P n^2 >= 1.6e6: 8192 chains of n = 14, 222 of
-                                 n = 85, 25 of n = 253) and the solver state fits HBM.  The device engine has no speculative FD rows
+                                 picks DEVICE where the host side is the bottleneck (P n^2 >= 1.6e6 and 20 P >= n: 8192 chains of n = 14,
+                                 222 of n = 85, 25 of n = 253, 42 of n = 832) and the solver state fits HBM.  The device engine has no speculative FD rows
                                  (they pay in small sweeps of small problems, which AUTO leaves on the host).  Environment
                                  SOCP_CHAINS_SOLVER=host|device overrides. */
 } socp_chain_options;

@@ -144,7 +144,11 @@ extern "C" int socp_chains_solve_ex(socp_ctx *ctx, int P, const socp_chain_optio
             // bottleneck from P n^2 ~ 1.6e6 up: 222 chains of n = 85, 25 of n = 253, 8192 of n = 14.  Measured at n = 14 (10^4
             // steps, 40-round budget): 8192 starts 0.53 -> 0.49 s, 65 536 starts 0.91 -> 0.70 s.  Below that the rounds are kernel
             // latency and the host engine's speculative FD rows save rounds (4096 starts: 65 rounds against 68).
-            solver = (n <= 2048 && (double)P * n * n >= 1.6e6) ? SOCP_SOLVER_DEVICE : SOCP_SOLVER_HOST;
+            // FEW LARGE problems stay on the host too (20 P >= n): a problem is one workgroup = one CU, so a handful of 832-unknown
+            // factorisations stream their matrices at the bandwidth of a handful of CUs (0.33-0.36 s for 1 ... 48 chains of n = 832)
+            // while the host gives each its share of 16 threads (0.04 s for one chain, 0.28 s for 32, 0.39 s for 48); measured
+            // crossovers: 44 chains at n = 832, 10 at n = 253 (scripts/probes/large_n_chains.py).
+            solver = (n <= 2048 && (double)P * n * n >= 1.6e6 && 20L * P >= n) ? SOCP_SOLVER_DEVICE : SOCP_SOLVER_HOST;
             if (solver == SOCP_SOLVER_DEVICE) {
                 size_t free_b = 0, total_b = 0;
                 int prev = -1;
@@ -204,7 +208,7 @@ extern "C" int socp_chains_solve_ex(socp_ctx *ctx, int P, const socp_chain_optio
     // which thread advances a chain
     socp::Pool workers(nthreads);
     auto parallel_for = [&](int count, auto &&body) {
-        if (nthreads <= 1 || count < 2 * nthreads) { for (int k = 0; k < count; k++) body(k); return; }
+        if (nthreads <= 1 || count < 2) { for (int k = 0; k < count; k++) body(k); return; }
         const int blocks = std::min(count, 8 * nthreads), per = (count + blocks - 1) / blocks;
         workers.run(blocks, [&](int b) { for (int k = b * per, e = std::min(count, (b + 1) * per); k < e; k++) body(k); });
     };
@@ -221,6 +225,10 @@ extern "C" int socp_chains_solve_ex(socp_ctx *ctx, int P, const socp_chain_optio
         c.eval_x.resize(n); c.slot_x.resize(n);
         if (kind != SOCP_CHAIN_PLAIN) { c.b = std::min(opt->step, 1.0); c.b_prec = 0; }
         blk.set(p, c.b);
+        // FEW LARGE problems (fewer chains than workers, n >= 192): the workers left over go INTO the solvers, for the O(n^3)
+        // factor work of a refresh (columns in SIMD lanes over a pool of their own, minpack.cpp; same numbers for any count) --
+        // 16 chains of n = 832 took 1.54 s one after the other on one thread each, 4 chains 0.39 s
+        if (c.solver && n >= 192 && P < nthreads) socp_hybr_set_threads(c.solver, std::max(1, nthreads / P));
         if (c.solver) socp_hybr_start(c.solver, c.committed.data(), nullptr);
     });
     auto cleanup = [&]() { for (Chain &c : ch) c.solver = nullptr; socp_hybr_pool_destroy(pool); pool = nullptr; };

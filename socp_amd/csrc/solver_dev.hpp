@@ -87,11 +87,17 @@ struct BlockExec {
     int tid, nt;
     __device__ BlockExec() : tid((int)threadIdx.x), nt((int)blockDim.x) {}
     __device__ void sync() const { __syncthreads(); }
+    // The first wavefront of the workgroup.  What every thread would compute alike from broadcast loads (a norm, the sum of a
+    // back-substitution step) is computed THERE and handed on through LDS: repeated by every wavefront it costs nothing extra only
+    // while each wavefront has a SIMD to itself -- with 14 wavefronts per problem (n = 832), or three workgroups sharing a CU,
+    // the copies take each other's issue slots and the chain runs 3-4 x slower.
+    __device__ bool leader() const { return tid < 64; }
 };
 #endif
 struct SerialExec {
     int tid = 0, nt = 1;
     SOCP_HD void sync() const {}
+    SOCP_HD bool leader() const { return true; }
 };
 
 // Development aid (-DSOCP_SOLVER_PROFILE, device only): thread 0 of every workgroup adds the clock ticks between marks to
@@ -423,8 +429,11 @@ SOCP_HD bool factor(const E &ex, int n, int ld, Work &w, Prof *pf = nullptr)
     ex.sync();
     // reflector 0 from column 0 as it stands, and every later column's dot product with it
     bool cur = false;
+    double *const shared = w.f[5];                           // shared[0]: a scalar from the leading wavefront to everybody
     {
-        double ajnorm = enorm(n, col);
+        if (ex.leader()) { const double nrm = enorm(n, col); if (ex.tid == 0) shared[0] = nrm; }
+        ex.sync();
+        double ajnorm = shared[0];
         if (ajnorm != 0 && col[0] < 0) ajnorm = -ajnorm;
         cur = ajnorm != 0;
         if (cur) {
@@ -459,7 +468,9 @@ SOCP_HD bool factor(const E &ex, int n, int ld, Work &w, Prof *pf = nullptr)
         ex.sync();
         SOCP_PF(9);
         if (c1 < n) {
-            double ajnorm = enorm(n - c1, col + c1);
+            if (ex.leader()) { const double nrm = enorm(n - c1, col + c1); if (ex.tid == 0) shared[0] = nrm; }
+            ex.sync();
+            double ajnorm = shared[0];
             if (ajnorm != 0 && col[c1] < 0) ajnorm = -ajnorm;
             next = ajnorm != 0;
             if (next) {
@@ -688,17 +699,19 @@ SOCP_HD void dogleg(const E &ex, int n, Work &w, double delta)
             row[i] = (i >= j + 2) ? rv * xl[i] : rv;
         }
         ex.sync();                                           // the row, qtb, and the x[j + 1] thread 0 stored before arriving here
-        double sum = 0.0;
-        if (j + 1 < n) sum += row[j + 1] * xl[j + 1];
-        sum = sum_run(row, j + 2, n, sum);
-        double temp = row[j];
-        if (temp == 0) {
-            long l = j;
-            for (int i = 0; i <= j; i++) { temp = max_of(temp, fabs(r[l])); l += n - i - 1; }
-            temp = kEpsMch * temp;
-            if (temp == 0) temp = kEpsMch;
+        if (ex.leader()) {                                   // (the other wavefronts go on to fetch the next row)
+            double sum = 0.0;
+            if (j + 1 < n) sum += row[j + 1] * xl[j + 1];
+            sum = sum_run(row, j + 2, n, sum);
+            double temp = row[j];
+            if (temp == 0) {
+                long l = j;
+                for (int i = 0; i <= j; i++) { temp = max_of(temp, fabs(r[l])); l += n - i - 1; }
+                temp = kEpsMch * temp;
+                if (temp == 0) temp = kEpsMch;
+            }
+            if (ex.tid == 0) xl[j] = (qtb[j] - sum) / temp;
         }
-        if (ex.tid == 0) xl[j] = (qtb[j] - sum) / temp;
     }
     ex.sync();
     SOCP_PAR_FOR(j, 0, n) sc[j] = diag[j] * xl[j];
