@@ -103,6 +103,10 @@ int socp_ctx_get_stream(const socp_ctx *ctx, void **hip_stream);
  * why the lock-step engines keep it instead of creating one per call -- and destroyed with the context.  Nothing is ever
  * enqueued on it by the context itself: the engines (socp_chains_solve, socp_multistart_solve) use it while they run. */
 int socp_ctx_aux_stream(socp_ctx *ctx, void **hip_stream);
+/* Pay now what a process otherwise pays inside its first large call: the context's second stream (above) and the start-up of the
+ * copy engines -- the first copy of more than 16 KB between pinned host memory and the device takes ~8 ms, once per process
+ * (measured: scripts/probes/first_copy.hip).  Optional; for callers whose first solve is latency-critical. */
+int socp_ctx_warm_up(socp_ctx *ctx);
 int socp_ctx_synchronize(socp_ctx *ctx);
 int socp_ctx_dims(const socp_ctx *ctx, int *dim, int *state_len, int *state_len_jac);
 int socp_ctx_control_dim(const socp_ctx *ctx);

@@ -80,7 +80,7 @@ def lib():
         L.socp_last_error.restype = C.c_char_p
         L.socp_last_error.argtypes = [_vp]
         L.socp_ctx_create.argtypes = [C.POINTER(_vp), C.c_int, C.c_int]
-        for name in ("socp_ctx_destroy", "socp_ctx_synchronize"):
+        for name in ("socp_ctx_destroy", "socp_ctx_synchronize", "socp_ctx_warm_up"):
             getattr(L, name).argtypes = [_vp]
         L.socp_ctx_set_params.argtypes = [_vp, _dp, C.c_int]
         L.socp_ctx_get_params.argtypes = [_vp, _dp, C.c_int]
@@ -200,6 +200,10 @@ class Context:
         st = C.c_void_p()
         self._chk(self.L.socp_ctx_aux_stream(self.h, C.byref(st)))
         return st.value
+
+    def warm_up(self):
+        """socp_ctx_warm_up: the process's one-time costs now (second stream, copy-engine start-up)."""
+        self._chk(self.L.socp_ctx_warm_up(self.h))
 
     def has_variational(self):
         return self.L.socp_ctx_has_variational(self.h) == 1

@@ -361,6 +361,29 @@ int socp_ctx_aux_stream(socp_ctx *c, void **hip_stream)
     return SOCP_OK;
 }
 
+int socp_ctx_warm_up(socp_ctx *c)
+{
+    if (!c) return SOCP_ERR_ARG;
+    void *aux = nullptr;
+    const int rc = socp_ctx_aux_stream(c, &aux);
+    if (rc != SOCP_OK) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t bytes = 256 * 1024;
+    void *h = nullptr, *d = nullptr;
+    HIP_TRY(c, hipHostMalloc(&h, bytes, hipHostMallocDefault));
+    hipError_t e = hipMalloc(&d, bytes);
+    if (e == hipSuccess) {
+        std::memset(h, 0, bytes);
+        e = hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        (void)hipFree(d);
+    }
+    (void)hipHostFree(h);
+    if (e != hipSuccess) return hip_fail(c, e, "socp_ctx_warm_up");
+    return SOCP_OK;
+}
+
 int socp_ctx_synchronize(socp_ctx *c)
 {
     if (!c) return SOCP_ERR_ARG;

@@ -181,10 +181,11 @@ def interceptor_config5_problem(ctx, M=21):
 
 def warm_up(ctx, args, solve_first):
     """What a process pays ONCE, kept out of the timed solve like the context and the problem set-up: the context's second stream
-    (~6 ms) and the first launch of every kernel the engine uses (code-object load, ~9 ms) -- through a solve of the first
-    --warmup starts (0: none; the timed call then includes both).  Returns the trajectory counter to subtract."""
-    ctx.aux_stream()
+    (~6 ms), the copy engines' start-up at the first pinned copy above 16 KB (~8 ms; both: socp_ctx_warm_up) and the first
+    launch of every kernel the engine uses (code-object load, ~9 ms) -- the last through a solve of the first --warmup starts
+    (0: no warm-up at all; the timed call then includes all three).  Returns the trajectory counter to subtract."""
     if args.warmup > 0:
+        ctx.warm_up()
         solve_first(min(args.warmup, args.starts))
     return ctx.counters()[0]
 
