@@ -472,7 +472,9 @@ def sweep_leg(torch, dist, capi, args, world, rank, local_rank, dev, use_dist, t
         stats.update(r["stats"])
         r["rounds"] = r["stats"]["rounds"]
         return r
-    # one small warm-up sweep (kernel modules, pinned buffers), untimed
+    # warm-up, untimed: what a process pays once (the context's second stream, the copy engines' start-up: socp_ctx_warm_up) and
+    # one small sweep (kernel modules)
+    ctx.warm_up()
     ctx.chains_solve(Z0[:64], kind=capi.CHAIN_PLAIN, xtol=1e-8, max_rounds=4)
     c0 = ctx.counters()[0]
     if use_dist:
