@@ -197,7 +197,15 @@ int socp_sweep_solve(const struct socp_ctx *proto, const int *devices, int ndev,
  * collective: gather(user, send, count, recv) must behave like an all-gather of `count` doubles per rank into
  * recv[world][count] -- ncclAllGather(send, recv, count, ncclDouble, comm, stream) + a stream synchronise, MPI_Allgather, or
  * a copy when world = 1 (INTEGRATION.md shows the RCCL form; this library does not link a communication library itself).
- * send / recv are HOST buffers unless gather_on_device != 0, in which case they are device buffers on ctx's device.
+ * send / recv are HOST buffers unless gather_on_device != 0, in which case they are device-visible buffers: memory of ctx's
+ * device, or -- when that staging cannot be allocated or written on some rank -- pinned host memory (hipHostMalloc), which a
+ * device collective reads and writes like device memory.
+ * The collective is entered EXACTLY ONCE by every rank whatever fails locally (the device switch, the staging allocation,
+ * the copy of the message, the solve): the failure travels in the rank's status slot and every rank returns it.  The one
+ * exception: a rank that can obtain neither device nor pinned memory for the message returns SOCP_ERR_HIP without having
+ * called gather -- the caller must then abort the communicator (ncclCommAbort / MPI_Abort), the other ranks are waiting.
+ * Argument errors (SOCP_ERR_ARG / SOCP_ERR_UNSUPPORTED before any work) are returned without the collective: the ranks of
+ * a job make the same call, so they all take that exit.
  * Outputs: the full tables of all P starts, on every rank. */
 typedef int (*socp_allgather_fn)(void *user, const double *send, long count, double *recv);
 int socp_sweep_solve_rank(struct socp_ctx *ctx, int rank, int world, int P, const socp_chain_options *opt, const double *Z0,

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -78,10 +79,25 @@ extern "C" int socp_sweep_solve(const socp_ctx *proto, const int *devices, int n
     return worst;
 }
 
+// Test hook: SOCP_SWEEP_INJECT = "<what>[:<rank>]" makes the staging of socp_sweep_solve_rank fail on that rank (all ranks without
+// ":<rank>") -- what = device_alloc (hipMalloc of the staging buffers), set_device (switching to the context's device), copy (the
+// host-to-device copy of the message).  tests/cpp/sweep_flow.cpp uses it to show that no failure path skips the collective.
+static bool injected(const char *what, int rank)
+{
+    const char *e = std::getenv("SOCP_SWEEP_INJECT");
+    if (!e) return false;
+    const size_t len = std::strlen(what);
+    if (std::strncmp(e, what, len) != 0) return false;
+    if (e[len] == '\0') return true;
+    return e[len] == ':' && std::atoi(e + len + 1) == rank;
+}
+
 extern "C" int socp_sweep_solve_rank(socp_ctx *ctx, int rank, int world, int P, const socp_chain_options *opt, const double *Z0,
                                      socp_allgather_fn gather, void *user, int gather_on_device, double *Zout, int *info, int *nfev_last,
                                      int *nfev_total, int *solves, double *fnorm, socp_chain_stats *stats)
 {
+    // argument errors are the same on every rank (the ranks of a job make the same call), so returning before the collective
+    // cannot strand anyone; everything that can fail on ONE rank is folded into that rank's message below
     if (!ctx || !opt || !gather || world < 1 || rank < 0 || rank >= world || P < 0 || (P > 0 && (!Z0 || !Zout || !info))) return SOCP_ERR_ARG;
     if (opt->kind != SOCP_CHAIN_PLAIN) return SOCP_ERR_UNSUPPORTED;          // continuation chains: socp_sweep_solve / socp_chains_solve per rank
     const int n = socp_problem_num_param(ctx);
@@ -93,35 +109,82 @@ extern "C" int socp_sweep_solve_rank(socp_ctx *ctx, int rank, int world, int P, 
     // a rank's message: kmax records + its own status, so that a rank whose solve failed still takes part in the collective
     // (the others would wait for it for ever) and EVERY rank returns the failure
     const long count = (long)kmax * W + 1;
+    const size_t send_bytes = sizeof(double) * (size_t)count, recv_bytes = send_bytes * (size_t)world;
+
+    // Staging for a collective on device buffers is set up BEFORE the solve, and a failure there is not a reason to stay away
+    // from the collective: the fallback is pinned host memory (hipHostMalloc: device-visible, so the caller's ncclAllGather /
+    // device copy works on it unchanged).  local = this rank's status; it travels in the message.
+    int local = SOCP_OK, prev = -1;
+    bool switched = false, pinned = false;
+    double *dsend = nullptr, *drecv = nullptr;
+    if (gather_on_device) {
+        bool dev_ok = !injected("set_device", rank) && hipGetDevice(&prev) == hipSuccess && hipSetDevice(socp_ctx_device(ctx)) == hipSuccess;
+        switched = dev_ok;
+        if (!dev_ok) local = SOCP_ERR_HIP;                                   // the solve may still run (the engine pins its own device); reported anyway
+        dev_ok = dev_ok && !injected("device_alloc", rank) && hipMalloc(&dsend, send_bytes) == hipSuccess && hipMalloc(&drecv, recv_bytes) == hipSuccess;
+        if (!dev_ok) {
+            (void)hipGetLastError();
+            if (dsend) { (void)hipFree(dsend); dsend = nullptr; }
+            if (drecv) { (void)hipFree(drecv); drecv = nullptr; }
+            pinned = hipHostMalloc(&dsend, send_bytes, hipHostMallocDefault) == hipSuccess && hipHostMalloc(&drecv, recv_bytes, hipHostMallocDefault) == hipSuccess;
+            if (!pinned) {
+                // neither device nor pinned memory: this rank has no buffer a device collective could read.  The one case in
+                // which it cannot enter the collective -- include/socp_solver.h tells the caller to abort the communicator.
+                if (dsend) (void)hipHostFree(dsend);
+                if (switched) (void)hipSetDevice(prev);
+                return SOCP_ERR_HIP;
+            }
+        }
+    }
+
     std::vector<double> z((size_t)mine * n), fn(mine, 0.0), send((size_t)count, 0.0), recv((size_t)world * count, 0.0);
     std::vector<int> inf(mine, 0), nl(mine, 0), nt(mine, 0), so(mine, 0);
     const int rc = socp_chains_solve(ctx, mine, opt, Z0 + (size_t)lo * n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, z.data(), inf.data(),
                                      nl.data(), nt.data(), so.data(), nullptr, nullptr, fn.data(), stats);
-    send[(size_t)count - 1] = rc;
+    if (rc != SOCP_OK) local = rc;
+    send[(size_t)count - 1] = local;
     for (int k = 0; k < mine && rc == SOCP_OK; k++) {
         double *rec = &send[(size_t)k * W];
         std::memcpy(rec, &z[(size_t)k * n], sizeof(double) * n);
         rec[n] = fn[k]; rec[n + 1] = inf[k]; rec[n + 2] = nl[k]; rec[n + 3] = nt[k]; rec[n + 4] = so[k];
     }
+
     int grc = 0;
+    bool read_ok = true;
     if (gather_on_device) {
-        int prev = -1;
-        if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(socp_ctx_device(ctx)) != hipSuccess) return SOCP_ERR_HIP;
-        double *dsend = nullptr, *drecv = nullptr;
-        bool ok = hipMalloc(&dsend, sizeof(double) * count) == hipSuccess && hipMalloc(&drecv, sizeof(double) * count * world) == hipSuccess &&
-                  hipMemcpy(dsend, send.data(), sizeof(double) * count, hipMemcpyHostToDevice) == hipSuccess;
-        // (an allocation failure here leaves the other ranks waiting: nothing this rank could still send)
-        if (ok) grc = gather(user, dsend, count, drecv);
-        ok = ok && grc == 0 && hipMemcpy(recv.data(), drecv, sizeof(double) * count * world, hipMemcpyDeviceToHost) == hipSuccess;
-        if (dsend) (void)hipFree(dsend);
-        if (drecv) (void)hipFree(drecv);
-        (void)hipSetDevice(prev);
-        if (!ok) return grc != 0 ? SOCP_ERR_ARG : SOCP_ERR_HIP;
+        const double *src = dsend;
+        double *hs = nullptr;
+        if (pinned) {
+            std::memcpy(dsend, send.data(), send_bytes);
+        } else if (injected("copy", rank) || hipMemcpy(dsend, send.data(), send_bytes, hipMemcpyHostToDevice) != hipSuccess) {
+            // the message did not reach the device buffer: send it from pinned memory instead (the receive side stays where it is)
+            (void)hipGetLastError();
+            if (hipHostMalloc(&hs, send_bytes, hipHostMallocDefault) == hipSuccess) {
+                std::memcpy(hs, send.data(), send_bytes);
+                src = hs;
+            } else {
+                // no pinned memory either: this rank's table is lost; say so in the status slot (8 bytes) if that much still goes through
+                local = SOCP_ERR_HIP;
+                const double st = local;
+                (void)hipMemcpy(dsend + (count - 1), &st, sizeof(double), hipMemcpyHostToDevice);
+            }
+        }
+        grc = gather(user, src, count, drecv);
+        if (hs) (void)hipHostFree(hs);
+        if (grc == 0) {
+            if (pinned) std::memcpy(recv.data(), drecv, recv_bytes);
+            else read_ok = hipMemcpy(recv.data(), drecv, recv_bytes, hipMemcpyDeviceToHost) == hipSuccess;
+        }
+        if (pinned) { if (dsend) (void)hipHostFree(dsend); (void)hipHostFree(drecv); }
+        else { if (dsend) (void)hipFree(dsend); (void)hipFree(drecv); }
+        if (switched) (void)hipSetDevice(prev);
     } else {
         grc = gather(user, send.data(), count, recv.data());
-        if (grc != 0) return SOCP_ERR_ARG;
     }
-    if (rc != SOCP_OK) return rc;
+    // from here on the collective is behind every rank: returning can no longer strand anyone
+    if (grc != 0) return SOCP_ERR_ARG;
+    if (!read_ok) return SOCP_ERR_HIP;
+    if (local != SOCP_OK) return local;
     for (int r = 0; r < world; r++) {
         const int theirs = (int)recv[(size_t)(r + 1) * count - 1];
         if (theirs != SOCP_OK) return theirs;                                 // another rank failed: no table to report

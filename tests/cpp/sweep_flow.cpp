@@ -7,6 +7,8 @@
 //   sweep_flow ranks   <world> <starts.bin> <P> <rk4_steps>    socp_sweep_solve_rank: `world` ranks emulated by threads that share
 //                                                               device 0, gathering through a user collective (here: shared memory
 //                                                               + a barrier; a real job passes ncclAllGather / MPI_Allgather)
+//                                                               SOCP_SWEEP_INJECT=device_alloc|set_device|copy[:rank] makes that step of the
+//                                                               device staging fail (csrc/sweep.cpp): stderr carries "rank_rc <r> <code>"
 // Problem: Goddard single shooting, n = 14 (BASELINE configs 2 / 4), throughput flavour.  starts.bin: P x 14 doubles.
 // Prints one JSON line: {"n": 14, "z": [[...]], "info": [...], "nfev": [...], "fnorm": [...], "wall_ms": ..., "trajectories": ...}
 #include <condition_variable>
@@ -23,7 +25,7 @@
 
 #include <dlfcn.h>
 // device-buffer form of the collective (what an RCCL job passes).  The program links no HIP itself: hipMemcpy is taken from the
-// runtime libsocp_hip.so has already loaded.  kind: 1 = host to device, 2 = device to host
+// runtime libsocp_hip.so has already loaded.  kind: 1 = host to device, 2 = device to host, 4 = decided from the addresses
 typedef int (*hip_memcpy_fn)(void *dst, const void *src, size_t bytes, int kind);
 static int hipMemcpy(void *dst, const void *src, size_t bytes, int kind)
 {
@@ -79,9 +81,9 @@ static int thread_allgather_dev(void *user, const double *send, long count, doub
 {
     RankGather *rg = static_cast<RankGather *>(user);
     std::vector<double> hs(count), hr((size_t)count * rg->g->world);
-    if (hipMemcpy(hs.data(), send, sizeof(double) * count, 2) != 0) return 1;
+    if (hipMemcpy(hs.data(), send, sizeof(double) * count, 4) != 0) return 1;      // 4 = by address: the buffers may be pinned host memory
     if (thread_allgather(user, hs.data(), count, hr.data()) != 0) return 1;
-    return hipMemcpy(recv, hr.data(), sizeof(double) * hr.size(), 1) != 0;
+    return hipMemcpy(recv, hr.data(), sizeof(double) * hr.size(), 4) != 0;
 }
 
 int main(int argc, char **argv)
@@ -142,8 +144,9 @@ int main(int argc, char **argv)
                 socp_ctx_destroy(c);
             });
         for (std::thread &t : th) t.join();
-        for (int r = 0; r < count; r++) {
-            if (rcs[r] != SOCP_OK) rc = rcs[r];
+        for (int r = 0; r < count; r++) std::fprintf(stderr, "rank_rc %d %d\n", r, rcs[r]);
+        for (int r = 0; r < count && rc == SOCP_OK; r++) if (rcs[r] != SOCP_OK) rc = rcs[r];
+        for (int r = 0; r < count && rc == SOCP_OK; r++) {
             // every rank must hold the same full table
             if (Zr[r] != Zr[0] || Ir[r] != Ir[0] || Nr[r] != Nr[0] || Fr[r] != Fr[0]) { std::fprintf(stderr, "rank %d holds a different table\n", r); return 4; }
         }
