@@ -30,8 +30,17 @@ Objects in the JSON line beside the contract's fields (N = 1; `--lean` drops the
                   timed here) and compared with what the two flavours left in HBM: max relative error, bitwise flag.
   single_problem  ONE problem (15 trajectories) per launch: the latency-bound case, stated not hidden.
   north_star_128  north_star's target size: Goddard, M = 9 segments, n = 128 unknowns: one FD Jacobian (1152 trajectories
-                  of 1e4 steps as the reference integrates them; fewer with the segment dedup), ms, trajectories/s and the
+                  of 1e4 steps as the reference integrates them; fewer with the segment dedup), ms, the reference's
+                  trajectory count over that time (reference_trajectories_per_s: a time-to-same-Jacobian rate) and its
                   ratio to cpu_baseline (B1) -- north_star asks for >= 10x.
+  sweep, sweep_large, sweep_xl   STRONG scaling: fixed totals of 65 536 / 524 288 / 4 194 304 single-shooting starts (BASELINE
+                  configs[3] class: full Newton solves in lock-step, 1e4 RK4 steps, 40-round budget) sharded over the ranks;
+                  wall time barrier to barrier, max over ranks.  A sweep's wall time is rounds x max(one trajectory latency,
+                  the block's trajectories / the kernel rate): only a block of >= ~0.5 M starts is throughput-bound, so only
+                  sweep_xl (524 288 per rank at N = 8) CAN scale near-linearly to 8 GPUs; the two smaller legs flatten at the
+                  latency floor.  At N = 1 every leg carries `predicted` (wall / speedup / efficiency at 2, 4, 8 GPUs read off
+                  this run's own one-GPU curve, `sweep_curve_one_gpu`); at N > 1 `expected` (from the curve recorded under
+                  profiles/) and measured_over_expected.
   cpu_baseline    B1: the reference's own model::ComputeTraj (oracle/_ref, kind "reference") or the C oracle (kind
                   "port") on this box's host cores, bounded sample.  cpu_baseline.b0 = "as shipped": the reference's
                   shooting.cpp + its per-call std::threads, bound to this library's hybrd (oracle/_ref/link), one
@@ -49,7 +58,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FLOP_PER_TRAJ = 1.17e7        # ~250 FP64 ops / RHS x 4 + 168 (RK4 combine), x 1e4 steps
+FLOP_PER_RK4_STEP = 1170.0    # ~250 FP64 ops / RHS x 4 + 168 (RK4 combine); x 1e4 steps = 1.17e7 per trajectory
 N_UNKNOWN = 14
 ROWS = N_UNKNOWN + 1          # residual rows (= trajectories, M = 1) per start and step
 BYTES_PER_TRAJ = 16 * N_UNKNOWN   # read z (8n) + write F (8n) per residual evaluation
@@ -96,11 +105,17 @@ def parse_args(argv=None):
                     help="the `sweep_large` leg: the same sweep with this many starts in total (default 8 x --sweep-starts): enough "
                          "that one GPU is throughput-bound, so the strong-scaling curve is not flattened by the per-round trajectory "
                          "latency the 65 536-start leg runs into; 0 skips it")
+    ap.add_argument("--sweep-xl-starts", type=int, default=None,
+                    help="the `sweep_xl` leg: the same sweep with this many starts in total (default 64 x --sweep-starts = 4 194 304): "
+                         "a rank's share at N = 8 is still 524 288 starts, i.e. throughput-bound -- the leg on which near-linear strong "
+                         "scaling to 8 GPUs can show at all; 0 skips it")
     args = ap.parse_args(argv)
     if args.sweep_starts is None:
         args.sweep_starts = 0 if args.lean else 65536
     if args.sweep_large_starts is None:
         args.sweep_large_starts = 0 if args.lean else 8 * args.sweep_starts
+    if args.sweep_xl_starts is None:
+        args.sweep_xl_starts = 0 if args.lean else 64 * args.sweep_starts
     return args
 
 
@@ -265,10 +280,11 @@ def cpu_baseline(steps_rk4, Z, target_seconds):
         P = len(cores)
         count, runs = best_of_3(P, 0.7 * target_seconds)
         count1, runs1 = best_of_3(1, 0.3 * target_seconds)
-        return {"value": max(runs), "unit": "trajectories/s", "cores": P, "kind": "reference", "per_core": max(runs) / P,
+        return {"value": max(runs), "median": float(np.median(runs)), "unit": "trajectories/s", "cores": P, "kind": "reference", "per_core": max(runs) / P,
                 "pinned": True, "cpu_model": model, "cpu_quota": quota, "logical_cpus_allowed": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
                 "samples": runs,
-                "p1": {"value": max(runs1), "cores": 1, "samples": runs1, "trajectories_per_sample": count1},
+                "p1": {"value": max(runs1), "median": float(np.median(runs1)), "cores": 1, "samples": runs1, "trajectories_per_sample": count1},
+                "cores_x_p1": P * max(runs1),
                 "parallel_efficiency": max(runs) / (P * max(runs1)),
                 "sample": "B1: best of 3 x %d trajectories (FD-batch rows of the first %d starts), %d RK4 steps each, reference "
                           "model::ComputeTraj, one goddard object per std::thread, %d threads pinned one per physical core (%s); "
@@ -283,8 +299,8 @@ def cpu_baseline(steps_rk4, Z, target_seconds):
     t = time.perf_counter()
     o.integrate_batch(0.0, TF, X0)
     sec = time.perf_counter() - t
-    return {"value": count / sec, "unit": "trajectories/s", "cores": 1, "kind": "port", "pinned": False, "cpu_model": model,
-            "p1": {"value": count / sec, "cores": 1},
+    return {"value": count / sec, "median": count / sec, "unit": "trajectories/s", "cores": 1, "kind": "port", "pinned": False, "cpu_model": model,
+            "p1": {"value": count / sec, "median": count / sec, "cores": 1}, "cores_x_p1": count / sec,
             "sample": "%d trajectories, %d RK4 steps each, C oracle single thread, %.1f s" % (count, steps_rk4, sec)}
 
 
@@ -360,8 +376,10 @@ def timed_region(torch, dist, ctx, stream, dev, cdev, world, P, d_Z, d_rows, d_J
     return float(t_max.item()), float(np.mean([a.elapsed_time(b) for a, b in evs]))
 
 
-def roofline_of(traj_per_launch, kernel_ms):
-    tflops = FLOP_PER_TRAJ * traj_per_launch / (kernel_ms * 1e-3) / 1e12
+def roofline_of(traj_per_launch, kernel_ms, rk4_steps):
+    """Algorithmic rates of one launch: flops scale with the step count of a trajectory (1170 per RK4 step), the bytes do not
+    (a trajectory reads z and writes F whatever its length)."""
+    tflops = FLOP_PER_RK4_STEP * rk4_steps * traj_per_launch / (kernel_ms * 1e-3) / 1e12
     gbs = BYTES_PER_TRAJ * traj_per_launch / (kernel_ms * 1e-3) / 1e9
     return tflops, gbs
 
@@ -439,16 +457,66 @@ def north_star_128(capi, device, rk4_steps, cpu_traj_per_s):
             res[key] = {"ms": 1e3 * sec, "trajectories_integrated": int((ctx.counters()[0] - c0) // reps), "finite": bool(np.isfinite(J).all())}
         best = min(res["full"]["ms"], res["dedup"]["ms"])
         res["jacobian_ms"] = best
-        res["trajectories_per_s"] = 128 * 9 / (best * 1e-3)          # the reference's count of integrations per Jacobian
+        # time-to-same-Jacobian rate: the REFERENCE's count of integrations per Jacobian (n x M = 1152) over this path's time for
+        # that Jacobian -- not this path's throughput (with the dedup it integrates 252 of them)
+        res["reference_trajectories_per_s"] = 128 * 9 / (best * 1e-3)
+        res["integrated_trajectories_per_s"] = res["dedup" if res["dedup"]["ms"] <= res["full"]["ms"] else "full"]["trajectories_integrated"] / (best * 1e-3)
         if cpu_traj_per_s:
-            res["x_over_cpu_baseline"] = res["trajectories_per_s"] / cpu_traj_per_s
+            res["x_over_cpu_baseline"] = res["reference_trajectories_per_s"] / cpu_traj_per_s
         out[tag] = res
         ctx.close()
     return out
 
 
+def predict_wall(curve, starts):
+    """Wall time of a `starts`-start sweep on ONE GPU read off a measured one-GPU curve [(starts, wall_s), ...]: log-log
+    interpolation between the measured sizes; below the smallest one its wall time (a sweep cannot take less than its rounds x one
+    trajectory latency, whatever its size), above the largest one proportional to the size (throughput-bound)."""
+    pts = sorted((float(a), float(b)) for a, b in curve if a > 0 and b > 0)
+    if not pts:
+        return None
+    if starts <= pts[0][0]:
+        return pts[0][1]
+    if starts >= pts[-1][0]:
+        return pts[-1][1] * starts / pts[-1][0]
+    for (a0, w0), (a1, w1) in zip(pts, pts[1:]):
+        if a0 <= starts <= a1:
+            f = (np.log(starts) - np.log(a0)) / (np.log(a1) - np.log(a0))
+            return float(np.exp(np.log(w0) + f * (np.log(w1) - np.log(w0))))
+    return None
+
+
+def predictions(curve, total, wall_1=None):
+    """What the strong-scaling leg of `total` starts should take on 2 / 4 / 8 GPUs if a rank's block of ceil(total / N) starts takes
+    what a sweep of that size takes on one GPU (blocks are independent; the gather is one small all_gather): the expectation the
+    measured SCALE curve is to be checked against."""
+    out = {}
+    for N in (2, 4, 8):
+        w = predict_wall(curve, -(-total // N))
+        if w is not None:
+            out[str(N)] = {"wall_s": w}
+            if wall_1:
+                out[str(N)]["speedup"] = wall_1 / w
+                out[str(N)]["efficiency"] = wall_1 / w / N
+    return out
+
+
+def recorded_sweep_curve(rk4_steps, max_rounds):
+    """The one-GPU sweep curve of the last profiled run (profiles/sweep_curve_latest.json, written from a bench line by
+    scripts/profile_bench.sh): what an N > 1 run -- which has no one-GPU leg of its own -- states as its expectation."""
+    path = os.path.join(ROOT, "profiles", "sweep_curve_latest.json")
+    try:
+        with open(path) as f:
+            c = json.load(f)
+        if c.get("rk4_steps") == rk4_steps and c.get("max_rounds") == max_rounds:
+            return [(int(a), float(b)) for a, b in c["curve"]], "profiles/sweep_curve_latest.json (RECORDED on one GPU: %s)" % c.get("source", "?")
+    except Exception:
+        pass
+    return None, None
+
+
 def sweep_leg(torch, dist, capi, args, world, rank, local_rank, dev, use_dist, total=None):
-    """BASELINE config 4 at N GPUs as STRONG scaling: a fixed total of --sweep-starts independent starts of the n = 14 single-shooting
+    """BASELINE config 4 at N GPUs as STRONG scaling: a fixed total of `total` independent starts of the n = 14 single-shooting
     problem (1e4 RK4 steps, full Newton solves in lock-step, throughput flavour, round budget --sweep-max-rounds), sharded in
     contiguous blocks (socp_amd/sweep.py), no data-path exchange, one all_gather of the result records.  Wall time = barrier to
     barrier, max over ranks.  Returned on rank 0."""
@@ -569,18 +637,22 @@ def main():
     else:
         recs = [rec.tolist()]
 
-    sweep_rec = sweep_large_rec = None
-    if args.sweep_starts > 0:
-        sweep_rec = sweep_leg(torch, dist, capi, args, world, rank, local_rank, dev, use_dist)
-    if args.sweep_large_starts > 0:
-        sweep_large_rec = sweep_leg(torch, dist, capi, args, world, rank, local_rank, dev, use_dist, total=args.sweep_large_starts)
+    # strong-scaling legs: fixed totals of starts sharded over the ranks.  At N = 1 (not --lean) one more, small sweep (an eighth
+    # of the `sweep` leg: what a rank of 8 gets of it) completes the one-GPU curve the predictions are read from.
+    legs = {}
+    leg_sizes = [("sweep", args.sweep_starts), ("sweep_large", args.sweep_large_starts), ("sweep_xl", args.sweep_xl_starts)]
+    if world == 1 and not args.lean and args.sweep_starts >= 8:
+        leg_sizes.insert(0, ("sweep_eighth", args.sweep_starts // 8))
+    for name, total in leg_sizes:
+        if total > 0 and args.sweep_starts > 0:
+            legs[name] = sweep_leg(torch, dist, capi, args, world, rank, local_rank, dev, use_dist, total=total)
 
     status = 0
     if rank == 0:
         ranks_seen = sorted(int(r[0]) for r in recs)
         total_traj = traj_per_step_rank * world * args.steps
         value = total_traj / elapsed_max
-        tflops, gbs = roofline_of(traj_per_step_rank, kernel_ms)
+        tflops, gbs = roofline_of(traj_per_step_rank, kernel_ms, args.rk4_steps)
         traffic, traffic_source = recorded_traffic(P, args.variant, args.rk4_steps)
         smooth = GODDARD_PARAMS[6] > 0
         # VGPR budget -> waves per SIMD the launcher may use: fast smooth law 156 VGPRs (3), fast general law 252-254 (2),
@@ -602,7 +674,8 @@ def main():
             "roofline": {"bound": "valu_fp64", "achieved": tflops, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                          "frac": tflops / PEAK_FP64_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "fdrows_lane_kernel", "kernel_ms": kernel_ms,
-                         "flop_per_trajectory": FLOP_PER_TRAJ,
+                         "flop_per_trajectory": FLOP_PER_RK4_STEP * args.rk4_steps, "flop_per_rk4_step": FLOP_PER_RK4_STEP,
+                         "traffic_measured_in_this_run": False,
                          "hbm": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                  "frac": gbs / PEAK_HBM_GBS, "bytes_per_trajectory": BYTES_PER_TRAJ}},
             # Newton-level rates: with M = 1 a residual evaluation is one trajectory, and a forward-difference
@@ -612,10 +685,30 @@ def main():
             "occupancy": {"waves_per_launch": waves, "waves_per_simd_cap": min(wpe_max, max(1, -(-waves // 1024))), "simds": 1024},
             "finite_jacobians": [int(r[1]) for r in recs],
         }
-        if sweep_rec is not None:
-            out["sweep"] = sweep_rec
-        if sweep_large_rec is not None:
-            out["sweep_large"] = sweep_large_rec
+        if legs:
+            if world == 1:
+                curve = sorted((r["total_starts"], r["wall_s"]) for r in legs.values())
+                source = "this run"
+                out["sweep_curve_one_gpu"] = {"curve": curve, "rk4_steps": args.rk4_steps, "max_rounds": args.sweep_max_rounds,
+                                              "model": "wall(N) = one-GPU wall of a sweep of ceil(total / N) starts: log-log interpolation of the "
+                                                       "measured sizes, flat below the smallest (rounds x one trajectory latency), "
+                                                       "proportional above the largest"}
+            else:
+                curve, source = recorded_sweep_curve(args.rk4_steps, args.sweep_max_rounds)
+            for name, r in legs.items():
+                if name == "sweep_eighth":
+                    r["note"] = "curve point only: the block a rank of 8 gets of the `sweep` leg"
+                    continue
+                if curve:
+                    if world == 1:
+                        r["predicted"] = predictions(curve, r["total_starts"], r["wall_s"])
+                    else:
+                        w = predict_wall(curve, r["starts_per_gpu"])
+                        w1 = predict_wall(curve, r["total_starts"])
+                        r["expected"] = {"wall_s": w, "one_gpu_wall_s": w1, "speedup": w1 / w if w and w1 else None,
+                                         "measured_over_expected": r["wall_s"] / w if w else None}
+                    r["prediction_source"] = source
+            out.update(legs)
         if ranks_seen != list(range(world)):
             sys.stderr.write("bench.py: records of ranks %s, expected 0..%d\n" % (ranks_seen, world - 1))
             status = 1
@@ -628,7 +721,7 @@ def main():
             d_rows2 = torch.empty_like(d_rows)
             k2 = max(1, min(args.steps, 5))
             e2, kms2 = timed_region(torch, dist, ctx2, stream, dev, cdev, 1, P, d_Z, d_rows2, d_J, k2, 1)
-            tf2, _ = roofline_of(traj_per_step_rank, kms2)
+            tf2, _ = roofline_of(traj_per_step_rank, kms2, args.rk4_steps)
             out[other] = {"value": traj_per_step_rank * k2 / e2, "unit": "trajectories/s", "steps": k2, "warmup": 1,
                           "ms_per_step": 1e3 * e2 / k2, "kernel_ms": kms2,
                           "roofline_frac": tf2 / PEAK_FP64_TFLOPS, "achieved_tflops": tf2,
@@ -664,9 +757,14 @@ def main():
             if b0:
                 out["cpu_baseline"]["b0"] = b0
             # the GPU figures as multiples of both CPU baselines (reported, not the target: the roofline fraction is)
-            ratios = {"headline_over_b1": value / out["cpu_baseline"]["value"]}
+            # B1's all-core figure swings with the host's other tenants (samples of one run differ up to 1.8 x); the per-core figure
+            # does not, so the ratio to cores x P1 -- a perfectly scaling CPU -- is the stable one
+            cb = out["cpu_baseline"]
+            ratios = {"headline_over_b1": value / cb["value"], "headline_over_b1_median": value / cb["median"],
+                      "headline_over_%dxP1" % cb["cores"]: value / cb["cores_x_p1"], "headline_over_16xP1": value / (16 * cb["p1"]["value"])}
             if "exact" in out:
-                ratios["exact_over_b1"] = out["exact"]["value"] / out["cpu_baseline"]["value"]
+                ratios["exact_over_b1"] = out["exact"]["value"] / cb["value"]
+                ratios["exact_over_16xP1"] = out["exact"]["value"] / (16 * cb["p1"]["value"])
             if b0:
                 ratios["headline_over_b0"] = value / b0["value"]
                 if "exact" in out:

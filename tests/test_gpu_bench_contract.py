@@ -33,7 +33,11 @@ def test_bench_line_contract():
     r = d["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source"):
         assert key in r, key
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] < 1.2
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] <= 1.0
+    # the algorithmic flops of a launch follow from the line itself, whatever --rk4-steps is
+    assert r["flop_per_trajectory"] == r["flop_per_rk4_step"] * d["config"]["rk4_steps"]
+    assert abs(r["achieved"] - r["flop_per_trajectory"] * per_step / (r["kernel_ms"] * 1e-3) / 1e12) <= 1e-9 * r["achieved"]
+    assert r["traffic_measured_in_this_run"] is False
     assert r["kernel_ms"] <= d["ms_per_step"] * 1.05                 # the kernel is (nearly all of) the step
     assert r["hbm"]["bound"] == "hbm" and r["hbm"]["peak"] == 8000.0
     c = d["cpu_baseline"]
@@ -57,6 +61,22 @@ def test_bench_line_contract():
     assert abs(sw["solves_per_s"] - 2048 / sw["wall_s"]) <= 1e-6 * sw["solves_per_s"] and sw["trajectories"] > 2048 * 15
     big = d["sweep_large"]
     assert big["total_starts"] == 8 * 2048 and big["scaling"] == "strong" and big["converged"] >= 8 * 2030
+    # the leg whose per-rank share at N = 8 equals the large leg's total, and the expectation for 2 / 4 / 8 GPUs read off this run's
+    # one-GPU curve (VERDICT r3 #1a): the eighth-size sweep is measured so that the smallest leg has a point to be read from
+    xl = d["sweep_xl"]
+    assert xl["total_starts"] == 64 * 2048 and xl["converged"] >= 64 * 2030
+    curve = d["sweep_curve_one_gpu"]["curve"]
+    assert [c[0] for c in curve] == [256, 2048, 8 * 2048, 64 * 2048]
+    for leg in (sw, big, xl):
+        pr = leg["predicted"]
+        assert set(pr) == {"2", "4", "8"} and pr["2"]["wall_s"] >= pr["4"]["wall_s"] >= pr["8"]["wall_s"] > 0
+        assert pr["8"]["speedup"] <= 8.0 + 1e-9 and leg["prediction_source"] == "this run"
+    assert abs(xl["predicted"]["8"]["wall_s"] - big["wall_s"]) <= 1e-9 * big["wall_s"]          # a rank's block of 8 IS the large leg
+    g = c["gpu_ratios"]
+    assert c["median"] <= c["value"] and c["p1"]["median"] <= c["p1"]["value"]
+    assert abs(g["headline_over_16xP1"] - d["value"] / (16 * c["p1"]["value"])) <= 1e-9 * g["headline_over_16xP1"]
+    assert "reference_trajectories_per_s" in ns["fast"] and "trajectories_per_s" not in ns["fast"]
+    assert ns["fast"]["integrated_trajectories_per_s"] <= ns["fast"]["reference_trajectories_per_s"]
     # CPU baseline as SURVEY 8d asks: one thread and all cores, pinned; the host is named
     assert c["p1"]["cores"] == 1 and c["p1"]["value"] > 0 and c["cores"] >= c["p1"]["cores"] and c["pinned"] in (True, False)
     assert isinstance(c["cpu_model"], str) and c["cpu_model"]
@@ -77,6 +97,9 @@ def test_gpus_2_really_runs_two_ranks():
     assert d["config"]["trajectories_per_step_per_gpu"] == 1024 * 15
     assert abs(d["value"] - 2 * 1024 * 15 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
     assert "cpu_baseline" not in d and "exact" not in d               # N = 1 extras only
+    # 1000-step trajectories: a tenth of the flops per trajectory, so the fraction stays below 1 whatever the step count
+    assert d["roofline"]["flop_per_trajectory"] == 1170.0 * 1000 and 0 < d["roofline"]["frac"] <= 1.0
+    assert d["sweep_xl"]["total_starts"] == 64 * 301 and "sweep_eighth" not in d
 
 
 def test_rccl_code_path_with_one_rank():
