@@ -93,6 +93,7 @@ int socp_ctx_set_integrator(socp_ctx *ctx, int kind, double tol);
 int socp_ctx_set_switching_times(socp_ctx *ctx, const double *sw, int nsw);  /* goddard.cpp:373-377 */
 int socp_ctx_get_switching_times(const socp_ctx *ctx, double *sw2);          /* the two values the control law reads */
 int socp_ctx_set_variant(socp_ctx *ctx, int variant);
+int socp_ctx_get_variant(const socp_ctx *ctx);      /* SOCP_VARIANT_* as set (AUTO = reference order) */
 /* enqueue on the caller's hipStream_t (NULL is the device's default stream); use_own != 0 switches
  * back to the context's private non-blocking stream */
 int socp_ctx_set_stream(socp_ctx *ctx, void *hip_stream, int use_own);

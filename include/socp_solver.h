@@ -69,6 +69,9 @@ int socp_hybr_njev(const socp_hybr *s);
 const double *socp_hybr_x(const socp_hybr *s);
 const double *socp_hybr_fvec(const socp_hybr *s);
 double socp_hybr_epsfcn(const socp_hybr *s);
+/* the trust-region radius, |diag x| and |F| of the current iterate: what MINPACK's convergence test reads -- info = 1 means
+ * delta <= xtol * xnorm (or |F| = 0), whatever |F| is */
+void socp_hybr_trust_region(const socp_hybr *s, double *delta, double *xnorm, double *fnorm);
 
 /* ---- lock-step multi-start = socp_chains_solve with SOCP_CHAIN_PLAIN (BASELINE config 4; the sequential continuation loops of
  * shooting.cpp:598-778 solve one problem at a time -- a sweep over P independent starts does not have to).
@@ -120,13 +123,21 @@ typedef struct socp_chain_options {
                                  qform / dogleg / r1updt / r1mpyq in HBM with the per-column operation order of the host code, so
                                  every iterate, nfev and info is the host solver's, bit for bit; Jacobians never cross PCIe.  AUTO
                                  picks DEVICE where the host side is the bottleneck (P n^2 >= 1.6e6 and 20 P >= n: 8192 chains of n = 14,
-                                 222 of n = 85, 25 of n = 253, 42 of n = 832) and the solver state fits HBM.  The device engine has no speculative FD rows
-                                 (they pay in small sweeps of small problems, which AUTO leaves on the host).  Environment
-                                 SOCP_CHAINS_SOLVER=host|device overrides. */
+                                 222 of n = 85, 25 of n = 253, 42 of n = 832) and the solver state fits HBM (if the device engine cannot
+                                 allocate it after all, AUTO runs the host engine; an explicit DEVICE returns SOCP_ERR_HIP).
+                                 SOCP_SOLVER_DEVICE_FAST: the device solvers with the Jacobian refresh (qrfac + qform, 70 % of the solver
+                                 time at n = 253) in its THROUGHPUT flavour -- blocked Householder, compact-WY panels of 16, trailing
+                                 updates on the FP64 matrix cores, free summation order (kernels_factor_fast.hip): iterates equal the
+                                 host solver's to rounding, NOT bit for bit; converged solutions within north_star's 1e-8.  Sizes
+                                 39 <= n <= 256, otherwise it is DEVICE.  AUTO picks it instead of DEVICE on a context whose arithmetic
+                                 flavour is the throughput one (SOCP_VARIANT_LANE_FAST: its trajectories differ from the reference
+                                 order's at rounding level already); on a reference-order context AUTO never does.
+                                 Environment SOCP_CHAINS_SOLVER=host|device|device_fast overrides. */
 } socp_chain_options;
 #define SOCP_SOLVER_AUTO   0
 #define SOCP_SOLVER_HOST   1
 #define SOCP_SOLVER_DEVICE 2
+#define SOCP_SOLVER_DEVICE_FAST 3
 #define SOCP_INFO_ROUND_LIMIT (-3)
 
 typedef struct socp_chain_stats {
@@ -211,6 +222,20 @@ typedef int (*socp_allgather_fn)(void *user, const double *send, long count, dou
 int socp_sweep_solve_rank(struct socp_ctx *ctx, int rank, int world, int P, const socp_chain_options *opt, const double *Z0,
                           socp_allgather_fn gather, void *user, int gather_on_device, double *Zout, int *info, int *nfev_last,
                           int *nfev_total, int *solves, double *fnorm, socp_chain_stats *stats);
+
+/* ---- the Jacobian refresh of the device solvers on its own: `count` QR factorisations of n x n matrices in MINPACK's convention
+ * (qrfac without pivoting: Householder vectors a_j / |a_j| + e_j, diag(R) = -|a_j| sign(a_jj); qform: Q = H_0 ... H_{n-1}; Q^T b),
+ * what hybrd does with every fresh Jacobian (call site shooting.cpp:803-826) -- for tests and for measuring the
+ * kernel.  flavour SOCP_FACTOR_EXACT: MINPACK's per-column operation order (bit-equal to the host solver's factors);
+ * SOCP_FACTOR_FAST: the blocked matrix-core form (39 <= n <= 256).  Host pointers; J[count][n * n] COLUMN-major (as the
+ * forward-difference kernels write Jacobians), b[count][n].  Outputs (any may be NULL): Q[count][n][n] row-major,
+ * R[count][n (n + 1) / 2] packed by rows (row i: diag, then (i, i + 1 .. n - 1)), qtb[count][n], rdiag[count][n],
+ * acnorm[count][n] (column norms of J), sing[count].  kernel_ms: mean time of the factor launch over `reps` >= 1 runs
+ * (the matrices are restored before each run, untimed). */
+#define SOCP_FACTOR_EXACT 0
+#define SOCP_FACTOR_FAST  1
+int socp_qr_factor_batch(int device, int n, int count, const double *J, const double *b, int flavour, int reps, double *Q, double *R,
+                         double *qtb, double *rdiag, double *acnorm, int *sing, double *kernel_ms);
 
 #ifdef __cplusplus
 }

@@ -34,7 +34,8 @@ _lib = None
 
 
 CHAIN_PLAIN, CHAIN_PARAM, CHAIN_DATA = 0, 1, 2
-SOLVER_AUTO, SOLVER_HOST, SOLVER_DEVICE = 0, 1, 2
+SOLVER_AUTO, SOLVER_HOST, SOLVER_DEVICE, SOLVER_DEVICE_FAST = 0, 1, 2, 3
+FACTOR_EXACT, FACTOR_FAST = 0, 1
 
 
 class ChainOptions(C.Structure):
@@ -142,8 +143,40 @@ def lib():
         for name in ("socp_hybr_x", "socp_hybr_fvec"):
             getattr(L, name).argtypes = [_vp]
             getattr(L, name).restype = _dp
+        L.socp_hybr_trust_region.argtypes = [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.socp_hybr_trust_region.restype = None
+        L.socp_qr_factor_batch.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _ip, C.POINTER(C.c_double)]
+        L.socp_ctx_get_variant.argtypes = [_vp]
         _lib = L
     return _lib
+
+
+def qr_factor_batch(J, b, flavour=FACTOR_FAST, reps=1, device=-1, outputs=True):
+    """socp_qr_factor_batch (include/socp_solver.h): J[count][n][n] as matrices J[k][i][j] = J_k(i, j), b[count][n].
+    Returns dict(Q[count][n][n], R[count][n][n] (upper triangular, unpacked), qtb, rdiag, acnorm, sing, kernel_ms)."""
+    L = lib()
+    J = _f64(J)
+    count, n = J.shape[0], J.shape[1]
+    Jcm = np.ascontiguousarray(np.transpose(J, (0, 2, 1)))                   # column-major per problem
+    b = _f64(b).reshape(count, n)
+    ms = C.c_double(0)
+    if not outputs:
+        rc = L.socp_qr_factor_batch(int(device), n, count, _d(Jcm), _d(b), int(flavour), int(reps), None, None, None, None, None, None, C.byref(ms))
+        if rc != OK:
+            raise RuntimeError("socp_qr_factor_batch: %d" % rc)
+        return {"kernel_ms": ms.value}
+    Q = np.empty((count, n, n))
+    Rp = np.empty((count, n * (n + 1) // 2))
+    qtb, rdiag, acnorm = np.empty((count, n)), np.empty((count, n)), np.empty((count, n))
+    sing = np.zeros(count, dtype=np.int32)
+    rc = L.socp_qr_factor_batch(int(device), n, count, _d(Jcm), _d(b), int(flavour), int(reps), _d(Q), _d(Rp), _d(qtb), _d(rdiag), _d(acnorm),
+                                sing.ctypes.data_as(_ip), C.byref(ms))
+    if rc != OK:
+        raise RuntimeError("socp_qr_factor_batch: %d" % rc)
+    R = np.zeros((count, n, n))
+    iu = np.triu_indices(n)
+    R[:, iu[0], iu[1]] = Rp                                                  # packed by rows = row-major order of the upper triangle
+    return {"Q": Q, "R": R, "qtb": qtb, "rdiag": rdiag, "acnorm": acnorm, "sing": sing, "kernel_ms": ms.value}
 
 
 def plugin_load(path):
@@ -237,6 +270,9 @@ class Context:
 
     def set_variant(self, v):
         self._chk(self.L.socp_ctx_set_variant(self.h, int(v)))
+
+    def get_variant(self):
+        return int(self.L.socp_ctx_get_variant(self.h))
 
     def set_stream(self, stream_ptr, use_own=False):
         """stream_ptr: hipStream_t as int (0 = the default stream); use_own=True: context's own stream."""
@@ -564,6 +600,13 @@ class HybrSolver:
     @property
     def njev(self):
         return self.L.socp_hybr_njev(self.h)
+
+    @property
+    def trust_region(self):
+        """(delta, |diag x|, |F|) of the current iterate."""
+        d, xn, fn = C.c_double(0), C.c_double(0), C.c_double(0)
+        self.L.socp_hybr_trust_region(self.h, C.byref(d), C.byref(xn), C.byref(fn))
+        return d.value, xn.value, fn.value
 
     @property
     def x(self):

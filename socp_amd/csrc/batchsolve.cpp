@@ -36,7 +36,12 @@
 int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt, const double *Z0, const double *params,
                              const double *goal, const double *time_prev, const double *x_prev, const double *time_goal,
                              const double *x_goal, double *Zout, int *info, int *nfev_last, int *nfev_total, int *njev_last,
-                             int *solves, double *b_reached, double *param_final, double *fnorm, socp_chain_stats *stats);
+                             int *solves, double *b_reached, double *param_final, double *fnorm, socp_chain_stats *stats, int fast_factor);
+// ... what it allocates on the device for P chains of this context's problem (one plan, shared with the allocation itself), whether the
+// throughput factorisation exists for size n, and the code with which it reports "could not allocate, nothing has run yet"
+double socp_chains_device_bytes(const socp_ctx *ctx, int P, const socp_chain_options *opt, bool per_chain_params, bool per_chain_bounds);
+bool socp_chains_fast_factor_applies(int n);
+constexpr int kDeviceEngineAllocFailed = -1000;
 
 namespace {
 
@@ -136,10 +141,12 @@ extern "C" int socp_chains_solve_ex(socp_ctx *ctx, int P, const socp_chain_optio
         int solver = opt->solver;
         if (const char *e = std::getenv("SOCP_CHAINS_SOLVER")) {
             if (std::strcmp(e, "device") == 0) solver = SOCP_SOLVER_DEVICE;
+            else if (std::strcmp(e, "device_fast") == 0) solver = SOCP_SOLVER_DEVICE_FAST;
             else if (std::strcmp(e, "host") == 0) solver = SOCP_SOLVER_HOST;
         }
-        if (solver != SOCP_SOLVER_AUTO && solver != SOCP_SOLVER_HOST && solver != SOCP_SOLVER_DEVICE) return SOCP_ERR_ARG;
-        if (solver == SOCP_SOLVER_AUTO) {
+        if (solver != SOCP_SOLVER_AUTO && solver != SOCP_SOLVER_HOST && solver != SOCP_SOLVER_DEVICE && solver != SOCP_SOLVER_DEVICE_FAST) return SOCP_ERR_ARG;
+        const bool automatic = solver == SOCP_SOLVER_AUTO;
+        if (automatic) {
             // The host side (P state machines advanced on <= 16 threads, P n^2 doubles over PCIe per Jacobian refresh) is the
             // bottleneck from P n^2 ~ 1.6e6 up: 222 chains of n = 85, 25 of n = 253, 8192 of n = 14.  Measured at n = 14 (10^4
             // steps, 40-round budget): 8192 starts 0.53 -> 0.49 s, 65 536 starts 0.91 -> 0.70 s.  Below that the rounds are kernel
@@ -150,18 +157,32 @@ extern "C" int socp_chains_solve_ex(socp_ctx *ctx, int P, const socp_chain_optio
             // crossovers: 44 chains at n = 832, 10 at n = 253 (scripts/probes/large_n_chains.py).
             solver = (n <= 2048 && (double)P * n * n >= 1.6e6 && 20L * P >= n) ? SOCP_SOLVER_DEVICE : SOCP_SOLVER_HOST;
             if (solver == SOCP_SOLVER_DEVICE) {
+                // does the device engine's state fit?  The figure is the engine's own allocation plan (an estimate of its
+                // own had drifted below what the arena really takes)
                 size_t free_b = 0, total_b = 0;
                 int prev = -1;
-                const double need = 8.0 * ((double)P * ((double)n * (n + 9) + 0.5 * n * (n + 1) + 14.0 * n) + std::min((double)P * n * n, 1.1e9));
+                const double need = socp_chains_device_bytes(ctx, P, opt, params != nullptr || kind == SOCP_CHAIN_PARAM,
+                                                             kind == SOCP_CHAIN_DATA || time_goal != nullptr || x_goal != nullptr);
                 if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(socp_ctx_device(ctx)) != hipSuccess ||
-                    hipMemGetInfo(&free_b, &total_b) != hipSuccess || need > 0.8 * (double)free_b)
+                    hipMemGetInfo(&free_b, &total_b) != hipSuccess || need > 0.9 * (double)free_b)
                     solver = SOCP_SOLVER_HOST;
                 if (prev >= 0) (void)hipSetDevice(prev);
             }
+            // a throughput-flavour context gets the throughput factorisation (its trajectories are rounding-level away from the
+            // reference order's already); a reference-order context keeps the bit-equal solver
+            if (solver == SOCP_SOLVER_DEVICE && socp_ctx_get_variant(ctx) == SOCP_VARIANT_LANE_FAST && socp_chains_fast_factor_applies(n))
+                solver = SOCP_SOLVER_DEVICE_FAST;
         }
-        if (solver == SOCP_SOLVER_DEVICE)
-            return socp_chains_solve_device(ctx, P, opt, Z0, params, goal, time_prev, x_prev, time_goal, x_goal, Zout, info, nfev_last, nfev_total,
-                                            njev_last, solves, b_reached, param_final, fnorm, stats);
+        if (solver == SOCP_SOLVER_DEVICE || solver == SOCP_SOLVER_DEVICE_FAST) {
+            const int fast = (solver == SOCP_SOLVER_DEVICE_FAST && socp_chains_fast_factor_applies(n)) ? 1 : 0;
+            const int rc = socp_chains_solve_device(ctx, P, opt, Z0, params, goal, time_prev, x_prev, time_goal, x_goal, Zout, info, nfev_last, nfev_total,
+                                                    njev_last, solves, b_reached, param_final, fnorm, stats, fast);
+            if (rc != kDeviceEngineAllocFailed) return rc;
+            // the arena did not fit after all (another process took the memory since the estimate): nothing has run.  AUTO made the
+            // choice, so AUTO takes the other engine; a caller who asked for the device solvers gets the error.
+            (void)hipGetLastError();
+            if (!automatic) return SOCP_ERR_HIP;
+        }
     }
 
     // every allocation, copy and stream below lives on the context's device, whatever the calling thread's current device

@@ -67,11 +67,48 @@ using Dev = Piece;
 
 }  // namespace
 
+constexpr int kDeviceEngineAllocFailed = -1000;      // to socp_chains_solve (batchsolve.cpp): the arenas did not fit, nothing has run
+
+namespace {
+// The device engine's allocation plan for P chains: per chain the solver workspace, its state, five index lists, six rows of n and
+// (per-chain parameters / boundary data) two staged copies of those; the Jacobians of a round in one buffer of at most 8 GiB.
+struct EnginePlan {
+    size_t ws_stride = 0, rowB = 0, jacB = 0, intsB = 0, parB = 0, timeB = 0, nodeB = 0;
+    int jlaunch = 1;
+    EnginePlan(int n, int P, int nodes, int S, int stride)
+    {
+        ws_stride = (size_t)socp::devsolver::ws_doubles(n, socp::devsolver::ld_for(n));
+        rowB = sizeof(double) * (size_t)n; jacB = rowB * n; intsB = sizeof(int) * (size_t)P;
+        parB = sizeof(double) * (size_t)stride * P; timeB = sizeof(double) * (size_t)nodes * P; nodeB = timeB * S;
+        // Jacobians of a round: one launch whenever they fit 8 GiB (batchsolve.cpp has the measurement), else passes
+        jlaunch = (int)std::max<size_t>(1, std::min<size_t>((size_t)P, ((size_t)8 << 30) / jacB));
+    }
+    double device_bytes(int P, bool pp_params, bool pp_bound) const
+    {
+        double b = (double)P * (sizeof(double) * (double)ws_stride + sizeof(State) + 6.0 * rowB) + 5.0 * intsB + (double)jacB * jlaunch;
+        if (pp_params) b += 2.0 * parB;
+        if (pp_bound) b += 2.0 * (timeB + nodeB);
+        return b + 64.0 * 256;                                               // every piece is rounded up to 256 B
+    }
+};
+}  // namespace
+
+double socp_chains_device_bytes(const socp_ctx *ctx, int P, const socp_chain_options *, bool per_chain_params, bool per_chain_bounds)
+{
+    const int n = socp_problem_num_param(ctx), nodes = socp_problem_num_nodes(ctx), nparams = socp_ctx_num_params(ctx);
+    int S = 0;
+    socp_ctx_dims(ctx, nullptr, &S, nullptr);
+    return EnginePlan(n, P, nodes, S, nparams + 2).device_bytes(P, per_chain_params, per_chain_bounds);
+}
+
+bool socp_chains_fast_factor_applies(int n) { return socp::devsolver::fast_factor_applies(n); }
+
 // Same contract as socp_chains_solve_ex (include/socp_solver.h); called from there when the device solvers are chosen.
+// fast_factor: the Jacobian refreshes go through the throughput factorisation (kernels_factor_fast.hip).
 int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt, const double *Z0, const double *params,
                              const double *goal, const double *time_prev, const double *x_prev, const double *time_goal,
                              const double *x_goal, double *Zout, int *info, int *nfev_last, int *nfev_total, int *njev_last,
-                             int *solves, double *b_reached, double *param_final, double *fnorm, socp_chain_stats *stats)
+                             int *solves, double *b_reached, double *param_final, double *fnorm, socp_chain_stats *stats, int fast_factor)
 {
     using clk = std::chrono::steady_clock;
     const clk::time_point t_begin = clk::now();
@@ -125,11 +162,11 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
     PoolDev pool;
     pool.cfg.n = n; pool.cfg.ld = socp::devsolver::ld_for(n); pool.cfg.maxfev = opt->maxfev; pool.cfg.mode = 1;
     pool.cfg.analytic = opt->analytic_jac ? 1 : 0; pool.cfg.xtol = opt->xtol; pool.cfg.epsfcn = opt->epsfcn; pool.cfg.factor = opt->factor;
-    pool.ws_stride = socp::devsolver::ws_doubles(n, pool.cfg.ld);
+    const EnginePlan plan_sizes(n, P, nodes, S, stride);
+    pool.ws_stride = (long)plan_sizes.ws_stride;
     pool.P = P;
-    const size_t rowB = sizeof(double) * n, jacB = rowB * n;
-    // Jacobians of a round: one launch whenever they fit 8 GiB (batchsolve.cpp has the measurement), else passes
-    const int jlaunch = (int)std::max<size_t>(1, std::min<size_t>((size_t)P, ((size_t)8 << 30) / jacB));
+    const size_t rowB = plan_sizes.rowB, jacB = plan_sizes.jacB;
+    const int jlaunch = plan_sizes.jlaunch;
 
     void *main_stream_v = nullptr;
     if (socp_ctx_synchronize(ctx) != SOCP_OK || socp_ctx_get_stream(ctx, &main_stream_v) != SOCP_OK) return SOCP_ERR_HIP;
@@ -139,7 +176,7 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
     Pinned hStates, hList, hFlags, hListF, hListJ, hX, hRes, hPF, hTF, hXF, hPJ, hTJ, hXJ;
     Arena dev_arena, host_arena;
     {
-        const size_t intsB = sizeof(int) * P, parB = sizeof(double) * stride * P, timeB = sizeof(double) * nodes * P, nodeB = timeB * S;
+        const size_t intsB = plan_sizes.intsB, parB = plan_sizes.parB, timeB = plan_sizes.timeB, nodeB = plan_sizes.nodeB;
         struct { Piece *piece; size_t bytes; bool host; } plan[] = {
             {&dWs, sizeof(double) * pool.ws_stride * P, false}, {&dStates, sizeof(State) * P, false}, {&dList, intsB, false},
             {&dFlags, intsB, false}, {&dListF, intsB, false}, {&dListJ, intsB, false}, {&dX, rowB * P, false}, {&dF, rowB * P, false},
@@ -161,7 +198,7 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
         fs = static_cast<hipStream_t>(aux);
         if (trace) std::fprintf(stderr, "[socp_chains/device] set-up: host tables %.2f ms, device arena (%.1f MB) %.2f ms, pinned arena (%.1f MB) %.2f ms, stream %.2f ms\n",
                                 t0, 1e-6 * dev_arena.cap, t1 - t0, 1e-6 * host_arena.cap, t2 - t1, ms_since(t_begin) - t2);
-        if (!ok) { (void)hipGetLastError(); return SOCP_ERR_HIP; }
+        if (!ok) { (void)hipGetLastError(); return (dev_arena.base && host_arena.base) ? SOCP_ERR_HIP : kDeviceEngineAllocFailed; }
         for (auto &e : plan) e.piece->bind(e.host ? host_arena : dev_arena);
     }
     pool.states = static_cast<State *>(dStates.p);
@@ -211,7 +248,8 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
             hip_ok(hipMemcpyAsync(dList.p, hList.p, sizeof(int) * count, hipMemcpyHostToDevice, main_stream));
             hip_ok(hipMemcpyAsync(dFlags.p, hFlags.p, sizeof(int) * count, hipMemcpyHostToDevice, main_stream));
             // the chains that have just received a Jacobian come first in the list (adv_jac of them) and go in their own launch
-            if (adv_jac > 0 && blocked_factor) hip_ok(socp::devsolver::launch_factor(main_stream, pool, dList.i(), adv_jac));
+            if (adv_jac > 0 && fast_factor) hip_ok(socp::devsolver::launch_factor_fast(main_stream, pool, dList.i(), adv_jac));
+            else if (adv_jac > 0 && blocked_factor) hip_ok(socp::devsolver::launch_factor(main_stream, pool, dList.i(), adv_jac));
             hip_ok(socp::devsolver::launch_advance(main_stream, pool, dList.i(), adv_jac, dFlags.i(), true));
             hip_ok(socp::devsolver::launch_advance(main_stream, pool, dList.i() + adv_jac, count - adv_jac, dFlags.i() + adv_jac, false));
             adv_jac = 0;
@@ -350,8 +388,9 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
                             std::chrono::duration<double, std::milli>(t_loop_end - t_loop_begin).count() - t_adv - t_eval - t_host, ms_since(t_loop_end));
     if (trace)
         std::fprintf(stderr, "[socp_chains/device] set-up %.1f ms, solver kernels + state read-back %.1f ms, evaluation launches %.1f ms, host chain logic %.1f ms, "
-                             "total %.1f ms; %lld rounds, %lld Jacobians, %lld solver restarts; %d threads per problem, %.1f MB of solver state\n",
+                             "total %.1f ms; %lld rounds, %lld Jacobians, %lld solver restarts; %d threads per problem, %s factorisation, %.1f MB of solver state\n",
                      t_setup, t_adv, t_eval, t_host, ms_since(t_begin), rounds, jac_launched, restarts, socp::devsolver::threads_for(n),
+                     fast_factor ? "matrix-core (throughput)" : "order-preserving",
                      1e-6 * sizeof(double) * pool.ws_stride * P);
     if (trace) {
         unsigned long long pf[16];
@@ -367,5 +406,91 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
         stats->rounds = rounds; stats->jacobians_launched = jac_launched; stats->jacobians_from_cache = 0;
         stats->speculative_rounds = 0; stats->restarts = restarts; stats->wall_ms = ms_since(t_begin);
     }
+    return rc;
+}
+
+// include/socp_solver.h: the Jacobian refresh alone, `count` problems at once
+extern "C" int socp_qr_factor_batch(int device, int n, int count, const double *J, const double *b, int flavour, int reps, double *Q, double *R,
+                                    double *qtb, double *rdiag, double *acnorm, int *sing, double *kernel_ms)
+{
+    using namespace socp::devsolver;
+    if (n < 1 || count < 0 || !J || !b || reps < 1 || (flavour != SOCP_FACTOR_EXACT && flavour != SOCP_FACTOR_FAST)) return SOCP_ERR_ARG;
+    if (flavour == SOCP_FACTOR_FAST && !fast_factor_applies(n)) return SOCP_ERR_UNSUPPORTED;
+    if (count == 0) return SOCP_OK;
+    struct DeviceGuard {
+        int prev = -1;
+        bool ok = false;
+        explicit DeviceGuard(int dev) { ok = hipGetDevice(&prev) == hipSuccess && (dev < 0 || hipSetDevice(dev) == hipSuccess); }
+        ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    } guard(device);
+    if (!guard.ok) return SOCP_ERR_HIP;
+    PoolDev pool;
+    pool.cfg.n = n; pool.cfg.ld = ld_for(n); pool.cfg.maxfev = 1; pool.cfg.mode = 1; pool.cfg.analytic = 0;
+    pool.cfg.xtol = 0; pool.cfg.epsfcn = 0; pool.cfg.factor = 1;
+    pool.ws_stride = ws_doubles(n, pool.cfg.ld);
+    pool.P = count;
+    const size_t nn = (size_t)n * n, wsB = sizeof(double) * (size_t)pool.ws_stride * count;
+    double *dJ = nullptr, *dB = nullptr;
+    int *dList = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    std::vector<int> list(count);
+    for (int k = 0; k < count; k++) list[k] = k;
+    int rc = SOCP_OK;
+    auto ok = [&](hipError_t e) { if (e != hipSuccess && rc == SOCP_OK) rc = SOCP_ERR_HIP; return e == hipSuccess; };
+    ok(hipMalloc(&pool.ws, wsB));
+    ok(hipMalloc(&pool.states, sizeof(State) * count));
+    ok(hipMalloc(&dJ, sizeof(double) * nn * count));
+    ok(hipMalloc(&dB, sizeof(double) * (size_t)n * count));
+    ok(hipMalloc(&dList, sizeof(int) * count));
+    ok(hipEventCreate(&e0));
+    ok(hipEventCreate(&e1));
+    if (rc == SOCP_OK) {
+        ok(hipMemset(pool.ws, 0, wsB));
+        ok(hipMemset(pool.states, 0, sizeof(State) * count));                 // eval_sel = 0: scatter_fvec writes fvec
+        ok(hipMemcpy(dJ, J, sizeof(double) * nn * count, hipMemcpyHostToDevice));
+        ok(hipMemcpy(dB, b, sizeof(double) * (size_t)n * count, hipMemcpyHostToDevice));
+        ok(hipMemcpy(dList, list.data(), sizeof(int) * count, hipMemcpyHostToDevice));
+    }
+    double total_ms = 0;
+    for (int rep = 0; rep < reps && rc == SOCP_OK; rep++) {
+        ok(launch_scatter_jac(nullptr, pool, dList, count, dJ));
+        ok(launch_scatter_fvec(nullptr, pool, dList, count, dB));
+        ok(hipEventRecord(e0, nullptr));
+        ok(flavour == SOCP_FACTOR_FAST ? launch_factor_fast(nullptr, pool, dList, count) : launch_factor_exact(nullptr, pool, dList, count));
+        ok(hipEventRecord(e1, nullptr));
+        ok(hipEventSynchronize(e1));
+        float ms = 0;
+        if (rc == SOCP_OK && ok(hipEventElapsedTime(&ms, e0, e1))) total_ms += ms;
+    }
+    if (kernel_ms) *kernel_ms = total_ms / reps;
+    if (rc == SOCP_OK && (Q || R || qtb || rdiag || acnorm || sing)) {
+        // the workspaces come back whole, in slices of at most 256 MB, and are taken apart here
+        const int per = (int)std::max<size_t>(1, ((size_t)256 << 20) / (sizeof(double) * (size_t)pool.ws_stride));
+        std::vector<double> h((size_t)pool.ws_stride * std::min(per, count));
+        std::vector<State> hs(count);
+        ok(hipMemcpy(hs.data(), pool.states, sizeof(State) * count, hipMemcpyDeviceToHost));
+        for (int k0 = 0; k0 < count && rc == SOCP_OK; k0 += per) {
+            const int kc = std::min(per, count - k0);
+            ok(hipMemcpy(h.data(), pool.ws + (size_t)k0 * pool.ws_stride, sizeof(double) * (size_t)pool.ws_stride * kc, hipMemcpyDeviceToHost));
+            for (int k = 0; k < kc && rc == SOCP_OK; k++) {
+                Work w(h.data() + (size_t)k * pool.ws_stride, n, pool.cfg.ld);
+                const size_t p = (size_t)(k0 + k);
+                if (Q) for (int i = 0; i < n; i++) std::memcpy(Q + p * nn + (size_t)i * n, w.A + (size_t)i * pool.cfg.ld, sizeof(double) * n);
+                if (R) std::memcpy(R + p * ((size_t)n * (n + 1) / 2), w.r, sizeof(double) * ((size_t)n * (n + 1) / 2));
+                if (qtb) std::memcpy(qtb + p * n, w.qtf, sizeof(double) * n);
+                if (rdiag) std::memcpy(rdiag + p * n, w.wa1, sizeof(double) * n);
+                if (acnorm) std::memcpy(acnorm + p * n, w.wa2, sizeof(double) * n);
+                if (sing) sing[p] = hs[p].sing;
+            }
+        }
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (dList) (void)hipFree(dList);
+    if (dB) (void)hipFree(dB);
+    if (dJ) (void)hipFree(dJ);
+    if (pool.states) (void)hipFree(pool.states);
+    if (pool.ws) (void)hipFree(pool.ws);
+    if (rc != SOCP_OK) (void)hipGetLastError();
     return rc;
 }

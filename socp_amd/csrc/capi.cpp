@@ -403,6 +403,7 @@ int socp_ctx_dims(const socp_ctx *c, int *dim, int *state_len, int *state_len_ja
 
 int socp_ctx_control_dim(const socp_ctx *c) { return c ? c->nu : SOCP_ERR_ARG; }
 int socp_ctx_device(const socp_ctx *c) { return c ? c->device : SOCP_ERR_ARG; }
+int socp_ctx_get_variant(const socp_ctx *c) { return c ? c->variant : SOCP_ERR_ARG; }
 int socp_ctx_model_id(const socp_ctx *c) { return c ? c->model_id : SOCP_ERR_ARG; }
 int socp_ctx_has_variational(const socp_ctx *c) { return c ? (has_var(c) ? 1 : 0) : SOCP_ERR_ARG; }
 

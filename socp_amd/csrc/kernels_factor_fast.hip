@@ -1,0 +1,463 @@
+// kernels_factor_fast.hip -- the Jacobian refresh of the device Powell solver in its THROUGHPUT flavour.
+//
+// What it replaces: solver_dev.hpp `factor` -- qrfac (no pivoting) + Q^T fvec + R + qform of MINPACK's hybrd as the reference
+// drives it (shooting.cpp:803-826) -- which keeps MINPACK's per-column operation order bit for bit and therefore
+// streams the trailing matrix twice per REFLECTOR: 2048 problems of n = 253 move 354 GB for 2.7 GB of matrices (62 ms).
+//
+// Here the same factorisation (same Householder vectors v_j = a_j / |a_j| + e_j, same signs: diag(R) = -|a_j| sign(a_jj), same
+// Q = H_0 H_1 ... H_{n-1}) is computed as a BLOCKED Householder QR with compact-WY panels of 16 reflectors, the trailing-matrix
+// update on the FP64 matrix cores (v_mfma_f64_16x16x4_f64), summation order free:
+//
+//   one workgroup (4 wavefronts) per problem; for every panel of 16 columns
+//     wave 0   factorises the panel in registers (a 16-column strip, <= 256 rows: lane = (row group g, column m), 4 rows per
+//              16-row chunk and lane), publishing V to LDS as it goes, then T of  H_j0 .. H_j0+15 = I - V T V^T  (larft recurrence
+//              on the Gram matrix V^T V, itself one MFMA pass)
+//     all      every later 16-column strip (and the strip that holds fvec, column n) goes through the panel ONCE:
+//                 W = V^T S (MFMA, K = rows)   Y = T^T W (4 MFMA)   S -= V Y (MFMA, K = 16)
+//              with the strip in registers in the MFMA C/D layout (row = 16 chunk + g + 4 reg, column = lane & 15).  Because a sum
+//              over K has no prescribed order here, the K slot of lane group g in step `reg` is simply DEFINED to be that row:
+//              the strip's own registers are the B operand of the first product and the accumulator of the last one -- no
+//              layout change, no LDS round trip; only the A operands (V, T) come from LDS, each read conflict-free.
+//   qform      Q = (I - V_0 T_0 V_0^T) ... (I - V_last T_last V_last^T) I accumulated backward over the panels (dorgqr's order):
+//              panel p touches rows and columns >= 16 p only, its own 16 columns start as identity columns in registers.
+//
+// A strip is read once and written once per PANEL: n^3 / 16 x 8 B ~ 8 MB per problem and phase at n = 253 (17 GB for 2048
+// problems) instead of 173 MB per problem.  Results differ from the order-preserving kernel at rounding level; the engine uses
+// this kernel only when asked for the throughput flavour (SOCP_SOLVER_DEVICE_FAST, or AUTO on a throughput-flavour context).
+// Sizes: 39 <= n <= 256 (fast_factor_applies: the strip of a panel must fit the registers of one wavefront); others keep `factor`.
+#include <algorithm>
+#include <atomic>
+
+#include "solver_launch.hpp"
+
+namespace socp {
+namespace devsolver {
+
+namespace {
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kLdT = 272;      // pitch (doubles) of the transposed, negated panel in LDS: 16 rows of up to 256 entries + padding
+
+__device__ __forceinline__ f64x4 mfma(double a, double b, f64x4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+
+// The lane coordinates re-defined where they are used.  Everything that depends on the lane alone (which rows and columns a lane
+// holds, on which side of a diagonal it sits: several hundred compares in the unrolled code below) is invariant in every loop of
+// the kernel; the compiler hoists all of it to the kernel's first lines, keeps the masks in scalar registers for the whole run,
+// runs out of them (sgpr_spill_count 670) and then out of vector registers.  A compare costs one instruction where it is needed.
+__device__ __forceinline__ int here(int x)
+{
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
+// the value lane `src` holds (src: a compile-time constant after unrolling), as a uniform
+__device__ __forceinline__ double from_lane(double x, int src)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
+    return __hiloint2double(hi, lo);
+}
+// sum over the four row groups of a column (lanes m, m + 16, m + 32, m + 48)
+__device__ __forceinline__ double sum_groups(double x)
+{
+    x += __shfl_xor(x, 16);
+    x += __shfl_xor(x, 32);
+    return x;
+}
+__device__ __forceinline__ double max_groups(double x)
+{
+    x = fmax(x, __shfl_xor(x, 16));
+    x = fmax(x, __shfl_xor(x, 32));
+    return x;
+}
+// LDS written by some lanes of this wavefront, read by others: the wave's LDS operations execute in order; keep the compiler
+// from moving the reads above the writes
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// A strip: 16 columns c0 .. c0 + 15, rows row0 .. row0 + 16 NCH - 1, in the C/D layout of v_mfma_f64_16x16x4_f64:
+// S[cc][reg] of lane (g = lane >> 4, m = lane & 15) = A(row0 + 16 cc + g + 4 reg, c0 + m).  Rows >= n and columns >= colmax read as 0.
+// One running pointer per lane, advanced by four rows per load (with the row index multiplied out per (chunk, register) the
+// compiler hoists 4 NCH row offsets x ld into scalar registers for the whole kernel and spills them), and no per-row lane masks
+// except in the one chunk that can be partly below the matrix (4 NCH hoisted exec masks were the other half of the spills):
+// chunks before the last one are whole, chunks after it are zero -- uniform branches.
+template <int NCH>
+__device__ __forceinline__ void strip_load(f64x4 (&S)[NCH], const double *__restrict__ A, int ld, int n, int row0, int nch, int c0, int colmax, int g, int m)
+{
+    g = here(g); m = here(m);
+    const int col = c0 + m;
+    const bool cok = col < colmax;
+    const double *p = A + (long)(row0 + g) * ld + col;
+    const long step = 4L * ld;
+#pragma unroll
+    for (int cc = 0; cc < NCH; cc++) {
+        if (cc + 1 < nch) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) { S[cc][r] = cok ? *p : 0.0; p += step; }
+        } else if (cc + 1 == nch) {
+            const int left = n - (row0 + 16 * cc + g);                       // rows of this lane's group still inside the matrix: 4 r < left
+#pragma unroll
+            for (int r = 0; r < 4; r++) { S[cc][r] = (cok && 4 * r < left) ? *p : 0.0; p += step; }
+        } else {
+            S[cc] = f64x4{0, 0, 0, 0};
+        }
+    }
+}
+template <int NCH>
+__device__ __forceinline__ void strip_store(const f64x4 (&S)[NCH], double *__restrict__ A, int ld, int n, int row0, int nch, int c0, int colmax, int g, int m)
+{
+    g = here(g); m = here(m);
+    const int col = c0 + m;
+    if (col >= colmax) return;
+    double *p = A + (long)(row0 + g) * ld + col;
+    const long step = 4L * ld;
+#pragma unroll
+    for (int cc = 0; cc < NCH; cc++) {
+        if (cc + 1 < nch) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) { *p = S[cc][r]; p += step; }
+        } else if (cc + 1 == nch) {
+            const int left = n - (row0 + 16 * cc + g);
+#pragma unroll
+            for (int r = 0; r < 4; r++) { if (4 * r < left) *p = S[cc][r]; p += step; }
+        }
+    }
+}
+
+// S <- (I - V X^T V^T) S for the panel in LDS: Vl[row][16] (row-major, rows relative to the panel's first row), Vt[k][kLdT] = -V
+// transposed, Xl[16][16] row-major (X = T applies H_last .. H_first, i.e. the panel's Q^T: qrfac; X = T^T applies the panel's Q: qform)
+// (the scheduler otherwise hoists every LDS read of a pass above the first MFMA -- 4 NCH more doubles per lane beside the strip's
+// 4 NCH -- and spills; a fence every kGroup chunks bounds what is in flight: the next group's operands while this group multiplies)
+constexpr int kGroup = 2;
+#define SOCP_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+template <int NCH>
+__device__ __forceinline__ void strip_apply(f64x4 (&S)[NCH], int nch, const double *Vl, const double *Vt, const double *Xl, int lane, int g, int m)
+{
+    lane = here(lane); g = lane >> 4; m = lane & 15;
+    f64x4 W = {0, 0, 0, 0};
+#pragma unroll
+    for (int cc = 0; cc < NCH; cc++) {
+        if (cc < nch) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) W = mfma(Vl[(16 * cc + 4 * r) * 16 + lane], S[cc][r], W);      // A: V(row of slot g, m); B: the strip itself
+        }
+        if (cc % kGroup == kGroup - 1) SOCP_SCHED_FENCE();
+    }
+    f64x4 Y = {0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 4; r++) Y = mfma(Xl[64 * r + lane], W[r], Y);                                   // A: X(g + 4 r, m) = X^T(m, k); B: W(k = g + 4 r, m)
+    SOCP_SCHED_FENCE();
+#pragma unroll
+    for (int cc = 0; cc < NCH; cc++) {
+        if (cc < nch) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) S[cc] = mfma(Vt[(g + 4 * r) * kLdT + 16 * cc + m], Y[r], S[cc]);   // A: -V(16 cc + m, k = g + 4 r); B: Y(k, m)
+        }
+        if (cc % kGroup == kGroup - 1) SOCP_SCHED_FENCE();
+    }
+}
+
+// The panel of columns j0 .. j0 + 15 (np of them are reflectors), rows j0 .. n - 1, factorised by ONE wavefront in registers.
+// Leaves: the strip in A (R above the diagonal, the vectors from the diagonal down, as MINPACK stores them), rdiag, V / -V^T / T
+// in LDS, T also in Tsave (row-major 16 x 16) for qform.
+template <int NCH>
+__device__ __forceinline__ void panel_factor(double *__restrict__ A, int ld, int n, int j0, int np, int nch, double *Vl, double *Vt, double *Tl, double *Gl,
+                             double *__restrict__ rdiag, double *__restrict__ Tsave, int lane, int g, int m)
+{
+    f64x4 S[NCH];
+    strip_load<NCH>(S, A, ld, n, j0, nch, j0, n + 1, g, m);                  // (column n = fvec rides along when it falls into this strip)
+    double tau_mine = 0.0;                                                   // lane t (t < 16) keeps tau_t
+    // a real loop over the panel's columns (unrolled 16 times the body exceeds what the compiler will unroll, and then every
+    // "constant" index below becomes a run-time register index, i.e. scratch): t is uniform, lanes and registers are SELECTED
+#pragma unroll 1
+    for (int t = 0; t < 16; t++) {
+        lane = here(lane); g = lane >> 4; m = lane & 15;
+        bool live = t < np;
+        double ajnorm = 0.0, ajj = 0.0;
+        if (live) {
+            // |column t| over the rows from the diagonal down (row_rel >= t); every lane does its own column, lane t's is wanted
+            double ss = 0.0, amax = 0.0;
+#pragma unroll
+            for (int cc = 0; cc < NCH; cc++) {
+                if (cc < nch) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const double x = (16 * cc + g + 4 * r >= t) ? S[cc][r] : 0.0;
+                        ss += x * x;
+                        amax = fmax(amax, fabs(x));
+                    }
+                }
+            }
+            ss = from_lane(sum_groups(ss), t);
+            if (ss != ss) {
+                ajnorm = ss;                                                 // a NaN in the column: handed on, as MINPACK's enorm does
+            } else if (!(ss > 1e-280 && ss < 1e280)) {
+                // outside the range in which a plain sum of squares is safe (or zero): scale by the largest entry
+                amax = from_lane(max_groups(amax), t);
+                if (amax > 0 && amax < INFINITY) {
+                    double s2 = 0.0;
+#pragma unroll
+                    for (int cc = 0; cc < NCH; cc++) {
+                        if (cc < nch) {
+#pragma unroll
+                            for (int r = 0; r < 4; r++) {
+                                const double x = (16 * cc + g + 4 * r >= t) ? S[cc][r] / amax : 0.0;
+                                s2 += x * x;
+                            }
+                        }
+                    }
+                    ajnorm = amax * sqrt(from_lane(sum_groups(s2), t));
+                } else {
+                    ajnorm = amax;                                           // a zero column (no reflector), or an infinity handed on
+                }
+            } else {
+                ajnorm = sqrt(ss);
+            }
+            // a(j, j): row_rel = t is chunk 0, g = t & 3, reg = t >> 2, of column t
+            const int rsel = t >> 2;
+            const double diag_reg = rsel == 0 ? S[0][0] : rsel == 1 ? S[0][1] : rsel == 2 ? S[0][2] : S[0][3];
+            ajj = from_lane(diag_reg, 16 * (t & 3) + t);
+            if (ajnorm != 0 && ajj < 0) ajnorm = -ajnorm;
+            if (lane == 0) rdiag[j0 + t] = -ajnorm;
+            live = ajnorm != 0;
+        }
+        double tau_t = 0.0;
+        if (live) {
+            const double vjj = ajj / ajnorm + 1.0;                           // in [1, 2]: ajnorm carries a(j, j)'s sign
+            tau_t = 1.0 / vjj;
+            if (m == t) {
+#pragma unroll
+                for (int cc = 0; cc < NCH; cc++) {
+                    if (cc < nch) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int rr = 16 * cc + g + 4 * r;
+                            if (rr >= t) S[cc][r] = S[cc][r] / ajnorm + (rr == t ? 1.0 : 0.0);
+                        }
+                    }
+                }
+            }
+        }
+        if (lane == t) tau_mine = tau_t;
+        // column t of V (zero above its diagonal; all zero for a skipped reflector or a column that is not one)
+        if (m == t) {
+#pragma unroll
+            for (int cc = 0; cc < NCH; cc++) {
+                if (cc < nch) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int rr = 16 * cc + g + 4 * r;
+                        const double v = (live && rr >= t) ? S[cc][r] : 0.0;
+                        Vl[rr * 16 + t] = v;
+                        Vt[t * kLdT + rr] = -v;
+                    }
+                }
+            }
+        }
+        wave_lds_fence();
+        if (live) {
+            // the later columns of the strip through reflector t:  a -= v (v . a) / v_t
+            double dot = 0.0;
+#pragma unroll
+            for (int cc = 0; cc < NCH; cc++) {
+                if (cc < nch) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) dot += Vl[(16 * cc + g + 4 * r) * 16 + t] * S[cc][r];
+                }
+                if (cc % kGroup == kGroup - 1) SOCP_SCHED_FENCE();
+            }
+            dot = sum_groups(dot);
+            const double coef = (m > t) ? dot * tau_t : 0.0;
+            wave_lds_fence();                                                // (re-read v below rather than hold 4 NCH more registers)
+#pragma unroll
+            for (int cc = 0; cc < NCH; cc++) {
+                if (cc < nch) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) S[cc][r] -= coef * Vl[(16 * cc + g + 4 * r) * 16 + t];
+                }
+                if (cc % kGroup == kGroup - 1) SOCP_SCHED_FENCE();
+            }
+        }
+    }
+    strip_store<NCH>(S, A, ld, n, j0, nch, j0, n + 1, g, m);
+    // G = V^T V on the matrix cores, then larft's recurrence: T(i, t) = -tau_t sum_{k = i}^{t - 1} T(i, k) G(k, t), T(t, t) = tau_t
+    lane = here(lane); g = lane >> 4; m = lane & 15;
+    f64x4 G = {0, 0, 0, 0};
+#pragma unroll
+    for (int cc = 0; cc < NCH; cc++) {
+        if (cc < nch) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const double v = Vl[(16 * cc + 4 * r) * 16 + lane];
+                G = mfma(v, v, G);
+            }
+        }
+        if (cc % kGroup == kGroup - 1) SOCP_SCHED_FENCE();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) Gl[(g + 4 * r) * 16 + m] = G[r];
+    wave_lds_fence();
+    {
+        const int i = here(lane) & 15;                                       // (every row group computes the same T; group 0 stores it)
+        double Trow[16];
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            const double tau_t = from_lane(tau_mine, t);
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < t; k++) acc += Trow[k] * Gl[k * 16 + t];      // (Trow[k] = 0 for k < i: T is upper triangular)
+            Trow[t] = (i < t) ? -tau_t * acc : (i == t ? tau_t : 0.0);
+            SOCP_SCHED_FENCE();
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int t = 0; t < 16; t++) { Tl[i * 16 + t] = Trow[t]; Tsave[i * 16 + t] = Trow[t]; }
+        }
+    }
+}
+
+// One workgroup of 256 threads per problem.  LDS (doubles): Vl[16 NCH][16] | Vt[16][kLdT] | Tl[256] | Gl[256]
+template <int NCH>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void factor_fast_kernel(Config c, State *states, double *ws, long ws_stride, const int *__restrict__ list, int count)
+{
+    extern __shared__ double lds[];
+    double *Vl = lds, *Vt = Vl + 16 * NCH * 16, *Tl = Vt + 16 * kLdT, *Gl = Tl + 256;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, m = lane & 15;
+    const int n = c.n, ld = c.ld;
+    for (int b = blockIdx.x; b < count; b += gridDim.x) {
+        const int p = list[b];
+        Work w(ws + (long)p * ws_stride, n, ld, lds);
+        double *A = w.A, *rdiag = w.wa1, *acnorm = w.wa2, *Tsave = w.V;
+        // ---- column norms of the Jacobian (scaled by the column's largest entry: no overflow / underflow), fvec into column n
+        for (int j = tid; j < n; j += 256) {
+            double ss = 0.0, amax = 0.0;
+            int i = 0;
+            for (; i + 8 <= n; i += 8) {
+                double x[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) x[q] = A[(long)(i + q) * ld + j];
+#pragma unroll
+                for (int q = 0; q < 8; q++) { ss += x[q] * x[q]; amax = fmax(amax, fabs(x[q])); }
+            }
+            for (; i < n; i++) { const double x = A[(long)i * ld + j]; ss += x * x; amax = fmax(amax, fabs(x)); }
+            double nrm = sqrt(ss);
+            if (ss == ss && !(ss > 1e-280 && ss < 1e280)) {
+                nrm = amax;                                                  // zero, or an infinity handed on
+                if (amax > 0 && amax < INFINITY) {
+                    double s2 = 0.0;
+                    for (int k = 0; k < n; k++) { const double x = A[(long)k * ld + j] / amax; s2 += x * x; }
+                    nrm = amax * sqrt(s2);
+                }
+            }
+            acnorm[j] = nrm;
+        }
+        for (int i = tid; i < n; i += 256) A[(long)i * ld + n] = w.fvec[i];
+        __syncthreads();
+        // ---- qrfac, panel by panel
+        const int npanels = (n + 15) >> 4;
+        for (int pi = 0; pi < npanels; pi++) {
+            const int j0 = 16 * pi, np = (n - j0 < 16) ? n - j0 : 16, nch = (n - j0 + 15) >> 4;
+            if (wave == 0) panel_factor<NCH>(A, ld, n, j0, np, nch, Vl, Vt, Tl, Gl, rdiag, Tsave + 256 * pi, lane, g, m);
+            __syncthreads();
+            for (int c0 = j0 + 16 + 16 * wave; c0 <= n; c0 += 64) {
+                f64x4 S[NCH];
+                strip_load<NCH>(S, A, ld, n, j0, nch, c0, n + 1, g, m);
+                strip_apply<NCH>(S, nch, Vl, Vt, Tl, lane, g, m);
+                strip_store<NCH>(S, A, ld, n, j0, nch, c0, n + 1, g, m);
+            }
+            __syncthreads();
+        }
+        // ---- Q^T fvec, R packed by rows (row i: rdiag[i], then A(i, i + 1 .. n - 1)), "singular"
+        for (int i = tid; i < n; i += 256) w.qtf[i] = A[(long)i * ld + n];
+        int zero = 0;
+        for (int i = wave; i < n; i += 4) {
+            const long off = row_off(n, i);
+            for (int k = i + lane; k < n; k += 64) w.r[off + (k - i)] = (k == i) ? rdiag[i] : A[(long)i * ld + k];
+        }
+        for (int j = tid; j < n; j += 256) zero |= (rdiag[j] == 0) ? 1 : 0;
+        const int sing = __syncthreads_or(zero);
+        // ---- qform: the panels backward, each applied to the rows and columns from its first one on
+        for (int pi = npanels - 1; pi >= 0; pi--) {
+            const int j0 = 16 * pi, np = (n - j0 < 16) ? n - j0 : 16, nch = (n - j0 + 15) >> 4;
+            for (int e = tid; e < nch * 256; e += 256) {
+                const int rr = e >> 4, t = e & 15, row = j0 + rr;
+                const double v = (rr >= t && t < np && row < n) ? A[(long)row * ld + j0 + t] : 0.0;
+                Vl[rr * 16 + t] = v;
+                Vt[t * kLdT + rr] = -v;
+            }
+            Tl[(tid & 15) * 16 + (tid >> 4)] = Tsave[256 * pi + tid];            // X = T^T
+            __syncthreads();
+            // the panel's own columns above its first row held R: zeros of Q now
+            for (int e = tid; e < j0 * 16; e += 256) { const int row = e >> 4, t = e & 15; if (t < np) A[(long)row * ld + j0 + t] = 0.0; }
+            for (int c0 = j0 + 16 * wave; c0 < n; c0 += 64) {
+                f64x4 S[NCH];
+                if (c0 == j0) {
+                    const int gi = here(g), mi = here(m);
+#pragma unroll
+                    for (int cc = 0; cc < NCH; cc++) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) S[cc][r] = (cc == 0 && gi + 4 * r == mi && mi < np) ? 1.0 : 0.0;
+                    }
+                } else {
+                    strip_load<NCH>(S, A, ld, n, j0, nch, c0, n, g, m);
+                }
+                strip_apply<NCH>(S, nch, Vl, Vt, Tl, lane, g, m);
+                strip_store<NCH>(S, A, ld, n, j0, nch, c0, n, g, m);
+            }
+            __syncthreads();
+        }
+        if (tid == 0) { states[p].sing = sing ? 1 : 0; states[p].pad = 1; }
+        __syncthreads();
+    }
+}
+
+template <auto Kernel>
+hipError_t raise_lds_limit_fast()
+{
+    static std::atomic<unsigned long long> raised{0};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 64 && ((raised.load(std::memory_order_acquire) >> dev) & 1ull)) return hipSuccess;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess && dev < 64) raised.fetch_or(1ull << dev, std::memory_order_release);
+    return e;
+}
+
+template <int NCH>
+hipError_t launch_nch(hipStream_t st, const PoolDev &pool, const int *d_list, int count)
+{
+    const size_t lds_bytes = sizeof(double) * (size_t)(16 * NCH * 16 + 16 * kLdT + 512);
+    if (lds_bytes > 65536) {
+        const hipError_t raised = raise_lds_limit_fast<factor_fast_kernel<NCH>>();
+        if (raised != hipSuccess) return raised;
+    }
+    hipLaunchKernelGGL(factor_fast_kernel<NCH>, dim3((unsigned)count), dim3(256), lds_bytes, st, pool.cfg, pool.states, pool.ws, pool.ws_stride, d_list, count);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// n <= 256: a panel's strip (n rows x 16 columns) lives in the registers of one wavefront; the T factors of the panels
+// (256 doubles each) are kept in the workspace's spare n (n + 1) / 2 doubles until qform, which they fit from n = 39 on
+// (n = 33 .. 38 excepted) -- below that the order-preserving kernel is fast anyway.
+bool fast_factor_applies(int n) { return n >= 1 && n <= 256 && (long)n * (n + 1) / 2 >= 256L * ((n + 15) / 16); }
+
+hipError_t launch_factor_fast(hipStream_t st, const PoolDev &pool, const int *d_list, int count)
+{
+    if (count <= 0) return hipSuccess;
+    const int n = pool.cfg.n;
+    if (!fast_factor_applies(n) || pool.cfg.ld < n + 1) return hipErrorInvalidValue;
+    if (n <= 64) return launch_nch<4>(st, pool, d_list, count);
+    if (n <= 128) return launch_nch<8>(st, pool, d_list, count);
+    return launch_nch<16>(st, pool, d_list, count);
+}
+
+}  // namespace devsolver
+}  // namespace socp

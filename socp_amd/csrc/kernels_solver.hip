@@ -61,6 +61,22 @@ __global__ __launch_bounds__(64) void factor_kernel(Config c, State *states, dou
     }
 }
 
+// The order-preserving factor work alone (what advance_kernel does with a fresh Jacobian), for socp_qr_factor_batch
+template <int MAXT>
+__global__ __launch_bounds__(MAXT) void factor_only_kernel(Config c, State *states, double *ws, long ws_stride, const int *__restrict__ list, int count)
+{
+    extern __shared__ double lds[];
+    BlockExec ex;
+    for (int b = blockIdx.x; b < count; b += gridDim.x) {
+        const int p = list[b];
+        Work w(ws + (long)p * ws_stride, c.n, c.ld, lds);
+        const bool sing = factor(ex, c.n, c.ld, w);
+        __syncthreads();
+        if (threadIdx.x == 0) { states[p].sing = sing ? 1 : 0; states[p].pad = 1; }
+        __syncthreads();
+    }
+}
+
 __global__ void gather_eval_kernel(Config c, const State *states, double *ws, long ws_stride, const int *__restrict__ list, double *__restrict__ dst)
 {
     const int p = list[blockIdx.x];
@@ -230,6 +246,30 @@ hipError_t launch_factor(hipStream_t st, const PoolDev &pool, const int *d_list,
         if (raised != hipSuccess) return raised;
     }
     hipLaunchKernelGGL(factor_kernel, dim3(count), dim3(64), lds_bytes, st, pool.cfg, pool.states, pool.ws, pool.ws_stride, d_list, count);
+    return hipGetLastError();
+}
+
+hipError_t launch_factor_exact(hipStream_t st, const PoolDev &pool, const int *d_list, int count)
+{
+    if (count <= 0) return hipSuccess;
+    const size_t lds_bytes = sizeof(double) * 8 * (size_t)pool.cfg.n;
+    if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
+    const int threads = threads_for(pool.cfg.n);
+#define SOCP_LAUNCH_FACTOR_ONLY(MAXT)                                                                                                     \
+    do {                                                                                                                                   \
+        if (lds_bytes > 65536) {                                                                                                           \
+            const hipError_t raised = raise_lds_limit<factor_only_kernel<MAXT>>();                                                         \
+            if (raised != hipSuccess) return raised;                                                                                       \
+        }                                                                                                                                  \
+        hipLaunchKernelGGL(factor_only_kernel<MAXT>, dim3((unsigned)count), dim3(threads), lds_bytes, st, pool.cfg, pool.states, pool.ws, \
+                           pool.ws_stride, d_list, count);                                                                                 \
+    } while (0)
+    if (threads <= 64) SOCP_LAUNCH_FACTOR_ONLY(64);
+    else if (threads <= 128) SOCP_LAUNCH_FACTOR_ONLY(128);
+    else if (threads <= 256) SOCP_LAUNCH_FACTOR_ONLY(256);
+    else if (threads <= 512) SOCP_LAUNCH_FACTOR_ONLY(512);
+    else SOCP_LAUNCH_FACTOR_ONLY(1024);
+#undef SOCP_LAUNCH_FACTOR_ONLY
     return hipGetLastError();
 }
 

@@ -1010,5 +1010,11 @@ int socp_hybr_njev(const socp_hybr *s) { return s->core.njev; }
 const double *socp_hybr_x(const socp_hybr *s) { return s->x; }
 const double *socp_hybr_fvec(const socp_hybr *s) { return s->fvec; }
 double socp_hybr_epsfcn(const socp_hybr *s) { return s->epsfcn; }
+void socp_hybr_trust_region(const socp_hybr *s, double *delta, double *xnorm, double *fnorm)
+{
+    if (delta) *delta = s->core.delta;
+    if (xnorm) *xnorm = s->core.xnorm;
+    if (fnorm) *fnorm = s->core.fnorm;
+}
 
 }  // extern "C"

@@ -28,6 +28,13 @@ hipError_t launch_advance(hipStream_t st, const PoolDev &pool, const int *d_list
 bool blocked_factor_applies(int n);
 hipError_t read_profile(unsigned long long out[16], bool reset);   // -DSOCP_SOLVER_PROFILE builds: per-phase clock totals
 hipError_t launch_factor(hipStream_t st, const PoolDev &pool, const int *d_list, int count);
+// the same refresh in the THROUGHPUT flavour (kernels_factor_fast.hip): blocked Householder QR, compact-WY panels of 16, trailing
+// updates on the FP64 matrix cores; results equal the order-preserving kernels' to rounding, not bit for bit.  A workgroup of four
+// wavefronts per problem; fast_factor_applies: the sizes it is built for (39 <= n <= 256)
+bool fast_factor_applies(int n);
+hipError_t launch_factor_fast(hipStream_t st, const PoolDev &pool, const int *d_list, int count);
+// the order-preserving factor work alone (solver_dev.hpp: factor), a thread per column: what socp_qr_factor_batch times beside it
+hipError_t launch_factor_exact(hipStream_t st, const PoolDev &pool, const int *d_list, int count);
 // dst[k][n] = the point problem list[k] asked to be evaluated (x, or the trial point)
 hipError_t launch_gather_eval(hipStream_t st, const PoolDev &pool, const int *d_list, int count, double *d_dst);
 // the residual of that evaluation back into the problem (fvec, or the trial residual)

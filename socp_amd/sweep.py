@@ -179,6 +179,47 @@ def interceptor_config5_problem(ctx, M=21):
     return n, np.concatenate([X[:M].ravel(), [tf]])
 
 
+def interceptor_config5_sweep(P, variant="fast", eps=1e-3, ode_tol=1e-8, fixed_step=False, device=0, xtol=1e-8):
+    """The config-5 solve sweep: a context with the n = 253 problem set and the adaptive integrator chosen, P starts around the
+    converged trajectory (node-0 costates perturbed by eps xi, SURVEY 8d's generator) and the keyword arguments of chains_solve.
+    Returns (ctx, Z0, kw)."""
+    from . import capi
+    ctx = capi.Context(capi.MODEL_INTERCEPTOR, device=device)
+    ctx.set_variant(capi.VARIANT_LANE_FAST if variant == "fast" else capi.VARIANT_LANE_EXACT)
+    n, z = interceptor_config5_problem(ctx)
+    if not fixed_step:
+        ctx.set_integrator(capi.INT_DOPRI5, ode_tol)
+    raw = mt19937_64(20250905, 6 * P)
+    xi = ((raw >> np.uint64(11)).astype(np.float64) * 2.0 ** -53 * 2.0 - 1.0).reshape(P, 6)
+    Z0 = np.tile(z, (P, 1))
+    Z0[:, 6:12] *= 1.0 + eps * xi
+    return ctx, Z0, dict(kind=capi.CHAIN_PLAIN, xtol=xtol)
+
+
+def goddard_kd_chains(ctx, P, eps=0.05, kd_goal=310.0, kd_spread=0.0):
+    """testGoddard's state before its KD continuation as P chains: M = 6, free tf, KD = 0, the converged no-drag unknowns
+    (tests/golden/goddard_flow.json) with node-0 costates perturbed by eps xi; chain p's goal = kd_goal (1 + kd_spread xi_p).
+    Sets the problem on ctx.  Returns (Z0, params, goals, index of KD in the parameter block)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gold = json.load(open(os.path.join(root, "tests", "golden", "goddard_flow.json")))
+    z_nd = np.array([g for g in gold["goddard_single_stage"] if g["stage"] == 2 and g["xtol"] == 1e-6][0]["init_z"])
+    goddard_multiple_shooting_problem(ctx, 6, tf=z_nd[-1])
+    xi = (goddard_starts(P, eps)[:, 7:] / PSTAR - 1.0) / eps              # the sweep's own uniform(-1, 1) draws
+    Z0 = np.tile(z_nd, (P, 1))
+    Z0[:, 7:14] *= 1.0 + eps * xi
+    params = np.tile(np.array(GODDARD_PARAMS), (P, 1))
+    params[:, 2] = 0.0
+    goals = kd_goal * (1.0 + kd_spread * xi[:, 0])
+    return Z0, params, goals, 2
+
+
+SOLVERS = {"auto": 0, "host": 1, "device": 2, "device_fast": 3}         # socp_chain_options.solver (include/socp_solver.h)
+SOLVER_HELP = ("socp_chain_options.solver (include/socp_solver.h has the rule): where the chains' hybrd state machines run.  auto: on the "
+               "device where the host side is the bottleneck (P n^2 >= 1.6e6 and 20 P >= n: 8192 starts of n = 14, 222 of n = 85, 25 of "
+               "n = 253) and the state fits HBM, with the matrix-core factorisation on a throughput-flavour context (39 <= n <= 256); "
+               "device: the bit-equal device solvers; device_fast: the matrix-core factorisation asked for explicitly")
+
+
 def warm_up(ctx, args, solve_first):
     """What a process pays ONCE, kept out of the timed solve like the context and the problem set-up: the context's second stream
     (~6 ms), the copy engines' start-up at the first pinned copy above 16 KB (~8 ms; both: socp_ctx_warm_up) and the first
@@ -191,16 +232,10 @@ def warm_up(ctx, args, solve_first):
 
 
 def interceptor_sweep(args, torch, dist, capi, world, rank, local_rank, dev, record_fd):
-    ctx = capi.Context(capi.MODEL_INTERCEPTOR, device=local_rank)
-    ctx.set_variant(capi.VARIANT_LANE_FAST if args.variant == "fast" else capi.VARIANT_LANE_EXACT)
-    n, z = interceptor_config5_problem(ctx)
-    if not args.fixed_step:
-        ctx.set_integrator(capi.INT_DOPRI5, args.ode_tol)
     eps = args.eps if args.eps is not None else 1e-3
-    raw = mt19937_64(20250905, 6 * args.starts)
-    xi = ((raw >> np.uint64(11)).astype(np.float64) * 2.0 ** -53 * 2.0 - 1.0).reshape(args.starts, 6)
-    Z0 = np.tile(z, (args.starts, 1))
-    Z0[:, 6:12] *= 1.0 + eps * xi
+    ctx, Z0, _kw = interceptor_config5_sweep(args.starts, variant=args.variant, eps=eps, ode_tol=args.ode_tol, fixed_step=args.fixed_step,
+                                             device=local_rank)
+    n = Z0.shape[1]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -208,7 +243,7 @@ def interceptor_sweep(args, torch, dist, capi, world, rank, local_rank, dev, rec
 
     def solve_block(Zb):
         r = ctx.chains_solve(Zb, kind=capi.CHAIN_PLAIN, xtol=args.xtol, speculate=args.speculate, max_rounds=args.max_rounds,
-                             solver={"auto": capi.SOLVER_AUTO, "host": capi.SOLVER_HOST, "device": capi.SOLVER_DEVICE}[args.solver])
+                             solver=SOLVERS[args.solver])
         stats.update(r["stats"])
         r["rounds"] = r["stats"]["rounds"]
         return r
@@ -271,8 +306,7 @@ def main():
     ap.add_argument("--speculate", type=int, default=-1, help="socp_chain_options.speculate: -1 auto, 0 never, 1 always")
     ap.add_argument("--warmup", type=int, default=8, help="starts of one untimed solve before the timed one (what a process pays once: the "
                     "context's second stream ~6 ms, first-launch code-object loads ~9 ms); 0: the timed call includes them")
-    ap.add_argument("--solver", choices=["auto", "host", "device"], default="auto", help="socp_chain_options.solver: where the chains' "
-                    "hybrd state machines run (auto: on the device from n >= 32 and P n^2 >= 2e6)")
+    ap.add_argument("--solver", choices=sorted(SOLVERS), default="auto", help=SOLVER_HELP)
     args = ap.parse_args()
 
     # stdout carries only the JSON record: RCCL prints a version banner to file descriptor 1 when a process group is created
@@ -305,18 +339,8 @@ def main():
     Z0 = goddard_starts(args.starts, eps)
     chain_kw = None
     if args.continuation == "kd":
-        # testGoddard's state before its KD continuation: M = 6, free tf, KD = 0, the converged no-drag unknowns
-        import json as _json
-        gold = _json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "goddard_flow.json")))
-        z_nd = np.array([g for g in gold["goddard_single_stage"] if g["stage"] == 2 and g["xtol"] == 1e-6][0]["init_z"])
         args.segments = 6
-        goddard_multiple_shooting_problem(ctx, 6, tf=z_nd[-1])
-        xi = (Z0[:, 7:] / PSTAR - 1.0) / eps                              # the sweep's own uniform(-1, 1) draws
-        Z0 = np.tile(z_nd, (args.starts, 1))
-        Z0[:, 7:14] *= 1.0 + eps * xi
-        params = np.tile(np.array(GODDARD_PARAMS), (args.starts, 1))
-        params[:, 2] = 0.0
-        goals = args.kd_goal * (1.0 + args.kd_spread * xi[:, 0])
+        Z0, params, goals, _kd = goddard_kd_chains(ctx, args.starts, eps, args.kd_goal, args.kd_spread)
         chain_kw = dict(kind=capi.CHAIN_PARAM, param_index=2, step=args.step, speculate=args.speculate)
     elif args.segments == 1:
         goddard_single_shooting_problem(ctx)
@@ -330,7 +354,7 @@ def main():
 
     stats = {}
 
-    solver = {"auto": capi.SOLVER_AUTO, "host": capi.SOLVER_HOST, "device": capi.SOLVER_DEVICE}[args.solver]
+    solver = SOLVERS[args.solver]
 
     def solve_block(Zb):
         lo, hi = shard(args.starts, rank, world)

@@ -97,10 +97,11 @@ def test_config4_at_4096_starts(built):
     assert ok.sum() >= 4080, (ok.sum(), np.unique(out["info"], return_counts=True))
     assert out["stats"]["rounds"] > 0 and out["stats"]["jacobians_from_cache"] + out["stats"]["jacobians_launched"] >= P
     # MINPACK reports info = 1 when the trust region has collapsed (delta <= xtol |x|), whatever |F| is: of the 4087 starts that
-    # end that way here, one does so with |F| = 4e-8 after 56 evaluations (the CPU path's rule, not a device matter).  The root
-    # comparison is made on the starts whose residual actually vanished.
+    # end that way here, one (start 4093) does so with |F| = 4e-8 after 56 evaluations.  The root comparison is made on the starts
+    # whose residual actually vanished; test_config4_outlier_start_is_minpacks_rule (below) shows WHY that start ends there.
     well = ok & (out["fnorm"] <= 1e-9)
     assert well.sum() >= 4080, well.sum()
+    assert (ok & ~well).sum() <= 2, np.where(ok & ~well)[0]
     err = np.max(np.abs(out["z"][well] - zg[None, :]), axis=1) / np.max(np.abs(zg))
     assert np.max(err) <= 1e-8, np.max(err)
     # 32 sampled chains: alone == in the batch of 4096
@@ -127,6 +128,71 @@ def test_config4_at_4096_starts(built):
     Fg = ctx.residual_batch(zs)
     assert np.max(np.abs(Fg - Fc)) <= 1e-8
     ctx.close()
+
+
+def test_config4_outlier_start_is_minpacks_rule(built):
+    """test_config4_at_4096_starts compares with the golden root only the starts whose residual vanished,
+    because ONE start of the throughput flavour (4093; scripts/probes/probe_c4_outliers.py -> profiles/r04_c4_outliers.json) ends
+    with info = 1 and |F| = 4e-8.  What that is, under test:
+      * it is MINPACK's own exit: the same start driven through the HOST solver (socp_hybr_*, the algorithm pinned to SciPy's
+        MINPACK bit for bit) with the throughput flavour's residuals reproduces the engine's result bit for bit, and at its exit
+        the trust region has collapsed -- delta <= xtol |diag x| (SURVEY App. A) -- while |F| is not zero: info = 1 by the rule;
+      * it is a matter of the rounding path, not of the device: the reference-order flavour on the GPU and the CPU path (oracle
+        residual + the same host solver) agree on this start BIT FOR BIT -- info 1, 38 evaluations, on the golden root;
+      * the throughput flavour itself reaches the root from where it stopped (restart: |F| < 1e-9, within 1e-8 of the golden)."""
+    from socp_amd import capi, sweep
+    from oracle import oracle as orc
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "c2_root.json")))
+    zg = np.array(gold["z"])
+    p, xtol = 4093, 1e-12
+    Z0 = sweep.goddard_starts(4096, 1e-3)
+
+    def ctx_of(variant):
+        c = capi.Context(capi.MODEL_GODDARD)
+        c.set_params(sweep.GODDARD_PARAMS)
+        c.set_step_number(10000)
+        c.set_variant(variant)
+        assert sweep.goddard_single_shooting_problem(c) == 14
+        return c
+
+    # -- throughput flavour: engine result, then the same start through the host state machine with the trust region read out
+    fast = ctx_of(capi.VARIANT_LANE_FAST)
+    eng = fast.chains_solve(Z0[p:p + 1], kind=capi.CHAIN_PLAIN, xtol=xtol, speculate=0)
+    assert eng["info"][0] == 1 and eng["fnorm"][0] > 1e-9            # the outlier (if this ever stops being one, the filter can go)
+    h = capi.HybrSolver(14, xtol=xtol, maxfev=10000, epsfcn=1e-15)
+    h.start(Z0[p])
+    req, xe, out_buf = h.advance(0)
+    while req != capi.REQ_DONE:
+        if req == capi.REQ_FVEC:
+            out_buf[:] = fast.residual(xe.copy())
+        else:
+            x = xe.copy()
+            out_buf[:] = fast.fd_jacobian(x, h.fvec, epsfcn=1e-15, dedup=True).T.ravel()        # column-major
+        req, xe, out_buf = h.advance(0)
+    delta, xnorm, fnorm = h.trust_region
+    assert h.info == 1 and h.nfev == eng["nfev"][0] and np.array_equal(h.x, eng["z"][0])
+    assert delta <= xtol * xnorm and fnorm > 1e-9 and abs(fnorm - eng["fnorm"][0]) <= 1e-12 * fnorm
+    # ... and from there the flavour does reach the root
+    again = fast.chains_solve(eng["z"], kind=capi.CHAIN_PLAIN, xtol=xtol, speculate=0)
+    assert again["info"][0] == 1 and again["fnorm"][0] <= 1e-9
+    assert np.max(np.abs(again["z"][0] - zg)) / np.max(np.abs(zg)) <= 1e-8
+    fast.close()
+
+    # -- reference order on the GPU == the CPU path, on this start
+    exact = ctx_of(capi.VARIANT_LANE_EXACT)
+    ge = exact.chains_solve(Z0[p:p + 1], kind=capi.CHAIN_PLAIN, xtol=xtol, speculate=0)
+    exact.close()
+    o = orc.Oracle(orc.MODEL_GODDARD, step_nbr=10000, params=sweep.GODDARD_PARAMS)
+    mode_x = np.zeros((2, 7), dtype=np.int32)
+    mode_x[1, 3:7] = orc.FREE
+    X = np.zeros((2, 14))
+    X[0, :7] = sweep.X0_STATE
+    X[1, 0] = 1.01
+    prob = orc.Problem(7, [orc.FIXED, orc.FIXED], mode_x, np.array([0.0, sweep.TF]), X)
+    cpu = capi.hybrd(lambda v: o.residual(prob, v), Z0[p], xtol=xtol, epsfcn=1e-15)
+    assert cpu["info"] == 1 and ge["info"][0] == 1 and cpu["nfev"] == ge["nfev"][0]
+    assert np.array_equal(np.asarray(cpu["x"]), ge["z"][0])
+    assert ge["fnorm"][0] <= 1e-9 and np.max(np.abs(ge["z"][0] - zg)) / np.max(np.abs(zg)) <= 1e-8
 
 
 @pytest.mark.parametrize("variant", ["fast", "exact"])
