@@ -463,6 +463,13 @@ extern "C" int socp_qr_factor_batch(int device, int n, int count, const double *
         if (rc == SOCP_OK && ok(hipEventElapsedTime(&ms, e0, e1))) total_ms += ms;
     }
     if (kernel_ms) *kernel_ms = total_ms / reps;
+    if (flavour == SOCP_FACTOR_FAST && std::getenv("SOCP_MULTISTART_TRACE")) {
+        unsigned long long pf[16];
+        if (read_factor_profile(pf, true) == hipSuccess && (pf[1] | pf[3]))
+            std::fprintf(stderr, "[socp_qr_factor_batch] clock ticks of wave 0, summed over problems and runs (a -DSOCP_FACTOR_PROFILE build): norms %llu, panel %llu, "
+                                 "waiting for the panel %llu, trailing strips %llu, waiting after them %llu, R / qtf %llu, qform: panel load %llu, strips %llu, waiting %llu\n",
+                         pf[0], pf[1], pf[2], pf[3], pf[4], pf[5], pf[6], pf[7], pf[8]);
+    }
     if (rc == SOCP_OK && (Q || R || qtb || rdiag || acnorm || sing)) {
         // the workspaces come back whole, in slices of at most 256 MB, and are taken apart here
         const int per = (int)std::max<size_t>(1, ((size_t)256 << 20) / (sizeof(double) * (size_t)pool.ws_stride));

@@ -322,6 +322,29 @@ __device__ __forceinline__ void panel_factor(double *__restrict__ A, int ld, int
     }
 }
 
+// Development aid (-DSOCP_FACTOR_PROFILE): lane 0 of wave 0 of every workgroup adds the clock ticks between marks to per-phase totals
+// (read_factor_profile; scripts/measure_factor.py prints them).  Compiled out otherwise.
+#ifdef SOCP_FACTOR_PROFILE
+__device__ unsigned long long g_fprof[16];
+struct FProf {
+    unsigned long long t;
+    bool on;
+    __device__ explicit FProf(int tid) : t(clock64()), on(tid == 0) {}
+    __device__ void mark(int slot)
+    {
+        const unsigned long long now = clock64();
+        if (on) atomicAdd(&g_fprof[slot], now - t);
+        t = now;
+    }
+};
+#else
+struct FProf {
+    __device__ explicit FProf(int) {}
+    __device__ void mark(int) {}
+};
+#endif
+enum { FP_NORMS = 0, FP_PANEL = 1, FP_PANEL_WAIT = 2, FP_TRAIL = 3, FP_TRAIL_WAIT = 4, FP_RPACK = 5, FP_QLOAD = 6, FP_QSTRIPS = 7, FP_QWAIT = 8 };
+
 // One workgroup of 256 threads per problem.  LDS (doubles): Vl[16 NCH][16] | Vt[16][kLdT] | Tl[256] | Gl[256]
 template <int NCH>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void factor_fast_kernel(Config c, State *states, double *ws, long ws_stride, const int *__restrict__ list, int count)
@@ -334,6 +357,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int p = list[b];
         Work w(ws + (long)p * ws_stride, n, ld, lds);
         double *A = w.A, *rdiag = w.wa1, *acnorm = w.wa2, *Tsave = w.V;
+        FProf prof(tid);
         // ---- column norms of the Jacobian (scaled by the column's largest entry: no overflow / underflow), fvec into column n
         for (int j = tid; j < n; j += 256) {
             double ss = 0.0, amax = 0.0;
@@ -359,19 +383,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         for (int i = tid; i < n; i += 256) A[(long)i * ld + n] = w.fvec[i];
         __syncthreads();
+        prof.mark(FP_NORMS);
         // ---- qrfac, panel by panel
         const int npanels = (n + 15) >> 4;
         for (int pi = 0; pi < npanels; pi++) {
             const int j0 = 16 * pi, np = (n - j0 < 16) ? n - j0 : 16, nch = (n - j0 + 15) >> 4;
             if (wave == 0) panel_factor<NCH>(A, ld, n, j0, np, nch, Vl, Vt, Tl, Gl, rdiag, Tsave + 256 * pi, lane, g, m);
+            prof.mark(FP_PANEL);
             __syncthreads();
+            prof.mark(FP_PANEL_WAIT);
             for (int c0 = j0 + 16 + 16 * wave; c0 <= n; c0 += 64) {
                 f64x4 S[NCH];
                 strip_load<NCH>(S, A, ld, n, j0, nch, c0, n + 1, g, m);
                 strip_apply<NCH>(S, nch, Vl, Vt, Tl, lane, g, m);
                 strip_store<NCH>(S, A, ld, n, j0, nch, c0, n + 1, g, m);
             }
+            prof.mark(FP_TRAIL);
             __syncthreads();
+            prof.mark(FP_TRAIL_WAIT);
         }
         // ---- Q^T fvec, R packed by rows (row i: rdiag[i], then A(i, i + 1 .. n - 1)), "singular"
         for (int i = tid; i < n; i += 256) w.qtf[i] = A[(long)i * ld + n];
@@ -382,6 +411,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         for (int j = tid; j < n; j += 256) zero |= (rdiag[j] == 0) ? 1 : 0;
         const int sing = __syncthreads_or(zero);
+        prof.mark(FP_RPACK);
         // ---- qform: the panels backward, each applied to the rows and columns from its first one on
         for (int pi = npanels - 1; pi >= 0; pi--) {
             const int j0 = 16 * pi, np = (n - j0 < 16) ? n - j0 : 16, nch = (n - j0 + 15) >> 4;
@@ -393,6 +423,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
             Tl[(tid & 15) * 16 + (tid >> 4)] = Tsave[256 * pi + tid];            // X = T^T
             __syncthreads();
+            prof.mark(FP_QLOAD);
             // the panel's own columns above its first row held R: zeros of Q now
             for (int e = tid; e < j0 * 16; e += 256) { const int row = e >> 4, t = e & 15; if (t < np) A[(long)row * ld + j0 + t] = 0.0; }
             for (int c0 = j0 + 16 * wave; c0 < n; c0 += 64) {
@@ -410,7 +441,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 strip_apply<NCH>(S, nch, Vl, Vt, Tl, lane, g, m);
                 strip_store<NCH>(S, A, ld, n, j0, nch, c0, n, g, m);
             }
+            prof.mark(FP_QSTRIPS);
             __syncthreads();
+            prof.mark(FP_QWAIT);
         }
         if (tid == 0) { states[p].sing = sing ? 1 : 0; states[p].pad = 1; }
         __syncthreads();
@@ -425,7 +458,8 @@ hipError_t raise_lds_limit_fast()
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev < 64 && ((raised.load(std::memory_order_acquire) >> dev) & 1ull)) return hipSuccess;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    // (the kernel also has a few hundred bytes of static LDS -- the workgroup-wide "or" -- so the dynamic part may not claim all 160 KB)
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     if (e == hipSuccess && dev < 64) raised.fetch_or(1ull << dev, std::memory_order_release);
     return e;
 }
@@ -443,6 +477,23 @@ hipError_t launch_nch(hipStream_t st, const PoolDev &pool, const int *d_list, in
 }
 
 }  // namespace
+
+hipError_t read_factor_profile(unsigned long long out[16], bool reset)
+{
+    for (int k = 0; k < 16; k++) out[k] = 0;
+#ifdef SOCP_FACTOR_PROFILE
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fprof), sizeof(unsigned long long) * 16);
+    if (e != hipSuccess) return e;
+    if (reset) {
+        const unsigned long long zero[16] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_fprof), zero, sizeof(zero));
+    }
+    return e;
+#else
+    (void)reset;
+    return hipSuccess;
+#endif
+}
 
 // n <= 256: a panel's strip (n rows x 16 columns) lives in the registers of one wavefront; the T factors of the panels
 // (256 doubles each) are kept in the workspace's spare n (n + 1) / 2 doubles until qform, which they fit from n = 39 on

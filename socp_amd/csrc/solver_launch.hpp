@@ -33,6 +33,7 @@ hipError_t launch_factor(hipStream_t st, const PoolDev &pool, const int *d_list,
 // wavefronts per problem; fast_factor_applies: the sizes it is built for (39 <= n <= 256)
 bool fast_factor_applies(int n);
 hipError_t launch_factor_fast(hipStream_t st, const PoolDev &pool, const int *d_list, int count);
+hipError_t read_factor_profile(unsigned long long out[16], bool reset);   // -DSOCP_FACTOR_PROFILE builds: per-phase clock totals of the fast kernel
 // the order-preserving factor work alone (solver_dev.hpp: factor), a thread per column: what socp_qr_factor_batch times beside it
 hipError_t launch_factor_exact(hipStream_t st, const PoolDev &pool, const int *d_list, int count);
 // dst[k][n] = the point problem list[k] asked to be evaluated (x, or the trial point)
