@@ -37,7 +37,8 @@ namespace {
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kLdT = 272;      // pitch (doubles) of the transposed, negated panel in LDS: 16 rows of up to 256 entries + padding
+constexpr int kLdV = 17;       // pitch (doubles) of a panel's V in LDS: rows of 16 entries + 1, so that the lanes of BOTH operand reads of
+                               // the trailing update (16 consecutive entries of 4 rows; 4 consecutive entries of 16 rows) spread over the banks
 
 __device__ __forceinline__ f64x4 mfma(double a, double b, f64x4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 
@@ -51,24 +52,33 @@ __device__ __forceinline__ int here(int x)
     return x;
 }
 
-// the value lane `src` holds (src: a compile-time constant after unrolling), as a uniform
+// the value lane `src` holds (src uniform), as a uniform
 __device__ __forceinline__ double from_lane(double x, int src)
 {
     const int lo = __builtin_amdgcn_readlane(__double2loint(x), src);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
     return __hiloint2double(hi, lo);
 }
-// sum over the four row groups of a column (lanes m, m + 16, m + 32, m + 48)
-__device__ __forceinline__ double sum_groups(double x)
+// x of the lane whose index differs in bit 0 (CTRL = 0xB1: quad_perm [1, 0, 3, 2]) or bit 1 (0x4E: [2, 3, 0, 1]): data-parallel
+// primitives, no LDS round trip
+template <int CTRL>
+__device__ __forceinline__ double quad_swap(double x)
 {
-    x += __shfl_xor(x, 16);
-    x += __shfl_xor(x, 32);
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+// sum / maximum over the four lanes of a quad (the panel wave keeps the four row groups of a column in one quad)
+__device__ __forceinline__ double quad_sum(double x)
+{
+    x += quad_swap<0xB1>(x);
+    x += quad_swap<0x4E>(x);
     return x;
 }
-__device__ __forceinline__ double max_groups(double x)
+__device__ __forceinline__ double quad_max(double x)
 {
-    x = fmax(x, __shfl_xor(x, 16));
-    x = fmax(x, __shfl_xor(x, 32));
+    x = fmax(x, quad_swap<0xB1>(x));
+    x = fmax(x, quad_swap<0x4E>(x));
     return x;
 }
 // LDS written by some lanes of this wavefront, read by others: the wave's LDS operations execute in order; keep the compiler
@@ -80,8 +90,10 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// A strip: 16 columns c0 .. c0 + 15, rows row0 .. row0 + 16 NCH - 1, in the C/D layout of v_mfma_f64_16x16x4_f64:
-// S[cc][reg] of lane (g = lane >> 4, m = lane & 15) = A(row0 + 16 cc + g + 4 reg, c0 + m).  Rows >= n and columns >= colmax read as 0.
+// A strip: 16 columns c0 .. c0 + 15, rows row0 .. row0 + 16 NCH - 1, four rows per 16-row chunk and lane:
+// S[cc][reg] of the lane with row group g (0 .. 3) and column m (0 .. 15) = A(row0 + 16 cc + g + 4 reg, c0 + m).  With g = lane >> 4,
+// m = lane & 15 this is the C/D layout of v_mfma_f64_16x16x4_f64; the panel wave uses g = lane & 3, m = lane >> 2 (a column's four row
+// groups in one quad).  Rows >= n and columns >= colmax read as 0.
 // One running pointer per lane, advanced by four rows per load (with the row index multiplied out per (chunk, register) the
 // compiler hoists 4 NCH row offsets x ld into scalar registers for the whole kernel and spills them), and no per-row lane masks
 // except in the one chunk that can be partly below the matrix (4 NCH hoisted exec masks were the other half of the spills):
@@ -129,77 +141,92 @@ __device__ __forceinline__ void strip_store(const f64x4 (&S)[NCH], double *__res
     }
 }
 
-// S <- (I - V X^T V^T) S for the panel in LDS: Vl[row][16] (row-major, rows relative to the panel's first row), Vt[k][kLdT] = -V
-// transposed, Xl[16][16] row-major (X = T applies H_last .. H_first, i.e. the panel's Q^T: qrfac; X = T^T applies the panel's Q: qform)
 // (the scheduler otherwise hoists every LDS read of a pass above the first MFMA -- 4 NCH more doubles per lane beside the strip's
 // 4 NCH -- and spills; a fence every kGroup chunks bounds what is in flight: the next group's operands while this group multiplies)
 constexpr int kGroup = 2;
 #define SOCP_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
+// S <- (I - V X^T V^T) S for the panel in LDS: Vl[row][kLdV] (rows relative to the panel's first row, zero above the diagonal),
+// Xl[16][16] row-major (X = T applies H_last .. H_first, i.e. the panel's Q^T: qrfac; X = T^T applies the panel's Q: qform).
+// S in the MFMA layout (g = lane >> 4, m = lane & 15).
 template <int NCH>
-__device__ __forceinline__ void strip_apply(f64x4 (&S)[NCH], int nch, const double *Vl, const double *Vt, const double *Xl, int lane, int g, int m)
+__device__ __forceinline__ void strip_apply(f64x4 (&S)[NCH], int nch, const double *Vl, const double *Xl, int lane)
 {
-    lane = here(lane); g = lane >> 4; m = lane & 15;
+    lane = here(lane);
+    const int g = lane >> 4, m = lane & 15;
+    const double *vw = Vl + g * kLdV + m;                                    // W = V^T S:  A operand V(row of K slot g, m)
     f64x4 W = {0, 0, 0, 0};
 #pragma unroll
     for (int cc = 0; cc < NCH; cc++) {
         if (cc < nch) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) W = mfma(Vl[(16 * cc + 4 * r) * 16 + lane], S[cc][r], W);      // A: V(row of slot g, m); B: the strip itself
+            for (int r = 0; r < 4; r++) W = mfma(vw[(16 * cc + 4 * r) * kLdV], S[cc][r], W);            // B: the strip itself, K slot g = row g + 4 r of the chunk
         }
         if (cc % kGroup == kGroup - 1) SOCP_SCHED_FENCE();
     }
     f64x4 Y = {0, 0, 0, 0};
 #pragma unroll
     for (int r = 0; r < 4; r++) Y = mfma(Xl[64 * r + lane], W[r], Y);                                   // A: X(g + 4 r, m) = X^T(m, k); B: W(k = g + 4 r, m)
+#pragma unroll
+    for (int r = 0; r < 4; r++) Y[r] = -Y[r];
     SOCP_SCHED_FENCE();
+    const double *vu = Vl + m * kLdV + g;                                    // S -= V Y:  A operand V(16 cc + m, k = g + 4 r)
 #pragma unroll
     for (int cc = 0; cc < NCH; cc++) {
         if (cc < nch) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) S[cc] = mfma(Vt[(g + 4 * r) * kLdT + 16 * cc + m], Y[r], S[cc]);   // A: -V(16 cc + m, k = g + 4 r); B: Y(k, m)
+            for (int r = 0; r < 4; r++) S[cc] = mfma(vu[16 * cc * kLdV + 4 * r], Y[r], S[cc]);          // B: -Y(k, m)
         }
         if (cc % kGroup == kGroup - 1) SOCP_SCHED_FENCE();
     }
 }
 
-// The panel of columns j0 .. j0 + 15 (np of them are reflectors), rows j0 .. n - 1, factorised by ONE wavefront in registers.
-// Leaves: the strip in A (R above the diagonal, the vectors from the diagonal down, as MINPACK stores them), rdiag, V / -V^T / T
-// in LDS, T also in Tsave (row-major 16 x 16) for qform.
+// The panel of columns j0 .. j0 + 15 (np of them are reflectors), rows j0 .. n - 1, factorised by ONE wavefront in registers, a
+// column's four row groups in one quad of lanes (g = lane & 3, m = lane >> 2): the norm and the dot products are reduced with two
+// quad permutes each.  Leaves: the strip in A (R above the diagonal, the vectors from the diagonal down, as MINPACK stores them),
+// rdiag, V and T in LDS, T also in Tsave (row-major 16 x 16) for qform.
 template <int NCH>
-__device__ __forceinline__ void panel_factor(double *__restrict__ A, int ld, int n, int j0, int np, int nch, double *Vl, double *Vt, double *Tl, double *Gl,
-                             double *__restrict__ rdiag, double *__restrict__ Tsave, int lane, int g, int m)
+__device__ __forceinline__ void panel_factor(double *__restrict__ A, int ld, int n, int j0, int np, int nch, double *Vl, double *Tl, double *Gl,
+                                             double *__restrict__ rdiag, double *__restrict__ Tsave, int lane)
 {
     f64x4 S[NCH];
-    strip_load<NCH>(S, A, ld, n, j0, nch, j0, n + 1, g, m);                  // (column n = fvec rides along when it falls into this strip)
+    strip_load<NCH>(S, A, ld, n, j0, nch, j0, n + 1, lane & 3, lane >> 2);   // (column n = fvec rides along when it falls into this strip)
     double tau_mine = 0.0;                                                   // lane t (t < 16) keeps tau_t
     // a real loop over the panel's columns (unrolled 16 times the body exceeds what the compiler will unroll, and then every
     // "constant" index below becomes a run-time register index, i.e. scratch): t is uniform, lanes and registers are SELECTED
 #pragma unroll 1
     for (int t = 0; t < 16; t++) {
-        lane = here(lane); g = lane >> 4; m = lane & 15;
+        lane = here(lane);
+        const int g = lane & 3, m = lane >> 2;
         bool live = t < np;
         double ajnorm = 0.0, ajj = 0.0;
         if (live) {
-            // |column t| over the rows from the diagonal down (row_rel >= t); every lane does its own column, lane t's is wanted
-            double ss = 0.0, amax = 0.0;
+            // |column t| over the rows from the diagonal down (row_rel >= t: a question in chunk 0 only); every lane does its own
+            // column, the quad of column t is the one that counts
+            double ss = 0.0;
 #pragma unroll
-            for (int cc = 0; cc < NCH; cc++) {
+            for (int r = 0; r < 4; r++) { const double x = (g + 4 * r >= t) ? S[0][r] : 0.0; ss += x * x; }
+#pragma unroll
+            for (int cc = 1; cc < NCH; cc++) {
                 if (cc < nch) {
 #pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const double x = (16 * cc + g + 4 * r >= t) ? S[cc][r] : 0.0;
-                        ss += x * x;
-                        amax = fmax(amax, fabs(x));
-                    }
+                    for (int r = 0; r < 4; r++) ss += S[cc][r] * S[cc][r];
                 }
             }
-            ss = from_lane(sum_groups(ss), t);
+            ss = from_lane(quad_sum(ss), 4 * t);
             if (ss != ss) {
                 ajnorm = ss;                                                 // a NaN in the column: handed on, as MINPACK's enorm does
             } else if (!(ss > 1e-280 && ss < 1e280)) {
                 // outside the range in which a plain sum of squares is safe (or zero): scale by the largest entry
-                amax = from_lane(max_groups(amax), t);
+                double amax = 0.0;
+#pragma unroll
+                for (int cc = 0; cc < NCH; cc++) {
+                    if (cc < nch) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) amax = fmax(amax, (16 * cc + g + 4 * r >= t) ? fabs(S[cc][r]) : 0.0);
+                    }
+                }
+                amax = from_lane(quad_max(amax), 4 * t);
                 if (amax > 0 && amax < INFINITY) {
                     double s2 = 0.0;
 #pragma unroll
@@ -212,17 +239,17 @@ __device__ __forceinline__ void panel_factor(double *__restrict__ A, int ld, int
                             }
                         }
                     }
-                    ajnorm = amax * sqrt(from_lane(sum_groups(s2), t));
+                    ajnorm = amax * sqrt(from_lane(quad_sum(s2), 4 * t));
                 } else {
                     ajnorm = amax;                                           // a zero column (no reflector), or an infinity handed on
                 }
             } else {
                 ajnorm = sqrt(ss);
             }
-            // a(j, j): row_rel = t is chunk 0, g = t & 3, reg = t >> 2, of column t
+            // a(j, j): row_rel = t is chunk 0, row group t & 3, register t >> 2, of column t
             const int rsel = t >> 2;
             const double diag_reg = rsel == 0 ? S[0][0] : rsel == 1 ? S[0][1] : rsel == 2 ? S[0][2] : S[0][3];
-            ajj = from_lane(diag_reg, 16 * (t & 3) + t);
+            ajj = from_lane(diag_reg, 4 * t + (t & 3));
             if (ajnorm != 0 && ajj < 0) ajnorm = -ajnorm;
             if (lane == 0) rdiag[j0 + t] = -ajnorm;
             live = ajnorm != 0;
@@ -231,77 +258,89 @@ __device__ __forceinline__ void panel_factor(double *__restrict__ A, int ld, int
         if (live) {
             const double vjj = ajj / ajnorm + 1.0;                           // in [1, 2]: ajnorm carries a(j, j)'s sign
             tau_t = 1.0 / vjj;
-            if (m == t) {
+            // v = a / ajnorm + e_t from the diagonal down, as two multiplications (the first one exact: by 1, or by 2^600 when the
+            // reciprocal of a subnormal ajnorm would overflow) and in straight-line code: every lane multiplies, all but column t's
+            // by exactly 1 -- a divergent branch around 4 NCH register updates makes the compiler keep two copies of the strip
+            const double s1 = (fabs(ajnorm) < 1e-290) ? 0x1p600 : 1.0;
+            const double inv = 1.0 / (ajnorm * s1);
+            const bool mine = m == t;
+            const double f1 = mine ? s1 : 1.0, f2 = mine ? inv : 1.0;
 #pragma unroll
-                for (int cc = 0; cc < NCH; cc++) {
-                    if (cc < nch) {
+            for (int r = 0; r < 4; r++) {
+                const int rr = g + 4 * r;
+                const bool below = mine && rr >= t;
+                const double x = (S[0][r] * (below ? s1 : 1.0)) * (below ? inv : 1.0);
+                S[0][r] = (mine && rr == t) ? x + 1.0 : x;
+            }
 #pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            const int rr = 16 * cc + g + 4 * r;
-                            if (rr >= t) S[cc][r] = S[cc][r] / ajnorm + (rr == t ? 1.0 : 0.0);
-                        }
-                    }
+            for (int cc = 1; cc < NCH; cc++) {
+                if (cc < nch) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) S[cc][r] = (S[cc][r] * f1) * f2;
                 }
             }
         }
         if (lane == t) tau_mine = tau_t;
         // column t of V (zero above its diagonal; all zero for a skipped reflector or a column that is not one)
         if (m == t) {
+            double *vp = Vl + g * kLdV + t;
 #pragma unroll
-            for (int cc = 0; cc < NCH; cc++) {
+            for (int r = 0; r < 4; r++) vp[4 * r * kLdV] = (live && g + 4 * r >= t) ? S[0][r] : 0.0;
+#pragma unroll
+            for (int cc = 1; cc < NCH; cc++) {
                 if (cc < nch) {
 #pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const int rr = 16 * cc + g + 4 * r;
-                        const double v = (live && rr >= t) ? S[cc][r] : 0.0;
-                        Vl[rr * 16 + t] = v;
-                        Vt[t * kLdT + rr] = -v;
-                    }
+                    for (int r = 0; r < 4; r++) vp[(16 * cc + 4 * r) * kLdV] = live ? S[cc][r] : 0.0;
                 }
             }
         }
         wave_lds_fence();
         if (live) {
             // the later columns of the strip through reflector t:  a -= v (v . a) / v_t
+            const double *vp = Vl + g * kLdV + t;
             double dot = 0.0;
 #pragma unroll
             for (int cc = 0; cc < NCH; cc++) {
                 if (cc < nch) {
 #pragma unroll
-                    for (int r = 0; r < 4; r++) dot += Vl[(16 * cc + g + 4 * r) * 16 + t] * S[cc][r];
+                    for (int r = 0; r < 4; r++) dot += vp[(16 * cc + 4 * r) * kLdV] * S[cc][r];
                 }
                 if (cc % kGroup == kGroup - 1) SOCP_SCHED_FENCE();
             }
-            dot = sum_groups(dot);
+            dot = quad_sum(dot);
             const double coef = (m > t) ? dot * tau_t : 0.0;
             wave_lds_fence();                                                // (re-read v below rather than hold 4 NCH more registers)
 #pragma unroll
             for (int cc = 0; cc < NCH; cc++) {
                 if (cc < nch) {
 #pragma unroll
-                    for (int r = 0; r < 4; r++) S[cc][r] -= coef * Vl[(16 * cc + g + 4 * r) * 16 + t];
+                    for (int r = 0; r < 4; r++) S[cc][r] -= coef * vp[(16 * cc + 4 * r) * kLdV];
                 }
                 if (cc % kGroup == kGroup - 1) SOCP_SCHED_FENCE();
             }
         }
     }
-    strip_store<NCH>(S, A, ld, n, j0, nch, j0, n + 1, g, m);
+    strip_store<NCH>(S, A, ld, n, j0, nch, j0, n + 1, lane & 3, lane >> 2);
     // G = V^T V on the matrix cores, then larft's recurrence: T(i, t) = -tau_t sum_{k = i}^{t - 1} T(i, k) G(k, t), T(t, t) = tau_t
-    lane = here(lane); g = lane >> 4; m = lane & 15;
-    f64x4 G = {0, 0, 0, 0};
+    lane = here(lane);
+    {
+        const int g = lane >> 4, m = lane & 15;
+        const double *vw = Vl + g * kLdV + m;
+        f64x4 G = {0, 0, 0, 0};
 #pragma unroll
-    for (int cc = 0; cc < NCH; cc++) {
-        if (cc < nch) {
+        for (int cc = 0; cc < NCH; cc++) {
+            if (cc < nch) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const double v = Vl[(16 * cc + 4 * r) * 16 + lane];
-                G = mfma(v, v, G);
+                for (int r = 0; r < 4; r++) {
+                    const double v = vw[(16 * cc + 4 * r) * kLdV];
+                    G = mfma(v, v, G);
+                }
             }
+            if (cc % kGroup == kGroup - 1) SOCP_SCHED_FENCE();
         }
-        if (cc % kGroup == kGroup - 1) SOCP_SCHED_FENCE();
-    }
 #pragma unroll
-    for (int r = 0; r < 4; r++) Gl[(g + 4 * r) * 16 + m] = G[r];
+        for (int r = 0; r < 4; r++) Gl[(g + 4 * r) * 16 + m] = G[r];
+    }
     wave_lds_fence();
     {
         const int i = here(lane) & 15;                                       // (every row group computes the same T; group 0 stores it)
@@ -345,12 +384,12 @@ struct FProf {
 #endif
 enum { FP_NORMS = 0, FP_PANEL = 1, FP_PANEL_WAIT = 2, FP_TRAIL = 3, FP_TRAIL_WAIT = 4, FP_RPACK = 5, FP_QLOAD = 6, FP_QSTRIPS = 7, FP_QWAIT = 8 };
 
-// One workgroup of 256 threads per problem.  LDS (doubles): Vl[16 NCH][16] | Vt[16][kLdT] | Tl[256] | Gl[256]
+// One workgroup of 256 threads per problem.  LDS (doubles): Vl[16 NCH][kLdV] | Tl[256] | Gl[256]
 template <int NCH>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void factor_fast_kernel(Config c, State *states, double *ws, long ws_stride, const int *__restrict__ list, int count)
 {
     extern __shared__ double lds[];
-    double *Vl = lds, *Vt = Vl + 16 * NCH * 16, *Tl = Vt + 16 * kLdT, *Gl = Tl + 256;
+    double *Vl = lds, *Tl = Vl + 16 * NCH * kLdV, *Gl = Tl + 256;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, m = lane & 15;
     const int n = c.n, ld = c.ld;
     for (int b = blockIdx.x; b < count; b += gridDim.x) {
@@ -388,14 +427,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int npanels = (n + 15) >> 4;
         for (int pi = 0; pi < npanels; pi++) {
             const int j0 = 16 * pi, np = (n - j0 < 16) ? n - j0 : 16, nch = (n - j0 + 15) >> 4;
-            if (wave == 0) panel_factor<NCH>(A, ld, n, j0, np, nch, Vl, Vt, Tl, Gl, rdiag, Tsave + 256 * pi, lane, g, m);
+            // (the panels take turns on the four wavefronts: with two workgroups on a CU the serial part of both would otherwise
+            // sit on the same SIMD)
+            if (wave == (pi & 3)) panel_factor<NCH>(A, ld, n, j0, np, nch, Vl, Tl, Gl, rdiag, Tsave + 256 * pi, lane);
             prof.mark(FP_PANEL);
             __syncthreads();
             prof.mark(FP_PANEL_WAIT);
             for (int c0 = j0 + 16 + 16 * wave; c0 <= n; c0 += 64) {
                 f64x4 S[NCH];
                 strip_load<NCH>(S, A, ld, n, j0, nch, c0, n + 1, g, m);
-                strip_apply<NCH>(S, nch, Vl, Vt, Tl, lane, g, m);
+                strip_apply<NCH>(S, nch, Vl, Tl, lane);
                 strip_store<NCH>(S, A, ld, n, j0, nch, c0, n + 1, g, m);
             }
             prof.mark(FP_TRAIL);
@@ -418,8 +459,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int e = tid; e < nch * 256; e += 256) {
                 const int rr = e >> 4, t = e & 15, row = j0 + rr;
                 const double v = (rr >= t && t < np && row < n) ? A[(long)row * ld + j0 + t] : 0.0;
-                Vl[rr * 16 + t] = v;
-                Vt[t * kLdT + rr] = -v;
+                Vl[rr * kLdV + t] = v;
             }
             Tl[(tid & 15) * 16 + (tid >> 4)] = Tsave[256 * pi + tid];            // X = T^T
             __syncthreads();
@@ -438,7 +478,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 } else {
                     strip_load<NCH>(S, A, ld, n, j0, nch, c0, n, g, m);
                 }
-                strip_apply<NCH>(S, nch, Vl, Vt, Tl, lane, g, m);
+                strip_apply<NCH>(S, nch, Vl, Tl, lane);
                 strip_store<NCH>(S, A, ld, n, j0, nch, c0, n, g, m);
             }
             prof.mark(FP_QSTRIPS);
@@ -467,7 +507,7 @@ hipError_t raise_lds_limit_fast()
 template <int NCH>
 hipError_t launch_nch(hipStream_t st, const PoolDev &pool, const int *d_list, int count)
 {
-    const size_t lds_bytes = sizeof(double) * (size_t)(16 * NCH * 16 + 16 * kLdT + 512);
+    const size_t lds_bytes = sizeof(double) * (size_t)(16 * NCH * kLdV + 512);
     if (lds_bytes > 65536) {
         const hipError_t raised = raise_lds_limit_fast<factor_fast_kernel<NCH>>();
         if (raised != hipSuccess) return raised;
