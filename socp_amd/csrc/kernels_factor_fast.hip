@@ -181,16 +181,30 @@ __device__ __forceinline__ void strip_apply(f64x4 (&S)[NCH], int nch, const doub
     }
 }
 
-// The panel of columns j0 .. j0 + 15 (np of them are reflectors), rows j0 .. n - 1, factorised by ONE wavefront in registers, a
-// column's four row groups in one quad of lanes (g = lane & 3, m = lane >> 2): the norm and the dot products are reduced with two
-// quad permutes each.  Leaves: the strip in A (R above the diagonal, the vectors from the diagonal down, as MINPACK stores them),
-// rdiag, V and T in LDS, T also in Tsave (row-major 16 x 16) for qform.
-template <int NCH>
-__device__ __forceinline__ void panel_factor(double *__restrict__ A, int ld, int n, int j0, int np, int nch, double *Vl, double *Tl, double *Gl,
-                                             double *__restrict__ rdiag, double *__restrict__ Tsave, int lane)
+// 1 / x and 1 / sqrt(x) to double precision from the hardware estimates (relative error ~2^-24) in one cubic step each (error ~1e-22);
+// for arguments well inside the exponent range only -- the callers below check that
+__device__ __forceinline__ double rcp_in_range(double x)
 {
-    f64x4 S[NCH];
-    strip_load<NCH>(S, A, ld, n, j0, nch, j0, n + 1, lane & 3, lane >> 2);   // (column n = fvec rides along when it falls into this strip)
+    const double r = __builtin_amdgcn_rcp(x);
+    const double e = __builtin_fma(-x, r, 1.0);
+    return __builtin_fma(r, __builtin_fma(e, e, e), r);
+}
+__device__ __forceinline__ double rsqrt_in_range(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    const double d = __builtin_fma(-(x * y), y, 1.0);
+    return __builtin_fma(y * d, __builtin_fma(0.375, d, 0.5), y);
+}
+
+// A panel of 16 columns (np of them reflectors) held by ONE wavefront in registers, a column's four row groups in one quad of lanes
+// (g = lane & 3, m = lane >> 2: P[cc][reg] = entry (16 cc + g + 4 reg, m) of the panel, row 0 = the panel's first diagonal row): the
+// norm and the dot products are reduced with two quad permutes each.  Factorises it in place (R above the diagonal, the vectors
+// from the diagonal down, as MINPACK stores them) and leaves rdiag[0 .. np), V (zero above the diagonal) and T in LDS, T also in
+// Tsave (row-major 16 x 16) for qform.
+template <int NCH>
+__device__ __forceinline__ void panel_core(f64x4 (&S)[NCH], int np, int nch, double *Vl, double *Tl, double *Gl, double *__restrict__ rdiag,
+                                           double *__restrict__ Tsave, int lane)
+{
     double tau_mine = 0.0;                                                   // lane t (t < 16) keeps tau_t
     // a real loop over the panel's columns (unrolled 16 times the body exceeds what the compiler will unroll, and then every
     // "constant" index below becomes a run-time register index, i.e. scratch): t is uniform, lanes and registers are SELECTED
@@ -199,21 +213,24 @@ __device__ __forceinline__ void panel_factor(double *__restrict__ A, int ld, int
         lane = here(lane);
         const int g = lane & 3, m = lane >> 2;
         bool live = t < np;
-        double ajnorm = 0.0, ajj = 0.0;
+        double ajnorm = 0.0, ajj = 0.0, inv = 0.0, s1 = 1.0;
         if (live) {
-            // |column t| over the rows from the diagonal down (row_rel >= t: a question in chunk 0 only); every lane does its own
-            // column, the quad of column t is the one that counts
-            double ss = 0.0;
-#pragma unroll
-            for (int r = 0; r < 4; r++) { const double x = (g + 4 * r >= t) ? S[0][r] : 0.0; ss += x * x; }
+            // |column t| over the rows from the diagonal down (row >= t: a question in chunk 0 only); every lane does its own
+            // column, the quad of column t is the one that counts.  Four partial sums: the chain of dependent adds is the latency.
+            double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+            { const double x = (g >= t) ? S[0][0] : 0.0; q0 = x * x; }
+            { const double x = (g + 4 >= t) ? S[0][1] : 0.0; q1 = x * x; }
+            { const double x = (g + 8 >= t) ? S[0][2] : 0.0; q2 = x * x; }
+            { const double x = (g + 12 >= t) ? S[0][3] : 0.0; q3 = x * x; }
 #pragma unroll
             for (int cc = 1; cc < NCH; cc++) {
                 if (cc < nch) {
-#pragma unroll
-                    for (int r = 0; r < 4; r++) ss += S[cc][r] * S[cc][r];
+                    q0 = __builtin_fma(S[cc][0], S[cc][0], q0); q1 = __builtin_fma(S[cc][1], S[cc][1], q1);
+                    q2 = __builtin_fma(S[cc][2], S[cc][2], q2); q3 = __builtin_fma(S[cc][3], S[cc][3], q3);
                 }
             }
-            ss = from_lane(quad_sum(ss), 4 * t);
+            const double ss = from_lane(quad_sum((q0 + q1) + (q2 + q3)), 4 * t);
+            bool plain = false;
             if (ss != ss) {
                 ajnorm = ss;                                                 // a NaN in the column: handed on, as MINPACK's enorm does
             } else if (!(ss > 1e-280 && ss < 1e280)) {
@@ -244,25 +261,31 @@ __device__ __forceinline__ void panel_factor(double *__restrict__ A, int ld, int
                     ajnorm = amax;                                           // a zero column (no reflector), or an infinity handed on
                 }
             } else {
-                ajnorm = sqrt(ss);
+                ajnorm = ss * rsqrt_in_range(ss);
+                plain = true;
             }
-            // a(j, j): row_rel = t is chunk 0, row group t & 3, register t >> 2, of column t
+            // a(j, j): row t is chunk 0, row group t & 3, register t >> 2, of column t
             const int rsel = t >> 2;
             const double diag_reg = rsel == 0 ? S[0][0] : rsel == 1 ? S[0][1] : rsel == 2 ? S[0][2] : S[0][3];
             ajj = from_lane(diag_reg, 4 * t + (t & 3));
             if (ajnorm != 0 && ajj < 0) ajnorm = -ajnorm;
-            if (lane == 0) rdiag[j0 + t] = -ajnorm;
+            if (lane == 0) rdiag[t] = -ajnorm;
             live = ajnorm != 0;
+            // 1 / ajnorm: the quick reciprocal where the sum of squares was in range (|ajnorm| in 1e-140 .. 1e140); otherwise a
+            // division, of ajnorm 2^600 when ajnorm is so small that its reciprocal would overflow (s1 is 1 in every other case)
+            if (plain) {
+                inv = rcp_in_range(ajnorm);
+            } else if (live) {
+                s1 = (fabs(ajnorm) < 1e-290) ? 0x1p600 : 1.0;
+                inv = 1.0 / (ajnorm * s1);
+            }
         }
         double tau_t = 0.0;
         if (live) {
-            const double vjj = ajj / ajnorm + 1.0;                           // in [1, 2]: ajnorm carries a(j, j)'s sign
-            tau_t = 1.0 / vjj;
-            // v = a / ajnorm + e_t from the diagonal down, as two multiplications (the first one exact: by 1, or by 2^600 when the
-            // reciprocal of a subnormal ajnorm would overflow) and in straight-line code: every lane multiplies, all but column t's
-            // by exactly 1 -- a divergent branch around 4 NCH register updates makes the compiler keep two copies of the strip
-            const double s1 = (fabs(ajnorm) < 1e-290) ? 0x1p600 : 1.0;
-            const double inv = 1.0 / (ajnorm * s1);
+            const double vjj = (ajj * s1) * inv + 1.0;                       // in [1, 2]: ajnorm carries a(j, j)'s sign
+            tau_t = rcp_in_range(vjj);
+            // v = a / ajnorm + e_t from the diagonal down, in straight-line code: every lane multiplies, all but column t's by exactly 1
+            // (a divergent branch around 4 NCH register updates makes the compiler keep two copies of the strip)
             const bool mine = m == t;
             const double f1 = mine ? s1 : 1.0, f2 = mine ? inv : 1.0;
 #pragma unroll
@@ -298,29 +321,28 @@ __device__ __forceinline__ void panel_factor(double *__restrict__ A, int ld, int
         if (live) {
             // the later columns of the strip through reflector t:  a -= v (v . a) / v_t
             const double *vp = Vl + g * kLdV + t;
-            double dot = 0.0;
+            double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
 #pragma unroll
             for (int cc = 0; cc < NCH; cc++) {
                 if (cc < nch) {
-#pragma unroll
-                    for (int r = 0; r < 4; r++) dot += vp[(16 * cc + 4 * r) * kLdV] * S[cc][r];
+                    d0 = __builtin_fma(vp[(16 * cc) * kLdV], S[cc][0], d0); d1 = __builtin_fma(vp[(16 * cc + 4) * kLdV], S[cc][1], d1);
+                    d2 = __builtin_fma(vp[(16 * cc + 8) * kLdV], S[cc][2], d2); d3 = __builtin_fma(vp[(16 * cc + 12) * kLdV], S[cc][3], d3);
                 }
                 if (cc % kGroup == kGroup - 1) SOCP_SCHED_FENCE();
             }
-            dot = quad_sum(dot);
+            const double dot = quad_sum((d0 + d1) + (d2 + d3));
             const double coef = (m > t) ? dot * tau_t : 0.0;
             wave_lds_fence();                                                // (re-read v below rather than hold 4 NCH more registers)
 #pragma unroll
             for (int cc = 0; cc < NCH; cc++) {
                 if (cc < nch) {
 #pragma unroll
-                    for (int r = 0; r < 4; r++) S[cc][r] -= coef * vp[(16 * cc + 4 * r) * kLdV];
+                    for (int r = 0; r < 4; r++) S[cc][r] = __builtin_fma(-coef, vp[(16 * cc + 4 * r) * kLdV], S[cc][r]);
                 }
                 if (cc % kGroup == kGroup - 1) SOCP_SCHED_FENCE();
             }
         }
     }
-    strip_store<NCH>(S, A, ld, n, j0, nch, j0, n + 1, lane & 3, lane >> 2);
     // G = V^T V on the matrix cores, then larft's recurrence: T(i, t) = -tau_t sum_{k = i}^{t - 1} T(i, k) G(k, t), T(t, t) = tau_t
     lane = here(lane);
     {
@@ -361,6 +383,14 @@ __device__ __forceinline__ void panel_factor(double *__restrict__ A, int ld, int
     }
 }
 
+// a strip from the MFMA layout (lane = 16 g + m) to the panel wave's (lane = 4 m + g): the lane that will hold (g, m) fetches from
+// the lane that holds it now -- through the LDS crossbar (ds_bpermute), no LDS storage
+__device__ __forceinline__ double to_quad_layout(double x, int lane)
+{
+    const int src = 16 * (lane & 3) + (lane >> 2);
+    return __shfl(x, src);
+}
+
 // Development aid (-DSOCP_FACTOR_PROFILE): lane 0 of wave 0 of every workgroup adds the clock ticks between marks to per-phase totals
 // (read_factor_profile; scripts/measure_factor.py prints them).  Compiled out otherwise.
 #ifdef SOCP_FACTOR_PROFILE
@@ -384,12 +414,14 @@ struct FProf {
 #endif
 enum { FP_NORMS = 0, FP_PANEL = 1, FP_PANEL_WAIT = 2, FP_TRAIL = 3, FP_TRAIL_WAIT = 4, FP_RPACK = 5, FP_QLOAD = 6, FP_QSTRIPS = 7, FP_QWAIT = 8 };
 
-// One workgroup of 256 threads per problem.  LDS (doubles): Vl[16 NCH][kLdV] | Tl[256] | Gl[256]
+// One workgroup of 256 threads per problem.  LDS (doubles): two panels' V[16 NCH][kLdV] and T[256] (qrfac: the panel being applied and
+// the next one being factorised -- look-ahead; qform: the two panels applied in one pass), Gl[256]
 template <int NCH>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void factor_fast_kernel(Config c, State *states, double *ws, long ws_stride, const int *__restrict__ list, int count)
 {
     extern __shared__ double lds[];
-    double *Vl = lds, *Tl = Vl + 16 * NCH * kLdV, *Gl = Tl + 256;
+    constexpr int kPanelDoubles = 16 * NCH * kLdV + 256;
+    double *Gl = lds + 2 * kPanelDoubles;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, m = lane & 15;
     const int n = c.n, ld = c.ld;
     for (int b = blockIdx.x; b < count; b += gridDim.x) {
@@ -397,7 +429,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         Work w(ws + (long)p * ws_stride, n, ld, lds);
         double *A = w.A, *rdiag = w.wa1, *acnorm = w.wa2, *Tsave = w.V;
         FProf prof(tid);
-        // ---- column norms of the Jacobian (scaled by the column's largest entry: no overflow / underflow), fvec into column n
+        // ---- column norms of the Jacobian (scaled by the column's largest entry where a plain sum of squares is unsafe), fvec into column n
         for (int j = tid; j < n; j += 256) {
             double ss = 0.0, amax = 0.0;
             int i = 0;
@@ -423,23 +455,63 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int i = tid; i < n; i += 256) A[(long)i * ld + n] = w.fvec[i];
         __syncthreads();
         prof.mark(FP_NORMS);
-        // ---- qrfac, panel by panel
+        // ---- qrfac with look-ahead.  Panel 0 by wave 0; then, while panel pi goes through the trailing strips on three
+        // wavefronts, the fourth takes the strip that is the NEXT panel, applies panel pi to it and factorises it on the spot
+        // (the strip never leaves its registers between the two): the serial part hides behind the updates.
         const int npanels = (n + 15) >> 4;
+        if (wave == 0) {
+            f64x4 P[NCH];
+            const int np0 = n < 16 ? n : 16, nch0 = (n + 15) >> 4;
+            strip_load<NCH>(P, A, ld, n, 0, nch0, 0, n + 1, lane & 3, lane >> 2);          // (column n = fvec rides along when it falls into this strip)
+            panel_core<NCH>(P, np0, nch0, lds, lds + 16 * NCH * kLdV, Gl, rdiag, Tsave, lane);
+            strip_store<NCH>(P, A, ld, n, 0, nch0, 0, n + 1, lane & 3, lane >> 2);
+        }
+        prof.mark(FP_PANEL);
+        __syncthreads();
+        prof.mark(FP_PANEL_WAIT);
         for (int pi = 0; pi < npanels; pi++) {
-            const int j0 = 16 * pi, np = (n - j0 < 16) ? n - j0 : 16, nch = (n - j0 + 15) >> 4;
-            // (the panels take turns on the four wavefronts: with two workgroups on a CU the serial part of both would otherwise
-            // sit on the same SIMD)
-            if (wave == (pi & 3)) panel_factor<NCH>(A, ld, n, j0, np, nch, Vl, Tl, Gl, rdiag, Tsave + 256 * pi, lane);
-            prof.mark(FP_PANEL);
-            __syncthreads();
-            prof.mark(FP_PANEL_WAIT);
-            for (int c0 = j0 + 16 + 16 * wave; c0 <= n; c0 += 64) {
+            const int j0 = 16 * pi, nch = (n - j0 + 15) >> 4;
+            double *Vc = lds + (pi & 1) * kPanelDoubles, *Tc = Vc + 16 * NCH * kLdV;
+            double *Vn = lds + ((pi + 1) & 1) * kPanelDoubles, *Tn = Vn + 16 * NCH * kLdV;
+            const bool has_next = pi + 1 < npanels;
+            const int ahead = (pi + 1) & 3;                                  // the wavefront that runs ahead (they take turns: two workgroups
+                                                                             // share a CU, their serial parts should not share a SIMD)
+            if (has_next && wave == ahead) {
                 f64x4 S[NCH];
-                strip_load<NCH>(S, A, ld, n, j0, nch, c0, n + 1, g, m);
-                strip_apply<NCH>(S, nch, Vl, Tl, lane);
-                strip_store<NCH>(S, A, ld, n, j0, nch, c0, n + 1, g, m);
+                strip_load<NCH>(S, A, ld, n, j0, nch, j0 + 16, n + 1, g, m);
+                strip_apply<NCH>(S, nch, Vc, Tc, lane);
+                // its first 16 rows are rows of R now: they go home; the rest is the next panel, in the panel layout
+                {
+                    const int col = j0 + 16 + here(m);
+                    if (col <= n) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) A[(long)(j0 + here(g) + 4 * r) * ld + col] = S[0][r];
+                    }
+                }
+                SOCP_SCHED_FENCE();
+#pragma unroll
+                for (int cc = 0; cc + 1 < NCH; cc++) {                       // chunk by chunk, in place: one strip's worth of registers, not two
+#pragma unroll
+                    for (int r = 0; r < 4; r++) S[cc][r] = to_quad_layout(S[cc + 1][r], lane);
+                    SOCP_SCHED_FENCE();
+                }
+                S[NCH - 1] = f64x4{0, 0, 0, 0};
+                const int j1 = j0 + 16, np1 = (n - j1 < 16) ? n - j1 : 16;
+                panel_core<NCH>(S, np1, nch - 1, Vn, Tn, Gl, rdiag + j1, Tsave + 256 * (pi + 1), lane);
+                strip_store<NCH>(S, A, ld, n, j1, nch - 1, j1, n + 1, lane & 3, lane >> 2);
+                prof.mark(FP_PANEL);
+            } else {
+                // the trailing strips: three wavefronts while one runs ahead, all four for the last panel
+                const int first = j0 + (has_next ? 32 : 16);
+                const int slot = has_next ? ((wave - ahead - 1) & 3) : wave, stride = has_next ? 48 : 64;
+                for (int c0 = first + 16 * slot; c0 <= n; c0 += stride) {
+                    f64x4 S[NCH];
+                    strip_load<NCH>(S, A, ld, n, j0, nch, c0, n + 1, g, m);
+                    strip_apply<NCH>(S, nch, Vc, Tc, lane);
+                    strip_store<NCH>(S, A, ld, n, j0, nch, c0, n + 1, g, m);
+                }
+                prof.mark(FP_TRAIL);
             }
-            prof.mark(FP_TRAIL);
             __syncthreads();
             prof.mark(FP_TRAIL_WAIT);
         }
@@ -453,37 +525,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int j = tid; j < n; j += 256) zero |= (rdiag[j] == 0) ? 1 : 0;
         const int sing = __syncthreads_or(zero);
         prof.mark(FP_RPACK);
-        // ---- qform: the panels backward, each applied to the rows and columns from its first one on
-        for (int pi = npanels - 1; pi >= 0; pi--) {
-            const int j0 = 16 * pi, np = (n - j0 < 16) ? n - j0 : 16, nch = (n - j0 + 15) >> 4;
+        // ---- qform: the panels backward, TWO per pass over the rows and columns they reach (a strip is read and written once per
+        // pair: half the traffic of the pass); an odd panel count leaves the last panel a pass of its own
+        int pi = npanels - 1;
+        while (pi >= 0) {
+            const bool pair = pi >= 1 && (((pi + 1) & 1) == 0 || pi != npanels - 1);      // (an odd count: the first pass is the last panel alone)
+            const int lo = pair ? pi - 1 : pi, j0 = 16 * lo, nch = (n - j0 + 15) >> 4;
+            const int np_lo = (n - j0 < 16) ? n - j0 : 16, np_hi = pair ? ((n - j0 - 16 < 16) ? n - j0 - 16 : 16) : 0;
+            double *V0 = lds, *T0 = V0 + 16 * NCH * kLdV, *V1 = lds + kPanelDoubles, *T1 = V1 + 16 * NCH * kLdV;
+            // the vectors of both panels with rows relative to the LOWER panel's first row (the upper panel's first 16 rows are zero)
             for (int e = tid; e < nch * 256; e += 256) {
                 const int rr = e >> 4, t = e & 15, row = j0 + rr;
-                const double v = (rr >= t && t < np && row < n) ? A[(long)row * ld + j0 + t] : 0.0;
-                Vl[rr * kLdV + t] = v;
+                V0[rr * kLdV + t] = (rr >= t && t < np_lo && row < n) ? A[(long)row * ld + j0 + t] : 0.0;
+                if (pair) V1[rr * kLdV + t] = (rr - 16 >= t && t < np_hi && row < n) ? A[(long)row * ld + j0 + 16 + t] : 0.0;
             }
-            Tl[(tid & 15) * 16 + (tid >> 4)] = Tsave[256 * pi + tid];            // X = T^T
+            T0[(tid & 15) * 16 + (tid >> 4)] = Tsave[256 * lo + tid];                     // X = T^T
+            if (pair) T1[(tid & 15) * 16 + (tid >> 4)] = Tsave[256 * (lo + 1) + tid];
             __syncthreads();
             prof.mark(FP_QLOAD);
-            // the panel's own columns above its first row held R: zeros of Q now
-            for (int e = tid; e < j0 * 16; e += 256) { const int row = e >> 4, t = e & 15; if (t < np) A[(long)row * ld + j0 + t] = 0.0; }
+            // the panels' own columns above the pass's first row held R: zeros of Q now
+            {
+                const int width = np_lo + np_hi;
+                for (int e = tid; e < j0 * 32; e += 256) { const int row = e >> 5, t = e & 31; if (t < width) A[(long)row * ld + j0 + t] = 0.0; }
+            }
             for (int c0 = j0 + 16 * wave; c0 < n; c0 += 64) {
                 f64x4 S[NCH];
-                if (c0 == j0) {
-                    const int gi = here(g), mi = here(m);
+                if (c0 == j0 || (pair && c0 == j0 + 16)) {
+                    // a panel's own columns start as columns of the identity
+                    const int gi = here(g), mi = here(m), own = (c0 == j0) ? 0 : 1, npo = own ? np_hi : np_lo;
 #pragma unroll
                     for (int cc = 0; cc < NCH; cc++) {
 #pragma unroll
-                        for (int r = 0; r < 4; r++) S[cc][r] = (cc == 0 && gi + 4 * r == mi && mi < np) ? 1.0 : 0.0;
+                        for (int r = 0; r < 4; r++) S[cc][r] = (cc == own && gi + 4 * r == mi && mi < npo) ? 1.0 : 0.0;
                     }
                 } else {
                     strip_load<NCH>(S, A, ld, n, j0, nch, c0, n, g, m);
                 }
-                strip_apply<NCH>(S, nch, Vl, Tl, lane);
+                if (pair && c0 != j0) strip_apply<NCH>(S, nch, V1, T1, lane);           // (the lower panel's own columns are zero where the upper one acts)
+                strip_apply<NCH>(S, nch, V0, T0, lane);
                 strip_store<NCH>(S, A, ld, n, j0, nch, c0, n, g, m);
             }
             prof.mark(FP_QSTRIPS);
             __syncthreads();
             prof.mark(FP_QWAIT);
+            pi = lo - 1;
         }
         if (tid == 0) { states[p].sing = sing ? 1 : 0; states[p].pad = 1; }
         __syncthreads();
@@ -507,7 +592,7 @@ hipError_t raise_lds_limit_fast()
 template <int NCH>
 hipError_t launch_nch(hipStream_t st, const PoolDev &pool, const int *d_list, int count)
 {
-    const size_t lds_bytes = sizeof(double) * (size_t)(16 * NCH * kLdV + 512);
+    const size_t lds_bytes = sizeof(double) * (size_t)(2 * (16 * NCH * kLdV + 256) + 256);
     if (lds_bytes > 65536) {
         const hipError_t raised = raise_lds_limit_fast<factor_fast_kernel<NCH>>();
         if (raised != hipSuccess) return raised;
