@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_build", "libsocp_hip.so")
+LIB_PATH = os.environ.get("SOCP_LIB_PATH") or os.path.join(_HERE, "_build", "libsocp_hip.so")      # (SOCP_LIB_PATH: A/B builds of the library)
 
 OK, ERR_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4
 MODEL_GODDARD, MODEL_DOUBLE_INTEGRATOR, MODEL_COVID19, MODEL_INTERCEPTOR = 1, 2, 3, 4

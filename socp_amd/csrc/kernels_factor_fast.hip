@@ -83,11 +83,11 @@ __device__ __forceinline__ double quad_max(double x)
 }
 // LDS written by some lanes of this wavefront, read by others: the wave's LDS operations execute in order; keep the compiler
 // from moving the reads above the writes
+// (not a memory-model fence: that also waits for the wave's outstanding GLOBAL stores -- a round trip to L2 per column of the panel
+// when one lane stores diag(R) on the way, which was most of the panel's time)
 __device__ __forceinline__ void wave_lds_fence()
 {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
 // A strip: 16 columns c0 .. c0 + 15, rows row0 .. row0 + 16 NCH - 1, four rows per 16-row chunk and lane:
@@ -141,14 +141,21 @@ __device__ __forceinline__ void strip_store(const f64x4 (&S)[NCH], double *__res
     }
 }
 
-// (the scheduler otherwise hoists every LDS read of a pass above the first MFMA -- 4 NCH more doubles per lane beside the strip's
-// 4 NCH -- and spills; a fence every kGroup chunks bounds what is in flight: the next group's operands while this group multiplies)
-constexpr int kGroup = 2;
+// The passes over a strip's chunks run in blocks of kBlk chunks behind ONE uniform test per block (is any of it inside the matrix?):
+// with a test per chunk every chunk is a basic block of its own, the LDS reads of one chunk cannot be issued while the previous
+// chunk still computes, and each pass pays an LDS round trip per chunk -- measured: 6 000 cycles per column of the panel, most of
+// the kernel.  Chunks of a block beyond the last row compute on zeros (the strip's registers and V's rows there are zero).  The
+// block also bounds what the scheduler may hoist: 4 kBlk operands in flight beside the strip's 4 NCH registers.
+#ifndef SOCP_FACTOR_BLK
+#define SOCP_FACTOR_BLK 4
+#endif
+constexpr int kBlk = SOCP_FACTOR_BLK;
 #define SOCP_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+__device__ __forceinline__ int blocks_of(int nch) { return (nch + kBlk - 1) / kBlk * kBlk; }      // chunks the passes touch
 
-// S <- (I - V X^T V^T) S for the panel in LDS: Vl[row][kLdV] (rows relative to the panel's first row, zero above the diagonal),
-// Xl[16][16] row-major (X = T applies H_last .. H_first, i.e. the panel's Q^T: qrfac; X = T^T applies the panel's Q: qform).
-// S in the MFMA layout (g = lane >> 4, m = lane & 15).
+// S <- (I - V X^T V^T) S for the panel in LDS: Vl[row][kLdV] (rows relative to the panel's first row, zero above the diagonal and
+// from the matrix's last row to the end of the block of chunks), Xl[16][16] row-major (X = T applies H_last .. H_first, i.e. the
+// panel's Q^T: qrfac; X = T^T applies the panel's Q: qform).  S in the MFMA layout (g = lane >> 4, m = lane & 15).
 template <int NCH>
 __device__ __forceinline__ void strip_apply(f64x4 (&S)[NCH], int nch, const double *Vl, const double *Xl, int lane)
 {
@@ -157,12 +164,18 @@ __device__ __forceinline__ void strip_apply(f64x4 (&S)[NCH], int nch, const doub
     const double *vw = Vl + g * kLdV + m;                                    // W = V^T S:  A operand V(row of K slot g, m)
     f64x4 W = {0, 0, 0, 0};
 #pragma unroll
-    for (int cc = 0; cc < NCH; cc++) {
-        if (cc < nch) {
+    for (int cb = 0; cb < NCH; cb += kBlk) {
+        if (cb < nch) {
+            // the block's operands first, ALL of them in flight, then the products: left to itself the compiler, short of registers,
+            // reuses one register pair for every read and waits for each read before the next (an LDS round trip per operand)
+            double a[4 * kBlk];
 #pragma unroll
-            for (int r = 0; r < 4; r++) W = mfma(vw[(16 * cc + 4 * r) * kLdV], S[cc][r], W);            // B: the strip itself, K slot g = row g + 4 r of the chunk
+            for (int q = 0; q < 4 * kBlk; q++) a[q] = vw[(16 * cb + 4 * q) * kLdV];
+            SOCP_SCHED_FENCE();
+#pragma unroll
+            for (int q = 0; q < 4 * kBlk; q++) if (cb + q / 4 < NCH) W = mfma(a[q], S[cb + q / 4][q % 4], W);   // B: the strip itself, K slot g = row g + 4 r of the chunk
+            SOCP_SCHED_FENCE();
         }
-        if (cc % kGroup == kGroup - 1) SOCP_SCHED_FENCE();
     }
     f64x4 Y = {0, 0, 0, 0};
 #pragma unroll
@@ -172,14 +185,47 @@ __device__ __forceinline__ void strip_apply(f64x4 (&S)[NCH], int nch, const doub
     SOCP_SCHED_FENCE();
     const double *vu = Vl + m * kLdV + g;                                    // S -= V Y:  A operand V(16 cc + m, k = g + 4 r)
 #pragma unroll
-    for (int cc = 0; cc < NCH; cc++) {
-        if (cc < nch) {
+    for (int cb = 0; cb < NCH; cb += kBlk) {
+        if (cb < nch) {
+            double a[4 * kBlk];
 #pragma unroll
-            for (int r = 0; r < 4; r++) S[cc] = mfma(vu[16 * cc * kLdV + 4 * r], Y[r], S[cc]);          // B: -Y(k, m)
+            for (int q = 0; q < 4 * kBlk; q++) a[q] = vu[16 * (cb + q / 4) * kLdV + 4 * (q % 4)];
+            SOCP_SCHED_FENCE();
+#pragma unroll
+            for (int q = 0; q < 4 * kBlk; q++) if (cb + q / 4 < NCH) S[cb + q / 4] = mfma(a[q], Y[q % 4], S[cb + q / 4]);   // B: -Y(k, m)
+            SOCP_SCHED_FENCE();
         }
-        if (cc % kGroup == kGroup - 1) SOCP_SCHED_FENCE();
     }
 }
+
+// Development aid (-DSOCP_FACTOR_PROFILE): lane 0 of wave 0 of every workgroup adds the clock ticks between marks to per-phase totals
+// (read_factor_profile; scripts/measure_factor.py prints them).  Compiled out otherwise.
+#ifdef SOCP_FACTOR_PROFILE
+__device__ unsigned long long g_fprof[16];
+struct FProf {
+    unsigned long long t;
+    bool on;
+    __device__ explicit FProf(int tid) : t(clock64()), on(tid == 0) {}
+    __device__ void mark(int slot)
+    {
+        const unsigned long long now = clock64();
+        if (on) atomicAdd(&g_fprof[slot], now - t);
+        t = now;
+    }
+    // a nested measurement that leaves the outer one running: add the ticks since `from` to `slot`
+    __device__ unsigned long long stamp() const { return clock64(); }
+    __device__ void add(int slot, unsigned long long from) { if (on) atomicAdd(&g_fprof[slot], clock64() - from); }
+};
+#else
+struct FProf {
+    __device__ explicit FProf(int) {}
+    __device__ void mark(int) {}
+    __device__ unsigned long long stamp() const { return 0; }
+    __device__ void add(int, unsigned long long) {}
+};
+#endif
+enum { FP_NORMS = 0, FP_PANEL = 1, FP_PANEL_WAIT = 2, FP_TRAIL = 3, FP_TRAIL_WAIT = 4, FP_RPACK = 5, FP_QLOAD = 6, FP_QSTRIPS = 7, FP_QWAIT = 8,
+       FP_LA_APPLY = 9, FP_LA_CONVERT = 10, FP_COLS = 11, FP_LA_STORE = 12, FP_T = 13, FP_COL_NORM = 14, FP_COL_APPLY = 15 };
 
 // 1 / x and 1 / sqrt(x) to double precision from the hardware estimates (relative error ~2^-24) in one cubic step each (error ~1e-22);
 // for arguments well inside the exponent range only -- the callers below check that
@@ -199,13 +245,12 @@ __device__ __forceinline__ double rsqrt_in_range(double x)
 // A panel of 16 columns (np of them reflectors) held by ONE wavefront in registers, a column's four row groups in one quad of lanes
 // (g = lane & 3, m = lane >> 2: P[cc][reg] = entry (16 cc + g + 4 reg, m) of the panel, row 0 = the panel's first diagonal row): the
 // norm and the dot products are reduced with two quad permutes each.  Factorises it in place (R above the diagonal, the vectors
-// from the diagonal down, as MINPACK stores them) and leaves rdiag[0 .. np), V (zero above the diagonal) and T in LDS, T also in
-// Tsave (row-major 16 x 16) for qform.
+// from the diagonal down, as MINPACK stores them) and leaves rdiag[0 .. np) and V (zero above the diagonal) in LDS; returns tau_t in
+// lane t (panel_T's input).
 template <int NCH>
-__device__ __forceinline__ void panel_core(f64x4 (&S)[NCH], int np, int nch, double *Vl, double *Tl, double *Gl, double *__restrict__ rdiag,
-                                           double *__restrict__ Tsave, int lane)
+__device__ __forceinline__ double panel_core(f64x4 (&S)[NCH], int np, int nch, double *Vl, double *__restrict__ rdiag, int lane, FProf &prof)
 {
-    double tau_mine = 0.0;                                                   // lane t (t < 16) keeps tau_t
+    double tau_mine = 0.0, rdiag_mine = 0.0;                                 // lane t (t < 16) keeps tau_t and diag(R)_t
     // a real loop over the panel's columns (unrolled 16 times the body exceeds what the compiler will unroll, and then every
     // "constant" index below becomes a run-time register index, i.e. scratch): t is uniform, lanes and registers are SELECTED
 #pragma unroll 1
@@ -214,6 +259,7 @@ __device__ __forceinline__ void panel_core(f64x4 (&S)[NCH], int np, int nch, dou
         const int g = lane & 3, m = lane >> 2;
         bool live = t < np;
         double ajnorm = 0.0, ajj = 0.0, inv = 0.0, s1 = 1.0;
+        const unsigned long long t_col = prof.stamp();
         if (live) {
             // |column t| over the rows from the diagonal down (row >= t: a question in chunk 0 only); every lane does its own
             // column, the quad of column t is the one that counts.  Four partial sums: the chain of dependent adds is the latency.
@@ -223,10 +269,13 @@ __device__ __forceinline__ void panel_core(f64x4 (&S)[NCH], int np, int nch, dou
             { const double x = (g + 8 >= t) ? S[0][2] : 0.0; q2 = x * x; }
             { const double x = (g + 12 >= t) ? S[0][3] : 0.0; q3 = x * x; }
 #pragma unroll
-            for (int cc = 1; cc < NCH; cc++) {
-                if (cc < nch) {
-                    q0 = __builtin_fma(S[cc][0], S[cc][0], q0); q1 = __builtin_fma(S[cc][1], S[cc][1], q1);
-                    q2 = __builtin_fma(S[cc][2], S[cc][2], q2); q3 = __builtin_fma(S[cc][3], S[cc][3], q3);
+            for (int cb = 0; cb < NCH; cb += kBlk) {                         // (chunks of a block beyond the matrix hold zeros)
+                if (cb < nch) {
+#pragma unroll
+                    for (int cc = (cb ? cb : 1); cc < cb + kBlk && cc < NCH; cc++) {
+                        q0 = __builtin_fma(S[cc][0], S[cc][0], q0); q1 = __builtin_fma(S[cc][1], S[cc][1], q1);
+                        q2 = __builtin_fma(S[cc][2], S[cc][2], q2); q3 = __builtin_fma(S[cc][3], S[cc][3], q3);
+                    }
                 }
             }
             const double ss = from_lane(quad_sum((q0 + q1) + (q2 + q3)), 4 * t);
@@ -269,7 +318,7 @@ __device__ __forceinline__ void panel_core(f64x4 (&S)[NCH], int np, int nch, dou
             const double diag_reg = rsel == 0 ? S[0][0] : rsel == 1 ? S[0][1] : rsel == 2 ? S[0][2] : S[0][3];
             ajj = from_lane(diag_reg, 4 * t + (t & 3));
             if (ajnorm != 0 && ajj < 0) ajnorm = -ajnorm;
-            if (lane == 0) rdiag[t] = -ajnorm;
+            if (lane == t) rdiag_mine = -ajnorm;                             // (stored after the loop: no global store inside it)
             live = ajnorm != 0;
             // 1 / ajnorm: the quick reciprocal where the sum of squares was in range (|ajnorm| in 1e-140 .. 1e140); otherwise a
             // division, of ajnorm 2^600 when ajnorm is so small that its reciprocal would overflow (s1 is 1 in every other case)
@@ -280,6 +329,7 @@ __device__ __forceinline__ void panel_core(f64x4 (&S)[NCH], int np, int nch, dou
                 inv = 1.0 / (ajnorm * s1);
             }
         }
+        prof.add(FP_COL_NORM, t_col);
         double tau_t = 0.0;
         if (live) {
             const double vjj = (ajj * s1) * inv + 1.0;                       // in [1, 2]: ajnorm carries a(j, j)'s sign
@@ -296,10 +346,13 @@ __device__ __forceinline__ void panel_core(f64x4 (&S)[NCH], int np, int nch, dou
                 S[0][r] = (mine && rr == t) ? x + 1.0 : x;
             }
 #pragma unroll
-            for (int cc = 1; cc < NCH; cc++) {
-                if (cc < nch) {
+            for (int cb = 0; cb < NCH; cb += kBlk) {
+                if (cb < nch) {
 #pragma unroll
-                    for (int r = 0; r < 4; r++) S[cc][r] = (S[cc][r] * f1) * f2;
+                    for (int cc = (cb ? cb : 1); cc < cb + kBlk && cc < NCH; cc++) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) S[cc][r] = (S[cc][r] * f1) * f2;
+                    }
                 }
             }
         }
@@ -310,55 +363,85 @@ __device__ __forceinline__ void panel_core(f64x4 (&S)[NCH], int np, int nch, dou
 #pragma unroll
             for (int r = 0; r < 4; r++) vp[4 * r * kLdV] = (live && g + 4 * r >= t) ? S[0][r] : 0.0;
 #pragma unroll
-            for (int cc = 1; cc < NCH; cc++) {
-                if (cc < nch) {
+            for (int cb = 0; cb < NCH; cb += kBlk) {
+                if (cb < nch) {
 #pragma unroll
-                    for (int r = 0; r < 4; r++) vp[(16 * cc + 4 * r) * kLdV] = live ? S[cc][r] : 0.0;
+                    for (int cc = (cb ? cb : 1); cc < cb + kBlk && cc < NCH; cc++) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) vp[(16 * cc + 4 * r) * kLdV] = live ? S[cc][r] : 0.0;
+                    }
                 }
             }
         }
         wave_lds_fence();
+        const unsigned long long t_apply = prof.stamp();
         if (live) {
             // the later columns of the strip through reflector t:  a -= v (v . a) / v_t
             const double *vp = Vl + g * kLdV + t;
             double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
 #pragma unroll
-            for (int cc = 0; cc < NCH; cc++) {
-                if (cc < nch) {
-                    d0 = __builtin_fma(vp[(16 * cc) * kLdV], S[cc][0], d0); d1 = __builtin_fma(vp[(16 * cc + 4) * kLdV], S[cc][1], d1);
-                    d2 = __builtin_fma(vp[(16 * cc + 8) * kLdV], S[cc][2], d2); d3 = __builtin_fma(vp[(16 * cc + 12) * kLdV], S[cc][3], d3);
+            for (int cb = 0; cb < NCH; cb += kBlk) {
+                if (cb < nch) {
+                    double v[4 * kBlk];                                      // (all reads of the block in flight: see strip_apply)
+#pragma unroll
+                    for (int q = 0; q < 4 * kBlk; q++) v[q] = vp[(16 * cb + 4 * q) * kLdV];
+                    SOCP_SCHED_FENCE();
+#pragma unroll
+                    for (int q = 0; q < 4 * kBlk; q += 4) {
+                        if (cb + q / 4 < NCH) {
+                            d0 = __builtin_fma(v[q], S[cb + q / 4][0], d0); d1 = __builtin_fma(v[q + 1], S[cb + q / 4][1], d1);
+                            d2 = __builtin_fma(v[q + 2], S[cb + q / 4][2], d2); d3 = __builtin_fma(v[q + 3], S[cb + q / 4][3], d3);
+                        }
+                    }
+                    SOCP_SCHED_FENCE();
                 }
-                if (cc % kGroup == kGroup - 1) SOCP_SCHED_FENCE();
             }
             const double dot = quad_sum((d0 + d1) + (d2 + d3));
             const double coef = (m > t) ? dot * tau_t : 0.0;
             wave_lds_fence();                                                // (re-read v below rather than hold 4 NCH more registers)
 #pragma unroll
-            for (int cc = 0; cc < NCH; cc++) {
-                if (cc < nch) {
+            for (int cb = 0; cb < NCH; cb += kBlk) {
+                if (cb < nch) {
+                    double v[4 * kBlk];
 #pragma unroll
-                    for (int r = 0; r < 4; r++) S[cc][r] = __builtin_fma(-coef, vp[(16 * cc + 4 * r) * kLdV], S[cc][r]);
+                    for (int q = 0; q < 4 * kBlk; q++) v[q] = vp[(16 * cb + 4 * q) * kLdV];
+                    SOCP_SCHED_FENCE();
+#pragma unroll
+                    for (int q = 0; q < 4 * kBlk; q++) if (cb + q / 4 < NCH) S[cb + q / 4][q % 4] = __builtin_fma(-coef, v[q], S[cb + q / 4][q % 4]);
+                    SOCP_SCHED_FENCE();
                 }
-                if (cc % kGroup == kGroup - 1) SOCP_SCHED_FENCE();
             }
         }
+        prof.add(FP_COL_APPLY, t_apply);
     }
-    // G = V^T V on the matrix cores, then larft's recurrence: T(i, t) = -tau_t sum_{k = i}^{t - 1} T(i, k) G(k, t), T(t, t) = tau_t
+    if (lane < np) rdiag[lane] = rdiag_mine;
+    return tau_mine;
+}
+
+// ... and the panel's T of  H_first .. H_last = I - V T V^T: G = V^T V on the matrix cores, then larft's recurrence
+// T(i, t) = -tau_t sum_{k = i}^{t - 1} T(i, k) G(k, t), T(t, t) = tau_t.  Called AFTER the strip has gone home: with the strip's
+// 4 NCH registers still live beside it the recurrence spilled a hundred registers per panel, and those round trips to scratch
+// memory were most of a panel's time.
+template <int NCH>
+__device__ __forceinline__ void panel_T(int nch, double tau_mine, const double *Vl, double *Tl, double *Gl, double *__restrict__ Tsave, int lane)
+{
     lane = here(lane);
     {
         const int g = lane >> 4, m = lane & 15;
         const double *vw = Vl + g * kLdV + m;
         f64x4 G = {0, 0, 0, 0};
 #pragma unroll
-        for (int cc = 0; cc < NCH; cc++) {
-            if (cc < nch) {
+        for (int cb = 0; cb < NCH; cb += kBlk) {
+            if (cb < nch) {
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const double v = vw[(16 * cc + 4 * r) * kLdV];
-                    G = mfma(v, v, G);
+                for (int cc = cb; cc < cb + kBlk && cc < NCH; cc++) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const double v = vw[(16 * cc + 4 * r) * kLdV];
+                        G = mfma(v, v, G);
+                    }
                 }
             }
-            if (cc % kGroup == kGroup - 1) SOCP_SCHED_FENCE();
         }
 #pragma unroll
         for (int r = 0; r < 4; r++) Gl[(g + 4 * r) * 16 + m] = G[r];
@@ -390,29 +473,6 @@ __device__ __forceinline__ double to_quad_layout(double x, int lane)
     const int src = 16 * (lane & 3) + (lane >> 2);
     return __shfl(x, src);
 }
-
-// Development aid (-DSOCP_FACTOR_PROFILE): lane 0 of wave 0 of every workgroup adds the clock ticks between marks to per-phase totals
-// (read_factor_profile; scripts/measure_factor.py prints them).  Compiled out otherwise.
-#ifdef SOCP_FACTOR_PROFILE
-__device__ unsigned long long g_fprof[16];
-struct FProf {
-    unsigned long long t;
-    bool on;
-    __device__ explicit FProf(int tid) : t(clock64()), on(tid == 0) {}
-    __device__ void mark(int slot)
-    {
-        const unsigned long long now = clock64();
-        if (on) atomicAdd(&g_fprof[slot], now - t);
-        t = now;
-    }
-};
-#else
-struct FProf {
-    __device__ explicit FProf(int) {}
-    __device__ void mark(int) {}
-};
-#endif
-enum { FP_NORMS = 0, FP_PANEL = 1, FP_PANEL_WAIT = 2, FP_TRAIL = 3, FP_TRAIL_WAIT = 4, FP_RPACK = 5, FP_QLOAD = 6, FP_QSTRIPS = 7, FP_QWAIT = 8 };
 
 // One workgroup of 256 threads per problem.  LDS (doubles): two panels' V[16 NCH][kLdV] and T[256] (qrfac: the panel being applied and
 // the next one being factorised -- look-ahead; qform: the two panels applied in one pass), Gl[256]
@@ -463,8 +523,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             f64x4 P[NCH];
             const int np0 = n < 16 ? n : 16, nch0 = (n + 15) >> 4;
             strip_load<NCH>(P, A, ld, n, 0, nch0, 0, n + 1, lane & 3, lane >> 2);          // (column n = fvec rides along when it falls into this strip)
-            panel_core<NCH>(P, np0, nch0, lds, lds + 16 * NCH * kLdV, Gl, rdiag, Tsave, lane);
+            const double tau = panel_core<NCH>(P, np0, nch0, lds, rdiag, lane, prof);
             strip_store<NCH>(P, A, ld, n, 0, nch0, 0, n + 1, lane & 3, lane >> 2);
+            panel_T<NCH>(nch0, tau, lds, lds + 16 * NCH * kLdV, Gl, Tsave, lane);
         }
         prof.mark(FP_PANEL);
         __syncthreads();
@@ -478,8 +539,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                                                                              // share a CU, their serial parts should not share a SIMD)
             if (has_next && wave == ahead) {
                 f64x4 S[NCH];
+                const unsigned long long t_la = prof.stamp();
                 strip_load<NCH>(S, A, ld, n, j0, nch, j0 + 16, n + 1, g, m);
                 strip_apply<NCH>(S, nch, Vc, Tc, lane);
+                prof.add(FP_LA_APPLY, t_la);
+                const unsigned long long t_cv = prof.stamp();
                 // its first 16 rows are rows of R now: they go home; the rest is the next panel, in the panel layout
                 {
                     const int col = j0 + 16 + here(m);
@@ -497,8 +561,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
                 S[NCH - 1] = f64x4{0, 0, 0, 0};
                 const int j1 = j0 + 16, np1 = (n - j1 < 16) ? n - j1 : 16;
-                panel_core<NCH>(S, np1, nch - 1, Vn, Tn, Gl, rdiag + j1, Tsave + 256 * (pi + 1), lane);
+                prof.add(FP_LA_CONVERT, t_cv);
+                const unsigned long long t_cols = prof.stamp();
+                const double tau = panel_core<NCH>(S, np1, nch - 1, Vn, rdiag + j1, lane, prof);
+                prof.add(FP_COLS, t_cols);
+                const unsigned long long t_st = prof.stamp();
                 strip_store<NCH>(S, A, ld, n, j1, nch - 1, j1, n + 1, lane & 3, lane >> 2);
+                prof.add(FP_LA_STORE, t_st);
+                const unsigned long long t_T = prof.stamp();
+                panel_T<NCH>(nch - 1, tau, Vn, Tn, Gl, Tsave + 256 * (pi + 1), lane);
+                prof.add(FP_T, t_T);
                 prof.mark(FP_PANEL);
             } else {
                 // the trailing strips: three wavefronts while one runs ahead, all four for the last panel
@@ -534,7 +606,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int np_lo = (n - j0 < 16) ? n - j0 : 16, np_hi = pair ? ((n - j0 - 16 < 16) ? n - j0 - 16 : 16) : 0;
             double *V0 = lds, *T0 = V0 + 16 * NCH * kLdV, *V1 = lds + kPanelDoubles, *T1 = V1 + 16 * NCH * kLdV;
             // the vectors of both panels with rows relative to the LOWER panel's first row (the upper panel's first 16 rows are zero)
-            for (int e = tid; e < nch * 256; e += 256) {
+            const int nchb = blocks_of(nch) < NCH ? blocks_of(nch) : NCH;                // (rows from the matrix's end to the block's end: zeros)
+            for (int e = tid; e < nchb * 256; e += 256) {
                 const int rr = e >> 4, t = e & 15, row = j0 + rr;
                 V0[rr * kLdV + t] = (rr >= t && t < np_lo && row < n) ? A[(long)row * ld + j0 + t] : 0.0;
                 if (pair) V1[rr * kLdV + t] = (rr - 16 >= t && t < np_hi && row < n) ? A[(long)row * ld + j0 + 16 + t] : 0.0;
@@ -630,8 +703,11 @@ hipError_t launch_factor_fast(hipStream_t st, const PoolDev &pool, const int *d_
     if (count <= 0) return hipSuccess;
     const int n = pool.cfg.n;
     if (!fast_factor_applies(n) || pool.cfg.ld < n + 1) return hipErrorInvalidValue;
+    // the strip's register count follows the problem size: 16 rows per chunk
     if (n <= 64) return launch_nch<4>(st, pool, d_list, count);
+    if (n <= 96) return launch_nch<6>(st, pool, d_list, count);
     if (n <= 128) return launch_nch<8>(st, pool, d_list, count);
+    if (n <= 192) return launch_nch<12>(st, pool, d_list, count);
     return launch_nch<16>(st, pool, d_list, count);
 }
 
