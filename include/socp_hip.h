@@ -219,7 +219,9 @@ int socp_fd_diff_dev(socp_ctx *ctx, int np, const double *d_Z, double epsfcn, co
 
 /* replaces: shooting::ShootingFunctionJacobian (shooting.cpp:996-1130), variational Jacobian
  * for models with modelOrder == 1 (socp_ctx_has_variational); fjac column-major as handed to hybrj (shooting.cpp:889-893).
- * The variational state is integrated with fixed-step RK4 only: SOCP_ERR_UNSUPPORTED under SOCP_INT_DOPRI5. */
+ * The variational state follows the context's integrator (socp_ctx_set_integrator): fixed-step RK4, or -- as the reference does
+ * for EVERY integrate() call when built with -D_USE_BOOST, odeTools.cpp:129-134 -- adaptive Dormand-Prince on the whole augmented
+ * state, one wavefront per trajectory with per-wave step control ([ext] parity unpinned, like the state-only adaptive path). */
 int socp_var_jacobian(socp_ctx *ctx, const double *z, double *fjac);
 /* The same for `np` unknown vectors of one problem structure, device pointers: Z[np][n] -> Fjac[np][n*n]; one wavefront per
  * (problem, segment); per-problem blocks (socp_problem_set_blocks_dev) apply. */

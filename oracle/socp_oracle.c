@@ -372,7 +372,7 @@ long orc_integrate(const orc_model *m, double *X, double t0, double tf, double d
  * default_step_adjuster: reject -> dt *= max(0.9 err^(-1/3), 1/5); accept and err < 0.5 ->
  * dt *= 0.9 max(5^-5, err)^(-1/5); integrate_adaptive with a dense-output stepper: step while
  * t + dt <= tf, then re-initialise with dt = tf - t (which also drops the FSAL derivative). */
-static int dopri5_try_step(const orc_model *m, int n, const double *x, const double *k1, double *t, double *dt,
+static int dopri5_try_step(const orc_model *m, int n, int is_jac, const double *x, const double *k1, double *t, double *dt,
                            double tol, double *xnew, double *knew)
 {
     static const double a2 = 1.0 / 5, a3 = 3.0 / 10, a4 = 4.0 / 5, a5 = 8.0 / 9;
@@ -385,17 +385,17 @@ static int dopri5_try_step(const orc_model *m, int n, const double *x, const dou
     double k2[ORC_MAX_LEN], k3[ORC_MAX_LEN], k4[ORC_MAX_LEN], k5[ORC_MAX_LEN], k6[ORC_MAX_LEN], y[ORC_MAX_LEN];
     const double h = *dt, tt = *t;
     for (int i = 0; i < n; i++) y[i] = 1.0 * x[i] + h * b21 * k1[i];
-    orc_rhs(m, tt + h * a2, y, 0, k2);
+    orc_rhs(m, tt + h * a2, y, is_jac, k2);
     for (int i = 0; i < n; i++) y[i] = 1.0 * x[i] + h * b31 * k1[i] + h * b32 * k2[i];
-    orc_rhs(m, tt + h * a3, y, 0, k3);
+    orc_rhs(m, tt + h * a3, y, is_jac, k3);
     for (int i = 0; i < n; i++) y[i] = 1.0 * x[i] + h * b41 * k1[i] + h * b42 * k2[i] + h * b43 * k3[i];
-    orc_rhs(m, tt + h * a4, y, 0, k4);
+    orc_rhs(m, tt + h * a4, y, is_jac, k4);
     for (int i = 0; i < n; i++) y[i] = 1.0 * x[i] + h * b51 * k1[i] + h * b52 * k2[i] + h * b53 * k3[i] + h * b54 * k4[i];
-    orc_rhs(m, tt + h * a5, y, 0, k5);
+    orc_rhs(m, tt + h * a5, y, is_jac, k5);
     for (int i = 0; i < n; i++) y[i] = 1.0 * x[i] + h * b61 * k1[i] + h * b62 * k2[i] + h * b63 * k3[i] + h * b64 * k4[i] + h * b65 * k5[i];
-    orc_rhs(m, tt + h, y, 0, k6);
+    orc_rhs(m, tt + h, y, is_jac, k6);
     for (int i = 0; i < n; i++) xnew[i] = 1.0 * x[i] + h * c1 * k1[i] + h * c3 * k3[i] + h * c4 * k4[i] + h * c5 * k5[i] + h * c6 * k6[i];
-    orc_rhs(m, tt + h, xnew, 0, knew);
+    orc_rhs(m, tt + h, xnew, is_jac, knew);
     double err = 0;
     for (int i = 0; i < n; i++) {
         double e = h * dc1 * k1[i] + h * dc3 * k3[i] + h * dc4 * k4[i] + h * dc5 * k5[i] + h * dc6 * k6[i] + h * dc7 * knew[i];
@@ -416,10 +416,27 @@ static int dopri5_try_step(const orc_model *m, int n, const double *x, const dou
     return 1;
 }
 
+/* the same on the AUGMENTED state [X ; dX/dX0] (is_jac = 1): with -D_USE_BOOST every integrate() call of the reference goes through
+ * the adaptive stepper, the variational trajectories of the hybrj path included (odeTools.cpp:129-134, model.hpp:395-414,
+ * shooting.cpp:996-1130), the error norm taken over all (2d + 1) 2d entries.  [ext] parity unpinned like the state-only form. */
+static long integrate_dopri5_any(orc_model *m, int is_jac, double *X, double t0, double tf, double dt, double tol, long *rejected,
+                                 orc_step_hook hook);
+
 long orc_integrate_dopri5_hook(orc_model *m, double *X, double t0, double tf, double dt, double tol, long *rejected,
                                orc_step_hook hook)
 {
-    const int n = 2 * m->dim;
+    return integrate_dopri5_any(m, 0, X, t0, tf, dt, tol, rejected, hook);
+}
+
+long orc_integrate_dopri5_jac(const orc_model *m, double *X, double t0, double tf, double dt, double tol, long *rejected)
+{
+    return integrate_dopri5_any((orc_model *)m, 1, X, t0, tf, dt, tol, rejected, 0);
+}
+
+static long integrate_dopri5_any(orc_model *m, int is_jac, double *X, double t0, double tf, double dt, double tol, long *rejected,
+                                 orc_step_hook hook)
+{
+    const int n = orc_state_len(m, is_jac);
     const double eps = DBL_EPSILON;
     double k1[ORC_MAX_LEN], xn[ORC_MAX_LEN], kn[ORC_MAX_LEN];
     double t = t0, h = dt;
@@ -429,10 +446,10 @@ long orc_integrate_dopri5_hook(orc_model *m, double *X, double t0, double tf, do
     while (tf - t > eps && budget > 0) {                              /* less_with_sign(t, tf, dt) */
         while (t + h - tf <= eps && budget > 0) {                     /* less_eq_with_sign(t + dt, tf, dt) */
             if (hook && hook(m, t, X)) have_k1 = 0;
-            if (!have_k1) { orc_rhs(m, t, X, 0, k1); have_k1 = 1; }
+            if (!have_k1) { orc_rhs(m, t, X, is_jac, k1); have_k1 = 1; }
             int tries = 0, ok;
             do {
-                ok = dopri5_try_step(m, n, X, k1, &t, &h, tol, xn, kn);
+                ok = dopri5_try_step(m, n, is_jac, X, k1, &t, &h, tol, xn, kn);
                 budget--;
                 if (!ok) rej++;
             } while (!ok && ++tries < 500);
@@ -475,10 +492,11 @@ void orc_compute_traj(orc_model *m, double t0, const double *X0, double tf, int 
         memcpy(X, X0, sizeof(X));
         if (m->integrator == 1) orc_interceptor_compute_traj_adaptive(m, t0, X, tf, m->tol, Xf);
         else orc_interceptor_compute_traj(m, t0, X, tf, Xf);
-    } else if (m->integrator == 1 && !is_jac) {
-        int n = 2 * m->dim;
+    } else if (m->integrator == 1) {
+        int n = orc_state_len(m, is_jac);
         if (Xf != X0) memcpy(Xf, X0, sizeof(double) * n);
-        orc_integrate_dopri5(m, Xf, t0, tf, (tf - t0) / m->step_nbr, m->tol, 0);
+        if (is_jac) orc_integrate_dopri5_jac(m, Xf, t0, tf, (tf - t0) / m->step_nbr, m->tol, 0);
+        else orc_integrate_dopri5(m, Xf, t0, tf, (tf - t0) / m->step_nbr, m->tol, 0);
     } else {
         orc_model_int(m, t0, X0, tf, is_jac, Xf);
     }
@@ -761,7 +779,7 @@ void orc_shooting_jacobian(orc_model *m, const orc_problem *p, const double *z, 
     int nbr = s * M;
     for (int i = 0; i < M; i++) {
         double t1 = tl[i], t2 = tl[i + 1];
-        orc_model_int(m, t1, X1, t2, 1, Xtf);
+        orc_compute_traj(m, t1, X1, t2, 1, Xtf);                          /* Move(..., isJac = 1) -> model::ComputeTraj: the selected integrator */
         int index = s * (i + 1);
         if (i == 0) {
             if (p->mode_t[0] == ORC_FIXED) {

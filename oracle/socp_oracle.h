@@ -84,6 +84,9 @@ long orc_model_int(const orc_model *m, double t0, const double *X0, double tf, i
  * (controlled Dormand-Prince 5(4) with FSAL); validated by tolerance only.
  * Returns accepted steps; *rejected (may be NULL) counts rejected trial steps. */
 long orc_integrate_dopri5(const orc_model *m, double *X, double t0, double tf, double dt, double tol, long *rejected);
+/* ... on the augmented state [X ; dX/dX0] of the hybrj path (is_jac = 1 trajectories: odeTools.cpp:129-134 makes no difference
+ * between the two under -D_USE_BOOST); parity unpinned like the state-only form */
+long orc_integrate_dopri5_jac(const orc_model *m, double *X, double t0, double tf, double dt, double tol, long *rejected);
 /* The same loop with a hook called before every step (may be NULL); a hook that rewrites X (the interceptor's chart
  * change, interceptor.cpp:953-978) returns 1 and the FSAL derivative is recomputed.  At most ORC_ADAPTIVE_BUDGET trial
  * steps per call, then the state is NaN (odeint's step_adjustment_error; the device kernels do the same). */

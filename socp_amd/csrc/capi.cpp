@@ -423,8 +423,6 @@ int socp_integrate_batch_dev(socp_ctx *c, int B, const double *d_t0, const doubl
     if (!c) return SOCP_ERR_ARG;
     if (B < 0 || (B > 0 && (!d_t0 || !d_tf || !d_X0 || !d_Xf))) return fail(c, SOCP_ERR_ARG, "integrate_batch: null argument");
     HIP_TRY(c, hipSetDevice(c->device));
-    if (is_jac && c->P.integrator != SOCP_INT_RK4)
-        return fail(c, SOCP_ERR_UNSUPPORTED, "integrate_batch: the variational state is integrated with fixed-step RK4 only");
     if (is_jac) {
         // variational state: one wavefront per trajectory (doubleIntegrator; goddard has modelOrder 0 only)
         if (!has_var(c))
@@ -883,8 +881,6 @@ int socp_var_jacobian_multi_dev(socp_ctx *c, int np, const double *d_Z, double *
     if (np < 0 || (np > 0 && (!d_Z || !d_Fjac))) return fail(c, SOCP_ERR_ARG, "var_jacobian: null argument");
     if (!has_var(c))
         return fail(c, SOCP_ERR_UNSUPPORTED, "var_jacobian: this model has no variational equations (modelOrder 0)");
-    if (c->P.integrator != SOCP_INT_RK4)
-        return fail(c, SOCP_ERR_UNSUPPORTED, "var_jacobian: the variational state is integrated with fixed-step RK4 only");
     if (np == 0) return SOCP_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t M = c->M, L = (size_t)(c->S + 1) * c->S, B = (size_t)np * M;

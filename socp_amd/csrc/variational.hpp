@@ -8,7 +8,8 @@
 // (d/dt R = (df/dX) R couples rows), and the three costates the control law reads.  Operation
 // order per element is the reference's (odeTools.cpp:89-98; doubleIntegrator.cpp:113-213), the
 // translation unit is compiled -ffp-contract=off; the path contains no exp, so results are
-// bit-identical to the x86 path.
+// bit-identical to the x86 path.  Under the adaptive integrator (SOCP_INT_DOPRI5) the same wavefront-per-trajectory form
+// runs Dormand-Prince 5(4) with per-WAVE step control: traj_var_wave_dopri5_kernel.
 #pragma once
 #include "dev_common.hpp"
 
@@ -73,6 +74,136 @@ __global__ __launch_bounds__(64) void traj_var_wave_kernel(ModelParams P, const 
     }
 #pragma unroll
     for (int k = 0; k < K; k++) { const int e = lane + 64 * k; if (e < L) Xf[b * L + e] = X[k]; }
+}
+
+// The same trajectories under the ADAPTIVE integrator -- what the reference runs for every integrate() call when built with
+// -D_USE_BOOST, the isJac = 1 ones of the hybrj path included (odeTools.cpp:129-134; default ModelInt model.hpp:395-414; caller
+// shooting.cpp:996-1130): Dormand-Prince 5(4) on the whole augmented state, the error norm max_i |e_i| / (tol + tol (|x_i| + h |k1_i|))
+// over all (s + 1) s entries.  One wavefront per trajectory as above, step control PER WAVE: every lane computes its elements'
+// share of the norm, a wave-wide maximum makes it uniform, and the whole wave accepts, rejects and resizes together.  The
+// controller, the stage sums and the step budget are those of Lane::dopri5_try / integrate_dopri5 (integrator.hpp) element for
+// element -- a restatement of Boost.Odeint's published algorithm, [ext] PARITY UNPINNED.
+template <class Mdl>
+__global__ __launch_bounds__(64) void traj_var_wave_dopri5_kernel(ModelParams P, const double *__restrict__ t0,
+                                                                  const double *__restrict__ tf,
+                                                                  const double *__restrict__ X0,
+                                                                  double *__restrict__ Xf,
+                                                                  const double *__restrict__ pp_params, int pp_stride, int M)
+{
+    constexpr int L = (Mdl::S + 1) * Mdl::S;
+    constexpr int K = (L + 63) / 64;
+    constexpr int kBudget = 50000;                     // trial steps per segment (integrator.hpp: kAdaptiveStepBudget)
+    __shared__ double Y[L];
+    const int lane = threadIdx.x;
+    const long b = blockIdx.x;
+    if (pp_params) {
+        const double *src = pp_params + (b / M) * pp_stride;
+#pragma unroll
+        for (int k = 0; k < kMaxParams; k++)
+            if (k < pp_stride - 2) P.p[k] = src[k];
+    }
+    double X[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int e = lane + 64 * k;
+        X[k] = e < L ? X0[b * L + e] : 0.0;
+    }
+    auto stage = [&](double ts, const double (&v)[K], double (&out)[K]) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < K; k++) { const int e = lane + 64 * k; if (e < L) Y[e] = v[k]; }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < K; k++) { const int e = lane + 64 * k; out[k] = e < L ? Mdl::aug_rhs(P, ts, e, Y) : 0.0; }
+    };
+    // maximum over the wave, a NaN winning (the reference's loop: if (e > err || e != e) err = e)
+    auto wave_max = [](double v) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double o = __shfl_xor(v, off);
+            if (o > v || o != o) v = o;
+        }
+        return v;
+    };
+    constexpr double a2 = 1.0 / 5, a3 = 3.0 / 10, a4 = 4.0 / 5, a5 = 8.0 / 9;
+    constexpr double b21 = 1.0 / 5, b31 = 3.0 / 40, b32 = 9.0 / 40, b41 = 44.0 / 45, b42 = -56.0 / 15, b43 = 32.0 / 9,
+                     b51 = 19372.0 / 6561, b52 = -25360.0 / 2187, b53 = 64448.0 / 6561, b54 = -212.0 / 729,
+                     b61 = 9017.0 / 3168, b62 = -355.0 / 33, b63 = 46732.0 / 5247, b64 = 49.0 / 176, b65 = -5103.0 / 18656,
+                     c1 = 35.0 / 384, c3 = 500.0 / 1113, c4 = 125.0 / 192, c5 = -2187.0 / 6784, c6 = 11.0 / 84;
+    constexpr double dc1 = 35.0 / 384 - 5179.0 / 57600, dc3 = 500.0 / 1113 - 7571.0 / 16695, dc4 = 125.0 / 192 - 393.0 / 640,
+                     dc5 = -2187.0 / 6784 - -92097.0 / 339200, dc6 = 11.0 / 84 - 187.0 / 2100, dc7 = -1.0 / 40;
+    const double eps = 2.220446049250313e-16;
+    const double ta = t0[b], tb = tf[b];
+    double t = ta, h = (tb - ta) / P.step_nbr;
+    bool poison = false;
+    if (h > 0) {                                        // zero-length / backward segment: no step
+        double k1[K], k2[K], k3[K], k4[K], k5[K], k6[K], kn[K], xn[K], y[K];
+        bool have_k1 = false;
+        int budget = kBudget;                           // every wave reaches an exit (running out: NaN, like odeint's step_adjustment_error)
+        while (tb - t > eps && budget > 0 && !poison) {
+            while (t + h - tb <= eps && budget > 0) {
+                if (!have_k1) { stage(t, X, k1); have_k1 = true; }
+                int tries = 0;
+                bool ok = false;
+                do {
+                    const double hh = h, tt = t;
+#pragma unroll
+                    for (int k = 0; k < K; k++) y[k] = 1.0 * X[k] + hh * b21 * k1[k];
+                    stage(tt + hh * a2, y, k2);
+#pragma unroll
+                    for (int k = 0; k < K; k++) y[k] = 1.0 * X[k] + hh * b31 * k1[k] + hh * b32 * k2[k];
+                    stage(tt + hh * a3, y, k3);
+#pragma unroll
+                    for (int k = 0; k < K; k++) y[k] = 1.0 * X[k] + hh * b41 * k1[k] + hh * b42 * k2[k] + hh * b43 * k3[k];
+                    stage(tt + hh * a4, y, k4);
+#pragma unroll
+                    for (int k = 0; k < K; k++) y[k] = 1.0 * X[k] + hh * b51 * k1[k] + hh * b52 * k2[k] + hh * b53 * k3[k] + hh * b54 * k4[k];
+                    stage(tt + hh * a5, y, k5);
+#pragma unroll
+                    for (int k = 0; k < K; k++)
+                        y[k] = 1.0 * X[k] + hh * b61 * k1[k] + hh * b62 * k2[k] + hh * b63 * k3[k] + hh * b64 * k4[k] + hh * b65 * k5[k];
+                    stage(tt + hh, y, k6);
+#pragma unroll
+                    for (int k = 0; k < K; k++)
+                        xn[k] = 1.0 * X[k] + hh * c1 * k1[k] + hh * c3 * k3[k] + hh * c4 * k4[k] + hh * c5 * k5[k] + hh * c6 * k6[k];
+                    stage(tt + hh, xn, kn);
+                    double err = 0;
+#pragma unroll
+                    for (int k = 0; k < K; k++) {
+                        if (lane + 64 * k < L) {
+                            double e = hh * dc1 * k1[k] + hh * dc3 * k3[k] + hh * dc4 * k4[k] + hh * dc5 * k5[k] + hh * dc6 * k6[k] + hh * dc7 * kn[k];
+                            e = fabs(e) / (P.tol + P.tol * (1.0 * fabs(X[k]) + 1.0 * hh * fabs(k1[k])));
+                            if (e > err || e != e) err = e;
+                        }
+                    }
+                    err = wave_max(err);                // uniform from here on: the wave steps as one
+                    budget--;
+                    if (!(err <= 1.0)) {
+                        double f = 0.9 * pow(err, -1.0 / 3.0);
+                        if (!(f > 0.2)) f = 0.2;
+                        h = hh * f;
+                        ok = false;
+                    } else {
+                        t = tt + hh;
+                        if (err < 0.5) {
+                            const double floor5 = 1.0 / 3125.0;
+                            const double e = err > floor5 ? err : floor5;
+                            h = hh * (0.9 * pow(e, -1.0 / 5.0));
+                        }
+                        ok = true;
+                    }
+                } while (!ok && ++tries < 500);
+                if (!ok) { poison = true; break; }
+#pragma unroll
+                for (int k = 0; k < K; k++) { X[k] = xn[k]; k1[k] = kn[k]; }
+            }
+            h = tb - t;
+            have_k1 = false;
+        }
+        if (budget <= 0 && tb - t > eps) poison = true;
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) { const int e = lane + 64 * k; if (e < L) Xf[b * L + e] = poison ? __builtin_nan("") : X[k]; }
 }
 
 // K_vprep: augmented initial states and segment bounds of one unknown vector z:
@@ -250,7 +381,8 @@ template <class Mdl>
 hipError_t traj(hipStream_t st, const ModelParams &P, int B, const double *t0, const double *tf, const double *X0, double *Xf)
 {
     if (B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(traj_var_wave_kernel<Mdl>, dim3(B), dim3(64), 0, st, P, t0, tf, X0, Xf, (const double *)nullptr, 0, 1);
+    if (P.integrator == 1) hipLaunchKernelGGL(traj_var_wave_dopri5_kernel<Mdl>, dim3(B), dim3(64), 0, st, P, t0, tf, X0, Xf, (const double *)nullptr, 0, 1);
+    else hipLaunchKernelGGL(traj_var_wave_kernel<Mdl>, dim3(B), dim3(64), 0, st, P, t0, tf, X0, Xf, (const double *)nullptr, 0, 1);
     return hipGetLastError();
 }
 
@@ -261,7 +393,8 @@ hipError_t jacobian(hipStream_t st, const ModelParams &P, const ProblemDev &pb, 
     if (np <= 0) return hipSuccess;
     const unsigned B = (unsigned)((long)np * pb.M);                 // one wavefront per (problem, segment)
     hipLaunchKernelGGL(var_prepare_kernel<Mdl>, dim3(B), dim3(64), 0, st, pb, z, Xaug, t0, tf);
-    hipLaunchKernelGGL(traj_var_wave_kernel<Mdl>, dim3(B), dim3(64), 0, st, P, t0, tf, Xaug, Xtf, pb.pp_params, pb.pp_stride, pb.M);
+    if (P.integrator == 1) hipLaunchKernelGGL(traj_var_wave_dopri5_kernel<Mdl>, dim3(B), dim3(64), 0, st, P, t0, tf, Xaug, Xtf, pb.pp_params, pb.pp_stride, pb.M);
+    else hipLaunchKernelGGL(traj_var_wave_kernel<Mdl>, dim3(B), dim3(64), 0, st, P, t0, tf, Xaug, Xtf, pb.pp_params, pb.pp_stride, pb.M);
     hipError_t e = hipMemsetAsync(fjac, 0, sizeof(double) * (size_t)np * pb.n * pb.n, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(var_assemble_kernel<Mdl>, dim3((B + 63) / 64), dim3(64), 0, st, P, pb, np, z, Xtf, fjac);

@@ -2,6 +2,8 @@
 // helpers and the integration of user classes WITHOUT a device twin (only the reference's host virtuals) run here.
 #include "odeTools.hpp"
 
+#include <cfloat>
+#include <cmath>
 #include <iostream>
 #include <stdexcept>
 
@@ -111,6 +113,86 @@ void host_integrate(odeTools::modelStruct const &ode, odeTools::odeVector &X, do
         seen(X, t);
     }
 }
+
+// The adaptive branch of the reference's integrate() (odeTools.cpp:103-123 with an observer, :129-134 without) on the host, for
+// objects without device dynamics: integrate_adaptive(make_dense_output<runge_kutta_dopri5>(tol, tol), ode, X, t0, tf, dt).
+// [ext] Boost.Odeint is not vendored: this is its published algorithm as the device kernels state it (integrator.hpp:
+// Lane::dopri5_try / integrate_dopri5 -- same tableau, same left-to-right stage sums, same controller, same step budget), so a
+// class with and without a device twin walks the same steps.  PARITY UNPINNED.  `seen` is shown (X, t) at t0
+// and after every accepted step.
+template <class Seen>
+void host_integrate_adaptive(odeTools::modelStruct const &ode, odeTools::odeVector &X, double t0, double tf, double dt, double tol, Seen &&seen)
+{
+    warn_host_path_once();
+    typedef odeTools::odeVector vec;
+    const size_t n = X.size();
+    const double a2 = 1.0 / 5, a3 = 3.0 / 10, a4 = 4.0 / 5, a5 = 8.0 / 9;
+    const double b21 = 1.0 / 5, b31 = 3.0 / 40, b32 = 9.0 / 40, b41 = 44.0 / 45, b42 = -56.0 / 15, b43 = 32.0 / 9,
+                 b51 = 19372.0 / 6561, b52 = -25360.0 / 2187, b53 = 64448.0 / 6561, b54 = -212.0 / 729,
+                 b61 = 9017.0 / 3168, b62 = -355.0 / 33, b63 = 46732.0 / 5247, b64 = 49.0 / 176, b65 = -5103.0 / 18656,
+                 c1 = 35.0 / 384, c3 = 500.0 / 1113, c4 = 125.0 / 192, c5 = -2187.0 / 6784, c6 = 11.0 / 84;
+    const double dc1 = 35.0 / 384 - 5179.0 / 57600, dc3 = 500.0 / 1113 - 7571.0 / 16695, dc4 = 125.0 / 192 - 393.0 / 640,
+                 dc5 = -2187.0 / 6784 - -92097.0 / 339200, dc6 = 11.0 / 84 - 187.0 / 2100, dc7 = -1.0 / 40;
+    const double eps = DBL_EPSILON;
+    auto rhs = [&](double t, vec const &Y, vec &F) { F = Y; ode(Y, F, t); };          // (the output starts as a copy of its input: step_ode)
+    double t = t0, h = dt;
+    seen(X, t);
+    if (!(h > 0)) return;                                    // zero-length / backward segment: no step
+    vec k1(n), k2(n), k3(n), k4(n), k5(n), k6(n), kn(n), xn(n), y(n);
+    bool have_k1 = false;
+    long budget = 50000;                                     // trial steps per segment (integrator.hpp: kAdaptiveStepBudget)
+    auto poison = [&]() { for (size_t i = 0; i < n; i++) X[i] = std::nan(""); };
+    while (tf - t > eps && budget > 0) {
+        while (t + h - tf <= eps && budget > 0) {
+            if (!have_k1) { rhs(t, X, k1); have_k1 = true; }
+            int tries = 0;
+            bool ok = false;
+            do {
+                const double hh = h, tt = t;
+                for (size_t i = 0; i < n; i++) y[i] = 1.0 * X[i] + hh * b21 * k1[i];
+                rhs(tt + hh * a2, y, k2);
+                for (size_t i = 0; i < n; i++) y[i] = 1.0 * X[i] + hh * b31 * k1[i] + hh * b32 * k2[i];
+                rhs(tt + hh * a3, y, k3);
+                for (size_t i = 0; i < n; i++) y[i] = 1.0 * X[i] + hh * b41 * k1[i] + hh * b42 * k2[i] + hh * b43 * k3[i];
+                rhs(tt + hh * a4, y, k4);
+                for (size_t i = 0; i < n; i++) y[i] = 1.0 * X[i] + hh * b51 * k1[i] + hh * b52 * k2[i] + hh * b53 * k3[i] + hh * b54 * k4[i];
+                rhs(tt + hh * a5, y, k5);
+                for (size_t i = 0; i < n; i++)
+                    y[i] = 1.0 * X[i] + hh * b61 * k1[i] + hh * b62 * k2[i] + hh * b63 * k3[i] + hh * b64 * k4[i] + hh * b65 * k5[i];
+                rhs(tt + hh, y, k6);
+                for (size_t i = 0; i < n; i++)
+                    xn[i] = 1.0 * X[i] + hh * c1 * k1[i] + hh * c3 * k3[i] + hh * c4 * k4[i] + hh * c5 * k5[i] + hh * c6 * k6[i];
+                rhs(tt + hh, xn, kn);
+                double err = 0;
+                for (size_t i = 0; i < n; i++) {
+                    double e = hh * dc1 * k1[i] + hh * dc3 * k3[i] + hh * dc4 * k4[i] + hh * dc5 * k5[i] + hh * dc6 * k6[i] + hh * dc7 * kn[i];
+                    e = std::fabs(e) / (tol + tol * (1.0 * std::fabs(X[i]) + 1.0 * hh * std::fabs(k1[i])));
+                    if (e > err || e != e) err = e;
+                }
+                budget--;
+                if (!(err <= 1.0)) {                         // reject (also on NaN)
+                    double f = 0.9 * std::pow(err, -1.0 / 3.0);
+                    if (!(f > 0.2)) f = 0.2;
+                    h = hh * f;
+                } else {
+                    t = tt + hh;
+                    if (err < 0.5) {
+                        const double floor5 = 1.0 / 3125.0;
+                        h = hh * (0.9 * std::pow(err > floor5 ? err : floor5, -1.0 / 5.0));
+                    }
+                    ok = true;
+                }
+            } while (!ok && ++tries < 500);
+            if (!ok) { poison(); return; }                   // odeint throws step_adjustment_error: the result is NaN here, as on the device
+            X = xn;
+            k1 = kn;
+            seen(X, t);
+        }
+        h = tf - t;
+        have_k1 = false;
+    }
+    if (budget <= 0 && tf - t > eps) poison();
+}
 }  // namespace
 
 // The one-step helpers of the reference API (odeTools.hpp:107-165) run on the host: they take arbitrary host callbacks
@@ -130,9 +212,9 @@ void odeTools::integrate(modelStruct const &_model, odeVector &X, double const &
 {
     model *m = device_model(_model.m_ode);
     if (!m) {
-        // no device twin: the reference's own loop over the host virtual (fixed-step only; the adaptive integrator is a device kernel)
-        if (AdaptiveIntegrator()) throw std::runtime_error("odeTools::integrate: the adaptive integrator needs device dynamics");
-        host_integrate(_model, X, t0, tf, dt, [](odeVector const &, real) {});
+        // no device twin: the reference's own loop over the host virtual, fixed step or adaptive (odeTools.cpp:129-146)
+        if (AdaptiveIntegrator()) host_integrate_adaptive(_model, X, t0, tf, dt, odeIntTol, [](odeVector const &, real) {});
+        else host_integrate(_model, X, t0, tf, dt, [](odeVector const &, real) {});
         return;
     }
     const double dt_model = (tf - t0) / m->DeviceStepNumber();
@@ -150,8 +232,8 @@ void odeTools::integrate(modelStruct const &_model, odeVector &X, double const &
 {
     model *m = device_model(_model.m_ode);
     if (!m) {
-        if (AdaptiveIntegrator()) throw std::runtime_error("odeTools::integrate: the adaptive integrator needs device dynamics");
-        host_integrate(_model, X, t0, tf, dt, [&](odeVector const &Xs, real t) { _observer(Xs, t); });
+        if (AdaptiveIntegrator()) host_integrate_adaptive(_model, X, t0, tf, dt, odeIntTol, [&](odeVector const &Xs, real t) { _observer(Xs, t); });
+        else host_integrate(_model, X, t0, tf, dt, [&](odeVector const &Xs, real t) { _observer(Xs, t); });
         return;
     }
     const double dt_model = (tf - t0) / m->DeviceStepNumber();

@@ -74,9 +74,11 @@ int main(int argc, char **argv)
     hostOnly h;
     const model::mstate Xh = h.ComputeTraj(0.0, model::mstate(4, 0.5), 1.0, 0, 0);
     if (Xh.size() == 4 && std::fabs(Xh[0] - 1.5) < 1e-14 && std::fabs(Xh[3] - 1.5) < 1e-14) ok("no_device_twin_runs_on_host");
-    // ... but never with the adaptive integrator, which only exists as a device kernel
+    // ... and with the adaptive integrator too (odeTools.cpp:129-134 on the host: the reference's -D_USE_BOOST build): x' = 1 is
+    // integrated exactly by any Runge-Kutta step, whatever the controller makes of the step sizes
     odeTools::UseAdaptiveIntegrator(true);
-    try { h.ComputeTraj(0.0, model::mstate(4, 0.5), 1.0, 0, 0); } catch (const std::runtime_error &) { ok("no_device_twin_adaptive_throws"); }
+    const model::mstate Xa = h.ComputeTraj(0.0, model::mstate(4, 0.5), 1.0, 0, 0);
+    if (Xa.size() == 4 && std::fabs(Xa[0] - 1.5) < 1e-14 && std::fabs(Xa[3] - 1.5) < 1e-14) ok("no_device_twin_adaptive_runs_on_host");
     odeTools::UseAdaptiveIntegrator(false);
     // the one-step host helpers run host callbacks (odeTools.cpp:46-98; interceptor.cpp:117 uses the function-pointer form)
     struct Cb { static odeTools::odeVector f(real const &, odeTools::odeVector const &X, void *) { return odeTools::odeVector(X.size(), 2.0); } };

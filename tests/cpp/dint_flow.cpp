@@ -3,6 +3,7 @@
 // JSON line per solve.
 //   dint_flow basic <modelOrder> <xtol>
 //   dint_flow wp    <modelOrder> <xtol> [numMulti]     (numMulti > 2: way-points on the x axis, SURVEY 8d "C3")
+// SOCP_FLOW_ADAPTIVE=1: with the adaptive integrator (the reference built with -D_USE_BOOST), variational trajectories included
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -85,6 +86,7 @@ static int wp(int modelOrder, double xtol, int M)
 int main(int argc, char **argv)
 {
     if (argc < 4) { std::fprintf(stderr, "usage: dint_flow basic|wp <modelOrder> <xtol> [numMulti]\n"); return 64; }
+    if (std::getenv("SOCP_FLOW_ADAPTIVE")) odeTools::UseAdaptiveIntegrator(true);      // the reference's -D_USE_BOOST build (odeTools.cpp:129-134)
     const int order = std::atoi(argv[2]);
     const double xtol = std::atof(argv[3]);
     if (std::strcmp(argv[1], "basic") == 0) return basic(order, xtol);

@@ -217,7 +217,14 @@ def test_config5_sweep_at_256_starts(variant):
     spread = np.max(np.abs(r["z"] - np.median(r["z"], axis=0))) / np.max(np.abs(r["z"]))
     assert spread < 1e-8, spread
     alone = ctx.chains_solve(Z0[100:101], kind=capi.CHAIN_PLAIN, xtol=1e-9, speculate=0)
-    assert alone["nfev"][0] == r["nfev"][100] and np.array_equal(alone["z"][0], r["z"][100])
+    if variant == "exact":
+        assert alone["nfev"][0] == r["nfev"][100] and np.array_equal(alone["z"][0], r["z"][100])
+    else:
+        # throughput flavour: the sweep's Jacobian refreshes go through the matrix-core factorisation (AUTO, round 4), the lone
+        # chain through the host solver -- the same iteration to rounding, the same root to north_star's 1e-8
+        assert np.max(np.abs(alone["z"][0] - r["z"][100])) <= 1e-8 * np.max(np.abs(r["z"][100]))
+        same = ctx.chains_solve(Z0[:256], kind=capi.CHAIN_PLAIN, xtol=1e-9, solver=capi.SOLVER_DEVICE)
+        assert np.array_equal(same["info"], r["info"]) and np.max(np.abs(same["z"] - r["z"])) <= 1e-8 * np.max(np.abs(r["z"]))
     ctx.close()
 
 

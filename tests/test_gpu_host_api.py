@@ -24,7 +24,7 @@ def test_conventions():
     assert out.returncode == 0, out.stderr
     got = [l.split()[1] for l in out.stdout.splitlines() if l.startswith("ok ")]
     assert got == ["unknown_parameter_name", "out_of_range", "solve_returns_1", "get_parameters_new_array",
-                   "timeout_returns_minus_1", "no_device_twin_runs_on_host", "no_device_twin_adaptive_throws", "host_rk_helpers_run"], out.stdout + out.stderr
+                   "timeout_returns_minus_1", "no_device_twin_runs_on_host", "no_device_twin_adaptive_runs_on_host", "host_rk_helpers_run"], out.stdout + out.stderr
     assert "does not exist" in out.stdout
 
 

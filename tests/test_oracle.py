@@ -307,3 +307,35 @@ def test_residual_blocks_live_reference_agreement(built):
                 for which in range(5):
                     oth = Oa if which == 4 else other
                     assert np.array_equal(o.residual_block(which, t, Xa, oth, mode, 1), r.residual_block(which, t, Xa, oth, mode, 1))
+
+
+def test_adaptive_integration_of_the_variational_state():
+    """The restatement's adaptive integrator on the AUGMENTED state (orc_integrate_dopri5_jac; the reference under -D_USE_BOOST,
+    odeTools.cpp:129-134 -- parity unpinned): converges to the fine fixed-step trajectory as tol shrinks, takes no step on a
+    zero-length or backward segment, and the hybrj Jacobian built on it converges to the fixed-step one likewise."""
+    from oracle.oracle import Oracle, Problem, MODEL_DINT, FIXED, FREE
+    o = Oracle(MODEL_DINT)
+    X0 = np.zeros(156)
+    X0[:12] = [1, 2, 3, .1, .2, .3, .5, .04, -.3, 2.0, .1, -1.5]           # p_v / a_max crosses the saturation limits inside the segment
+    X0[12:] = np.eye(12).ravel()
+    o.m.step_nbr = 20000
+    fine = o.integrate_batch(np.zeros(1), np.array([7.5]), X0[None, :], is_jac=1)[0]
+    o.m.step_nbr = 30
+    errs = []
+    for tol in (1e-4, 1e-7, 1e-10):
+        o.set_integrator(1, tol)
+        got = o.integrate_batch(np.zeros(3), np.array([7.5, 0.0, -1.0]), np.tile(X0, (3, 1)), is_jac=1)
+        errs.append(np.max(np.abs(got[0] - fine)) / np.max(np.abs(fine)))
+        assert np.array_equal(got[1], X0) and np.array_equal(got[2], X0)
+    assert errs[0] >= errs[1] >= errs[2] and errs[0] > errs[2] and errs[2] <= 1e-8 and errs[0] <= 1e-2, errs
+    X = np.zeros((2, 12))
+    X[0, 6:] = 0.01
+    X[1, :3] = [10.0, 15.0, 0.0]
+    prob = Problem(6, [FIXED, FREE], np.zeros((2, 6), dtype=np.int32), np.array([0.0, 10.0]), X)
+    z = np.concatenate([X[0], [10.0]])
+    o.set_integrator(1, 1e-11)
+    Ja = o.jacobian(prob, z)
+    o.set_integrator(0)
+    o.m.step_nbr = 20000
+    Jf = o.jacobian(prob, z)
+    assert np.max(np.abs(Ja - Jf)) <= 1e-8 * np.max(np.abs(Jf))
