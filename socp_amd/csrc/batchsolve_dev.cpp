@@ -13,7 +13,9 @@
 //                  matrix on the way).  No Jacobian, factor or iterate ever crosses PCIe.
 //
 // The chain logic (continuation homotopy, bisection, per-chain parameter / boundary blocks) is the host engine's
-// (chains_common.hpp).  Not here: speculative FD rows and chain groups (they pay in small sweeps of small problems, which AUTO leaves to the host engine).
+// (chains_common.hpp).  Speculative FD rows as in the host engine (round 4): when a round's residual requests fit the idle SIMDs
+// as whole forward-difference batches they are evaluated that way, the rows of a chain's last accepted point stay in HBM, and a
+// Jacobian asked for at that point is formed from them without trajectories -- no iterate changes.  Not here: chain groups.
 #include "../../include/socp_hip.h"
 #include "../../include/socp_solver.h"
 
@@ -88,6 +90,7 @@ struct EnginePlan {
         double b = (double)P * (sizeof(double) * (double)ws_stride + sizeof(State) + 6.0 * rowB) + 5.0 * intsB + (double)jacB * jlaunch;
         if (pp_params) b += 2.0 * parB;
         if (pp_bound) b += 2.0 * (timeB + nodeB);
+        b += 2.0 * (double)P * rowB * (rowB / sizeof(double) + 1);          // (upper bound: a cache slot per chain and as much staging)
         return b + 64.0 * 256;                                               // every piece is rounded up to 256 B
     }
 };
@@ -172,7 +175,24 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
     if (socp_ctx_synchronize(ctx) != SOCP_OK || socp_ctx_get_stream(ctx, &main_stream_v) != SOCP_OK) return SOCP_ERR_HIP;
     hipStream_t main_stream = static_cast<hipStream_t>(main_stream_v), fs = nullptr;
 
-    Dev dWs, dStates, dList, dFlags, dListF, dListJ, dX, dF, dJx, dJf, dJ, dRes, dPF, dTF, dXF, dPJ, dTJ, dXJ;
+    // ---- speculative FD rows (DESIGN section 6 "Fewer rounds"; the host engine's rule): off for hybrj chains and when a slot per chain
+    // ((n + 1) n doubles) would take more than 4 GiB
+    int num_simd = 1024;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, socp_ctx_device(ctx)) == hipSuccess && prop.multiProcessorCount > 0) num_simd = 4 * prop.multiProcessorCount;
+    }
+    const int segs = nodes - 1;
+    const long rowsLen = (long)(n + 1) * n;
+    const size_t rowsB = sizeof(double) * (size_t)rowsLen;
+    int speculate = opt->speculate;
+    if (const char *e = std::getenv("SOCP_CHAINS_SPECULATE")) speculate = std::atoi(e);
+    if (opt->analytic_jac || (double)P * rowsB > 4.0 * 1024 * 1024 * 1024) speculate = 0;
+    const bool spec_on = speculate != 0;
+    // the most residual requests a round evaluates as FD batches: all P when forced, else what one wavefront per SIMD holds
+    const int capS = !spec_on ? 0 : (speculate > 0 ? P : (int)std::min<long>(P, std::max<long>(1, (long)num_simd * 64 / ((long)(n + 1) * segs))));
+    Dev dWs, dStates, dList, dFlags, dListF, dListJ, dX, dF, dJx, dJf, dJ, dRes, dPF, dTF, dXF, dPJ, dTJ, dXJ, dSlots, dStage, dIdxA, dIdxB;
+    Pinned hIdxA, hIdxB;
     Pinned hStates, hList, hFlags, hListF, hListJ, hX, hRes, hPF, hTF, hXF, hPJ, hTJ, hXJ;
     Arena dev_arena, host_arena;
     {
@@ -186,7 +206,9 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
             {&hStates, sizeof(State) * P, true}, {&hList, intsB, true}, {&hFlags, intsB, true}, {&hListF, intsB, true},
             {&hListJ, intsB, true}, {&hX, rowB * P, true}, {&hRes, 2 * rowB * P, true}, {&hPF, pp_params ? parB : 0, true},
             {&hPJ, pp_params ? parB : 0, true}, {&hTF, pp_bound ? timeB : 0, true}, {&hTJ, pp_bound ? timeB : 0, true},
-            {&hXF, pp_bound ? nodeB : 0, true}, {&hXJ, pp_bound ? nodeB : 0, true}};
+            {&hXF, pp_bound ? nodeB : 0, true}, {&hXJ, pp_bound ? nodeB : 0, true},
+            {&dSlots, spec_on ? rowsB * P : 0, false}, {&dStage, spec_on ? rowsB * capS : 0, false}, {&dIdxA, spec_on ? intsB : 0, false},
+            {&dIdxB, spec_on ? intsB : 0, false}, {&hIdxA, spec_on ? intsB : 0, true}, {&hIdxB, spec_on ? intsB : 0, true}};
         for (auto &e : plan) e.piece->plan(e.host ? host_arena : dev_arena, e.bytes);
         const double t0 = ms_since(t_begin);
         bool ok = dev_arena.alloc(false);
@@ -205,8 +227,13 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
     pool.ws = dWs.d();
     State *hS = static_cast<State *>(hStates.p);
 
+    // per chain: where its request's FD rows sit in the staging area (-1: none), what the solver's iteration counter and the kind of
+    // the request were when they were staged, and for which iteration counter the rows in its slot are the rows at x (-1: none).
+    // The solver's x changes exactly when `iter` grows (an accepted trial step) or a new solve starts, so the counter stands for x.
+    std::vector<int> stage_idx(spec_on ? P : 0, -1), stage_iter(spec_on ? P : 0, 0), stage_sel(spec_on ? P : 0, 0), slot_iter(spec_on ? P : 0, -1);
+    std::vector<int> accepted, reqJc;
     int rc = SOCP_OK;
-    long long rounds = 0, jac_launched = 0, restarts = 0;
+    long long rounds = 0, jac_launched = 0, restarts = 0, jac_from_cache = 0, spec_rounds = 0;
     bool round_limit_hit = false;
     double t_adv = 0, t_eval = 0, t_host = 0;
     const double t_setup = ms_since(t_begin);
@@ -259,13 +286,57 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
             if (rc != SOCP_OK) break;
             const clk::time_point th = clk::now();
             done.clear();
+            if (spec_on) {
+                // the rows staged for a chain's last request are the rows at its x now if that request was F(x) itself, or a trial
+                // point that has just been accepted: staging -> the chain's slot, one gather launch
+                accepted.clear();
+                for (int p : adv) {
+                    if (stage_idx[p] < 0) continue;
+                    const bool live = hS[p].req != socp::devsolver::RQ_DONE;
+                    if (live && (stage_sel[p] == 0 || hS[p].iter == stage_iter[p] + 1)) accepted.push_back(p);
+                    else if (!live) slot_iter[p] = -1;
+                }
+                if (!accepted.empty()) {
+                    for (size_t k = 0; k < accepted.size(); k++) { hIdxA.i()[k] = stage_idx[accepted[k]]; hIdxB.i()[k] = accepted[k]; }
+                    hip_ok(hipMemcpyAsync(dIdxA.p, hIdxA.p, sizeof(int) * accepted.size(), hipMemcpyHostToDevice, main_stream));
+                    hip_ok(hipMemcpyAsync(dIdxB.p, hIdxB.p, sizeof(int) * accepted.size(), hipMemcpyHostToDevice, main_stream));
+                    hip_ok(socp::devsolver::launch_copy_blocks(main_stream, dStage.d(), dIdxA.i(), dSlots.d(), dIdxB.i(), (int)accepted.size(), rowsLen));
+                    hip_ok(hipStreamSynchronize(main_stream));       // (the index buffers are reused below)
+                    for (int p : accepted) slot_iter[p] = hS[p].iter;
+                }
+                for (int p : adv) stage_idx[p] = -1;                 // the staging area is about to be reused
+            }
+            reqJc.clear();
             for (int p : adv) {
                 const int rq = hS[p].req;
                 if (rq == socp::devsolver::RQ_FVEC) reqF.push_back(p);
-                else if (rq == socp::devsolver::RQ_JAC) reqJ.push_back(p);
-                else done.push_back(p);
+                else if (rq == socp::devsolver::RQ_JAC) {
+                    if (spec_on && slot_iter[p] >= 0 && slot_iter[p] == hS[p].iter) reqJc.push_back(p);
+                    else reqJ.push_back(p);
+                } else done.push_back(p);
             }
             adv.clear(); advflag.clear();
+            if (!reqJc.empty() && rc == SOCP_OK) {
+                // Jacobians from cached rows, no trajectories: slots -> staging (gather), differences, into the solvers' matrices;
+                // those chains go straight back into the advance loop (their factorisation)
+                std::sort(reqJc.begin(), reqJc.end());
+                const int chunk = std::max(1, std::min(capS, jlaunch));
+                for (size_t j0 = 0; j0 < reqJc.size() && rc == SOCP_OK; j0 += (size_t)chunk) {
+                    const int kc = (int)std::min<size_t>((size_t)chunk, reqJc.size() - j0);
+                    std::memcpy(hIdxA.p, reqJc.data() + j0, sizeof(int) * kc);
+                    hip_ok(hipMemcpyAsync(dIdxA.p, hIdxA.p, sizeof(int) * kc, hipMemcpyHostToDevice, main_stream));
+                    hip_ok(socp::devsolver::launch_copy_blocks(main_stream, dSlots.d(), dIdxA.i(), dStage.d(), nullptr, kc, rowsLen));
+                    hip_ok(socp::devsolver::launch_gather_jac(main_stream, pool, dIdxA.i(), kc, dJx.d(), dJf.d()));
+                    const int r = socp_fd_diff_dev(ctx, kc, dJx.d(), opt->epsfcn, dStage.d(), dJ.d());
+                    if (r != SOCP_OK) { rc = r; break; }
+                    hip_ok(socp::devsolver::launch_scatter_jac(main_stream, pool, dIdxA.i(), kc, dJ.d()));
+                    hip_ok(hipStreamSynchronize(main_stream));       // (dIdxA is rewritten by the next chunk / the next pass)
+                }
+                jac_from_cache += (long long)reqJc.size();
+                adv = reqJc;
+                adv_jac = (int)reqJc.size();
+                advflag.assign(adv.size(), 0);
+            }
             if (!done.empty()) {
                 // results of the solves that ended: x and fvec of those chains, then the homotopy logic on the host
                 std::memcpy(hList.p, done.data(), sizeof(int) * done.size());
@@ -289,7 +360,8 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
                 }
                 restarts += (long long)restart.size();
                 start_chains(restart);
-                adv = restart;
+                if (spec_on) for (int p : restart) slot_iter[p] = -1;         // another problem now: cached rows are not its rows
+                adv.insert(adv.end(), restart.begin(), restart.end());       // (after the chains that have just received a cached Jacobian)
                 advflag.assign(adv.size(), 0);
             }
             t_host += ms_since(th);
@@ -323,12 +395,28 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
                 hip_ok(hipMemcpyAsync(dXF.p, hXF.p, sizeof(double) * nodes * S * kF, hipMemcpyHostToDevice, fs));
             }
             hip_ok(socp::devsolver::launch_gather_eval(fs, pool, dListF.i(), kF, dX.d()));
+            // all of them as whole forward-difference batches when they fit the idle SIMDs (one wavefront per SIMD keeps the round at
+            // one trajectory latency), else none: a round that is part FD batches, part plain residuals would be two launches on
+            // one stream, i.e. two latencies.  speculate = 1 forces all.
+            bool as_batches = false;
+            if (spec_on && kF <= capS) {
+                const long lanes = ((long)num_simd - ((long)kJ * n * segs + 63) / 64) * 64;
+                as_batches = speculate > 0 || (long)kF * (n + 1) * segs <= lanes;
+            }
             socp_ctx_set_stream(ctx, fs, 0);
             socp_problem_set_blocks_dev(ctx, pp_params ? dPF.d() : nullptr, stride, pp_bound ? dTF.d() : nullptr, pp_bound ? dXF.d() : nullptr);
-            const int r = socp_residual_batch_dev(ctx, kF, dX.d(), dF.d());
+            const int r = as_batches ? socp_fd_rows_dev(ctx, kF, dX.d(), opt->epsfcn, dStage.d()) : socp_residual_batch_dev(ctx, kF, dX.d(), dF.d());
             socp_ctx_set_stream(ctx, main_stream, 0);
             if (r != SOCP_OK) { rc = r; break; }
-            hip_ok(socp::devsolver::launch_scatter_fvec(fs, pool, dListF.i(), kF, dF.d()));
+            if (as_batches) {
+                // F is row 0 of a request's (n + 1) x n block; the block waits in the staging area for the solver's verdict on the point
+                hip_ok(socp::devsolver::launch_scatter_fvec(fs, pool, dListF.i(), kF, dStage.d(), rowsLen));
+                for (int k = 0; k < kF; k++) { const int p = reqF[k]; stage_idx[p] = k; stage_iter[p] = hS[p].iter; stage_sel[p] = hS[p].eval_sel; }
+                spec_rounds++;
+            } else {
+                hip_ok(socp::devsolver::launch_scatter_fvec(fs, pool, dListF.i(), kF, dF.d()));
+            }
+            if (trace && as_batches) std::fprintf(stderr, "[socp_chains/device]   (the %d residual requests as FD batches)\n", kF);
         }
         // ---- Jacobian requests: the context's stream, in passes of jlaunch -----------------------------------------------------
         if (kJ) {
@@ -388,8 +476,8 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
                             std::chrono::duration<double, std::milli>(t_loop_end - t_loop_begin).count() - t_adv - t_eval - t_host, ms_since(t_loop_end));
     if (trace)
         std::fprintf(stderr, "[socp_chains/device] set-up %.1f ms, solver kernels + state read-back %.1f ms, evaluation launches %.1f ms, host chain logic %.1f ms, "
-                             "total %.1f ms; %lld rounds, %lld Jacobians, %lld solver restarts; %d threads per problem, %s factorisation, %.1f MB of solver state\n",
-                     t_setup, t_adv, t_eval, t_host, ms_since(t_begin), rounds, jac_launched, restarts, socp::devsolver::threads_for(n),
+                             "total %.1f ms; %lld rounds, %lld Jacobians launched, %lld from cached rows, %lld solver restarts; %d threads per problem, %s factorisation, %.1f MB of solver state\n",
+                     t_setup, t_adv, t_eval, t_host, ms_since(t_begin), rounds, jac_launched, jac_from_cache, restarts, socp::devsolver::threads_for(n),
                      fast_factor ? "matrix-core (throughput)" : "order-preserving",
                      1e-6 * sizeof(double) * pool.ws_stride * P);
     if (trace) {
@@ -403,8 +491,8 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
                                  "R, clearing %llu; qform %llu\n", pf[8], pf[9], pf[10], pf[11], pf[12], pf[13]);
     }
     if (stats) {
-        stats->rounds = rounds; stats->jacobians_launched = jac_launched; stats->jacobians_from_cache = 0;
-        stats->speculative_rounds = 0; stats->restarts = restarts; stats->wall_ms = ms_since(t_begin);
+        stats->rounds = rounds; stats->jacobians_launched = jac_launched; stats->jacobians_from_cache = jac_from_cache;
+        stats->speculative_rounds = spec_rounds; stats->restarts = restarts; stats->wall_ms = ms_since(t_begin);
     }
     return rc;
 }

@@ -85,12 +85,27 @@ __global__ void gather_eval_kernel(Config c, const State *states, double *ws, lo
     for (int j = threadIdx.x; j < c.n; j += blockDim.x) dst[(long)blockIdx.x * c.n + j] = src[j];
 }
 
-__global__ void scatter_fvec_kernel(Config c, const State *states, double *ws, long ws_stride, const int *__restrict__ list, const double *__restrict__ src)
+// src_stride: doubles between the results of consecutive problems (n for a residual batch; (n + 1) n when the evaluation ran as a
+// whole forward-difference batch and F is row 0 of the problem's block)
+__global__ void scatter_fvec_kernel(Config c, const State *states, double *ws, long ws_stride, const int *__restrict__ list, const double *__restrict__ src,
+                                    long src_stride)
 {
     const int p = list[blockIdx.x];
     const Work w(ws + (long)p * ws_stride, c.n, c.ld);
     double *dst = states[p].eval_sel ? w.wa4 : w.fvec;
-    for (int j = threadIdx.x; j < c.n; j += blockDim.x) dst[j] = src[(long)blockIdx.x * c.n + j];
+    for (int j = threadIdx.x; j < c.n; j += blockDim.x) dst[j] = src[(long)blockIdx.x * src_stride + j];
+}
+
+// dst[dst_idx[k]][0 .. len) = src[src_idx[k]][0 .. len) (an index list may be null: block k): moves the (n + 1) x n row blocks of
+// forward-difference batches between a round's staging area and the chains' cache slots in one launch
+__global__ void copy_blocks_kernel(const double *__restrict__ src, const int *__restrict__ src_idx, double *__restrict__ dst,
+                                   const int *__restrict__ dst_idx, int count, long len)
+{
+    const int k = blockIdx.y;
+    if (k >= count) return;
+    const double *s = src + (long)(src_idx ? src_idx[k] : k) * len;
+    double *d = dst + (long)(dst_idx ? dst_idx[k] : k) * len;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < len; e += (long)gridDim.x * blockDim.x) d[e] = s[e];
 }
 
 __global__ void gather_jac_kernel(Config c, double *ws, long ws_stride, const int *__restrict__ list, double *__restrict__ dX, double *__restrict__ dF)
@@ -298,10 +313,23 @@ hipError_t launch_gather_eval(hipStream_t st, const PoolDev &pool, const int *d_
     return hipGetLastError();
 }
 
-hipError_t launch_scatter_fvec(hipStream_t st, const PoolDev &pool, const int *d_list, int count, const double *d_src)
+hipError_t launch_scatter_fvec(hipStream_t st, const PoolDev &pool, const int *d_list, int count, const double *d_src, long src_stride)
 {
     if (count <= 0) return hipSuccess;
-    hipLaunchKernelGGL(scatter_fvec_kernel, dim3(count), dim3(64), 0, st, pool.cfg, pool.states, pool.ws, pool.ws_stride, d_list, d_src);
+    hipLaunchKernelGGL(scatter_fvec_kernel, dim3(count), dim3(64), 0, st, pool.cfg, pool.states, pool.ws, pool.ws_stride, d_list, d_src,
+                       src_stride > 0 ? src_stride : (long)pool.cfg.n);
+    return hipGetLastError();
+}
+
+hipError_t launch_copy_blocks(hipStream_t st, const double *src, const int *d_src_idx, double *dst, const int *d_dst_idx, int count, long len)
+{
+    if (count <= 0) return hipSuccess;
+    const unsigned gx = (unsigned)std::min<long>(8, (len + 255) / 256);
+    for (int k0 = 0; k0 < count; k0 += 32768) {                  // grid.y is limited to 65535
+        const int kc = std::min(32768, count - k0);
+        hipLaunchKernelGGL(copy_blocks_kernel, dim3(gx, (unsigned)kc), dim3(256), 0, st, src + (d_src_idx ? 0 : (long)k0 * len), d_src_idx ? d_src_idx + k0 : nullptr,
+                           dst + (d_dst_idx ? 0 : (long)k0 * len), d_dst_idx ? d_dst_idx + k0 : nullptr, kc, len);
+    }
     return hipGetLastError();
 }
 

@@ -39,7 +39,10 @@ hipError_t launch_factor_exact(hipStream_t st, const PoolDev &pool, const int *d
 // dst[k][n] = the point problem list[k] asked to be evaluated (x, or the trial point)
 hipError_t launch_gather_eval(hipStream_t st, const PoolDev &pool, const int *d_list, int count, double *d_dst);
 // the residual of that evaluation back into the problem (fvec, or the trial residual)
-hipError_t launch_scatter_fvec(hipStream_t st, const PoolDev &pool, const int *d_list, int count, const double *d_src);
+// (src_stride: doubles between consecutive problems' results; 0 = n.  (n + 1) n: F is row 0 of a forward-difference batch)
+hipError_t launch_scatter_fvec(hipStream_t st, const PoolDev &pool, const int *d_list, int count, const double *d_src, long src_stride = 0);
+// dst[dst_idx[k]][0 .. len) = src[src_idx[k]][0 .. len), k < count; a null index list means block k
+hipError_t launch_copy_blocks(hipStream_t st, const double *src, const int *d_src_idx, double *dst, const int *d_dst_idx, int count, long len);
 // Jacobian requests: dX[k] = x, dF[k] = fvec of problem list[k]
 hipError_t launch_gather_jac(hipStream_t st, const PoolDev &pool, const int *d_list, int count, double *d_X, double *d_F);
 // column-major Jacobians J[k][n * n] (what the FD / variational kernels write) into the problems' row-major matrices

@@ -206,15 +206,22 @@ def test_boundary_data_chains_equal_the_sequential_loop():
 
 
 @pytest.mark.parametrize("variant", ["exact", "fast"])
-def test_speculative_jacobians_change_no_iterate(variant):
+@pytest.mark.parametrize("solver", ["host", "device"])
+def test_speculative_jacobians_change_no_iterate(variant, solver):
     """Residual requests evaluated as whole FD batches (speculate = 1) / never (0) / when the chip has idle SIMDs (-1): same
-    solutions, same evaluation counts, fewer launch rounds and no launched Jacobian when every request is speculated."""
-    from socp_amd import sweep
+    solutions, same evaluation counts, fewer launch rounds and no launched Jacobian when every request is speculated -- with the
+    solvers on the host and (round 4: the device engine has the cache too) on the device, and both engines agree bit for bit."""
+    from socp_amd import capi, sweep
     ctx = make_ctx(variant, steps=200)
     ctx.set_params(sweep.GODDARD_PARAMS)
     sweep.goddard_single_shooting_problem(ctx)
     Z0 = sweep.goddard_starts(96, 1e-3)
-    runs = {s: ctx.chains_solve(Z0, kind=0, xtol=1e-8, speculate=s) for s in (0, 1, -1)}
+    which = capi.SOLVER_HOST if solver == "host" else capi.SOLVER_DEVICE
+    runs = {s: ctx.chains_solve(Z0, kind=0, xtol=1e-8, speculate=s, solver=which) for s in (0, 1, -1)}
+    other = ctx.chains_solve(Z0, kind=0, xtol=1e-8, speculate=1, solver=capi.SOLVER_DEVICE if solver == "host" else capi.SOLVER_HOST)
+    for key in ("z", "info", "nfev", "fnorm"):
+        assert np.array_equal(other[key], runs[1][key]), key
+    assert other["stats"]["rounds"] == runs[1]["stats"]["rounds"] and other["stats"]["jacobians_from_cache"] == runs[1]["stats"]["jacobians_from_cache"]
     for s in (1, -1):
         for key in ("z", "info", "nfev", "fnorm"):
             assert np.array_equal(runs[0][key], runs[s][key]), (s, key)
