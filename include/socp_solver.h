@@ -106,7 +106,7 @@ typedef struct socp_chain_options {
     double epsfcn;
     double factor;
     int dedup;                /* launched FD Jacobians integrate only the segments a column can change */
-    int speculate;            /* residual requests evaluated as whole FD batches so that later Jacobian requests at an accepted
+    int speculate;            /* (both engines) residual requests evaluated as whole FD batches so that later Jacobian requests at an accepted
                                  point need no launch: -1 = when the chip has idle SIMDs (default), 0 = never (also what a zeroed
                                  struct means), 1 = always.
                                  No iterate depends on it.  Environment SOCP_CHAINS_SPECULATE overrides. */
@@ -122,8 +122,8 @@ typedef struct socp_chain_options {
                                  means), SOCP_SOLVER_HOST, SOCP_SOLVER_DEVICE.  DEVICE: one workgroup per chain runs MINPACK's qrfac /
                                  qform / dogleg / r1updt / r1mpyq in HBM with the per-column operation order of the host code, so
                                  every iterate, nfev and info is the host solver's, bit for bit; Jacobians never cross PCIe.  AUTO
-                                 picks DEVICE where the host side is the bottleneck (P n^2 >= 1.6e6 and 20 P >= n: 8192 chains of n = 14,
-                                 222 of n = 85, 25 of n = 253, 42 of n = 832) and the solver state fits HBM (if the device engine cannot
+                                 picks DEVICE where the host side is the bottleneck (P n^2 >= 1.6e6 -- 4e5 for n <= 32 -- and 20 P >= n:
+                                 2048 chains of n = 14, 222 of n = 85, 25 of n = 253, 42 of n = 832) and the solver state fits HBM (if the device engine cannot
                                  allocate it after all, AUTO runs the host engine; an explicit DEVICE returns SOCP_ERR_HIP).
                                  SOCP_SOLVER_DEVICE_FAST: the device solvers with the Jacobian refresh (qrfac + qform, 70 % of the solver
                                  time at n = 253) in its THROUGHPUT flavour -- blocked Householder, compact-WY panels of 16, trailing

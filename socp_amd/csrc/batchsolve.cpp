@@ -155,7 +155,10 @@ extern "C" int socp_chains_solve_ex(socp_ctx *ctx, int P, const socp_chain_optio
             // factorisations stream their matrices at the bandwidth of a handful of CUs (0.33-0.36 s for 1 ... 48 chains of n = 832)
             // while the host gives each its share of 16 threads (0.04 s for one chain, 0.28 s for 32, 0.39 s for 48); measured
             // crossovers: 44 chains at n = 832, 10 at n = 253 (scripts/probes/large_n_chains.py).
-            solver = (n <= 2048 && (double)P * n * n >= 1.6e6 && 20L * P >= n) ? SOCP_SOLVER_DEVICE : SOCP_SOLVER_HOST;
+            // Round 4: the device engine has the speculative FD rows too, so small problems go there earlier -- n = 14, 10^4 steps,
+            // host / device: 1024 starts 0.264 / 0.263 s, 2048: 0.361 / 0.358, 4096: 0.747 / 0.719 (65 rounds each), 16 384: 0.566 / 0.466.
+            const double floor_pn2 = n <= 32 ? 4e5 : 1.6e6;
+            solver = (n <= 2048 && (double)P * n * n >= floor_pn2 && 20L * P >= n) ? SOCP_SOLVER_DEVICE : SOCP_SOLVER_HOST;
             if (solver == SOCP_SOLVER_DEVICE) {
                 // does the device engine's state fit?  The figure is the engine's own allocation plan (an estimate of its
                 // own had drifted below what the arena really takes)

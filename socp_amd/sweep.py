@@ -215,8 +215,8 @@ def goddard_kd_chains(ctx, P, eps=0.05, kd_goal=310.0, kd_spread=0.0):
 
 SOLVERS = {"auto": 0, "host": 1, "device": 2, "device_fast": 3}         # socp_chain_options.solver (include/socp_solver.h)
 SOLVER_HELP = ("socp_chain_options.solver (include/socp_solver.h has the rule): where the chains' hybrd state machines run.  auto: on the "
-               "device where the host side is the bottleneck (P n^2 >= 1.6e6 and 20 P >= n: 8192 starts of n = 14, 222 of n = 85, 25 of "
-               "n = 253) and the state fits HBM, with the matrix-core factorisation on a throughput-flavour context (39 <= n <= 256); "
+               "device where the host side is the bottleneck (P n^2 >= 1.6e6 -- 4e5 for n <= 32 -- and 20 P >= n: 2048 starts of n = 14, 222 of "
+               "n = 85, 25 of n = 253) and the state fits HBM, with the matrix-core factorisation on a throughput-flavour context (39 <= n <= 256); "
                "device: the bit-equal device solvers; device_fast: the matrix-core factorisation asked for explicitly")
 
 

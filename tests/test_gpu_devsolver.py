@@ -19,7 +19,7 @@ KEYS = ("z", "info", "nfev", "nfev_total", "njev", "solves", "b_reached", "param
 def both(ctx, Z0, **kw):
     from socp_amd import capi
     host = ctx.chains_solve(Z0, solver=capi.SOLVER_HOST, speculate=0, **kw)
-    dev = ctx.chains_solve(Z0, solver=capi.SOLVER_DEVICE, **kw)
+    dev = ctx.chains_solve(Z0, solver=capi.SOLVER_DEVICE, speculate=0, **kw)      # (speculative rows, both engines: tests/test_gpu_chains.py)
     for k in KEYS:
         assert np.array_equal(host[k], dev[k], equal_nan=True), k
     assert host["stats"]["rounds"] == dev["stats"]["rounds"]
@@ -171,8 +171,8 @@ def test_nan_start_round_limit_and_refusals():
 
 
 def test_auto_picks_the_device_for_large_sweeps_only():
-    """socp_chain_options.solver = AUTO: the host engine (with its speculative FD rows) for small sweeps, the device engine from
-    P n^2 >= 1.6e6 -- visible in the stats: the device engine never forms Jacobians from cached rows."""
+    """socp_chain_options.solver = AUTO: the host engine for small sweeps, the device engine where the host side is the bottleneck
+    (P n^2 >= 1.6e6; from 4e5 for n <= 32) -- and, on a reference-order context, the same iterates either way."""
     from socp_amd import capi, sweep
     ctx = capi.Context(capi.MODEL_GODDARD)
     ctx.set_params(sweep.GODDARD_PARAMS)
@@ -180,14 +180,14 @@ def test_auto_picks_the_device_for_large_sweeps_only():
     ctx.set_variant(capi.VARIANT_LANE_FAST)
     sweep.goddard_single_shooting_problem(ctx)
     small = ctx.chains_solve(sweep.goddard_starts(64, 1e-3), kind=capi.CHAIN_PLAIN, xtol=1e-8)
-    assert small["stats"]["jacobians_from_cache"] > 0
+    assert small["stats"]["jacobians_from_cache"] > 0 and small["stats"]["wall_ms"] > 0
     # (reference-order context: AUTO's device choice is the bit-equal solver; on a throughput-flavour context it is the matrix-core
     # factorisation, whose iterates differ at rounding level -- tests/test_gpu_factor_fast.py)
     ctx.set_variant(capi.VARIANT_LANE_EXACT)
     sweep.goddard_multiple_shooting_problem(ctx, 6)
     Z0 = sweep.goddard_multiple_shooting_starts(ctx, sweep.goddard_starts(300, 0.05), 6)
     big = ctx.chains_solve(Z0, kind=capi.CHAIN_PLAIN, xtol=1e-8)
-    assert big["stats"]["jacobians_from_cache"] == 0 and big["stats"]["speculative_rounds"] == 0 and np.all(big["info"] == 1)
+    assert np.all(big["info"] == 1)
     forced = ctx.chains_solve(Z0, kind=capi.CHAIN_PLAIN, xtol=1e-8, solver=capi.SOLVER_HOST)
     assert np.array_equal(forced["z"], big["z"]) and np.array_equal(forced["nfev"], big["nfev"])
     ctx.close()
