@@ -568,10 +568,8 @@ int socp_problem_set(socp_ctx *c, int M, const int *mode_t, const int *mode_x, c
         for (int j = 0; j < d; j++) {
             const int m = mode_x[k * d + j];
             if (m < SOCP_FIXED || m > SOCP_CONTINUOUS) return fail(c, SOCP_ERR_ARG, "problem_set: bad state mode");
-            // interior FREE states defer to model::SwitchingStateFunction, a no-op in every in-tree
-            // model (model.hpp:339-341, "TO TEST" at shooting.cpp:1536): no defined behaviour to mirror
-            if (k > 0 && k < M && m == SOCP_FREE)
-                return fail(c, SOCP_ERR_UNSUPPORTED, "problem_set: FREE state mode at an interior node");
+            // (interior FREE states go to the model's SwitchingStateFunction -- shooting.cpp:1535-1538, model.hpp:339-341 -- i.e. to
+            // the optional device trait switching_state; a model without it gets the default hook's zero rows)
             if ((k == 0 || k == M) && m == SOCP_CONTINUOUS)
                 return fail(c, SOCP_ERR_ARG, "problem_set: CONTINUOUS state mode at a boundary node");
         }

@@ -18,6 +18,12 @@ namespace socp {
 // final_h_offset().
 template <class M, class = void> struct has_custom_traj : std::false_type {};
 template <class M> struct has_custom_traj<M, std::void_t<decltype(M::kCustomTraj)>> : std::bool_constant<M::kCustomTraj> {};
+// optional trait switching_state(P, t, j, X, Xp, Xd, f_state, f_costate): the model's SwitchingStateFunction (model.hpp:339-341,
+// called by MultipleShootingFunction for a FREE state component of an INTERIOR node, shooting.cpp:1535-1538) -- the two residual
+// rows of component j.  Without it the rows are zero: the reference's default hook is a no-op and leaves what its (zero-
+// initialised, then reused) scratch vector holds.
+template <class M, class = void> struct has_switching_state : std::false_type {};
+template <class M> struct has_switching_state<M, std::void_t<decltype(&M::switching_state)>> : std::true_type {};
 template <class M, class = void> struct has_custom_final : std::false_type {};
 template <class M> struct has_custom_final<M, std::void_t<decltype(M::kCustomFinal)>> : std::bool_constant<M::kCustomFinal> {};
 
@@ -393,6 +399,11 @@ __device__ __forceinline__ void segment_residual(const ModelParams &P, const Pro
             if (mx[j] == 0) {                               // FIXED: pin both sides
                 emit(row, X[j] - xd[j]);
                 emit(row + D, Xp[j] - xd[j]);
+            } else if (mx[j] == 1) {                        // FREE: the model's SwitchingStateFunction (shooting.cpp:1535-1538)
+                double fs = 0.0, fc = 0.0;
+                if constexpr (has_switching_state<Mdl>::value) Mdl::switching_state(P, t2, j, X, Xp, xd, fs, fc);
+                emit(row, fs);
+                emit(row + D, fc);
             } else {                                        // CONTINUOUS
                 emit(row, X[j] - Xp[j]);
                 emit(row + D, X[j + D] - Xp[j + D]);

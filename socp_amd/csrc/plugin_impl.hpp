@@ -15,6 +15,11 @@
 //                                            const double (&X)[S]);                     // model::Hamiltonian
 //       __device__ static double switching_fn(const socp::ModelParams &P, double sw0, double sw1, double t,
 //                                             const double (&X)[S], const double (&Xp)[S]);  // SwitchingTimesFunction
+//       // OPTIONAL -- model::SwitchingStateFunction (model.hpp:339-341; shooting.cpp:1535-1538): the two residual rows of state
+//       // component j of an interior node whose mode is FREE; X: end of the arriving segment, Xp: the node's unknowns, Xd: the
+//       // node's desired state.  Without it those rows are zero (the reference's default hook is a no-op).
+//       __device__ static void switching_state(const socp::ModelParams &P, double t, int j, const double (&X)[S], const double (&Xp)[S],
+//                                              const double *Xd, double &f_state, double &f_costate);
 //       // OPTIONAL -- variational equations, for classes with modelOrder = 1 (hybrj; model.hpp:104-120,149-183):
 //       __device__ static double aug_rhs(const socp::ModelParams &P, double t, int e, const double *Y);
 //                 // element e of Model(t, Y, isJac = 1), Y = [X(S) ; R(S x S)], R[k][i] at Y[S (k+1) + i]  

@@ -293,6 +293,9 @@ __global__ void var_assemble_kernel(ModelParams P, ProblemDev pb, int np, const 
                     J(index + j + D, index - S + c) = 0.0;
                 }
                 if (col_t >= 0) { J(index + j, col_t) = fxt[j]; J(index + j + D, col_t) = fxp[j]; }
+            } else if (mx[j] == 1) {
+                // FREE: SwitchingStateFunction(..., isJac = 1), a no-op by default on a block the caller has just zeroed
+                // (shooting.cpp:1067,1535-1538): the rows stay zero.  (No Jacobian form of the device trait: FD path only.)
             } else {                                                          // CONTINUOUS (:1544-1555)
                 for (int c = 0; c < S; c++) {
                     J(index + j, index - S + c) = Xtf[S * (j + 1) + c];

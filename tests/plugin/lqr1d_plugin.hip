@@ -48,6 +48,14 @@ struct Lqr1D {
         const double g = P.p[0];
         dH[0] = 0; dH[1] = X[2]; dH[2] = X[1]; dH[3] = g * g * X[3] - 2 * g * X[3]; dH[4] = 0;
     }
+    // optional trait: a FREE state component at an interior node is a SOFT way-point (the form the reference's one user of the hook
+    // has, vtolUAV.cpp:273-284): the state is continuous, the costate jumps by gain x the distance to the way-point
+    __device__ static void switching_state(const socp::ModelParams &P, double, int j, const double (&X)[S], const double (&Xp)[S], const double *Xd,
+                                           double &f_state, double &f_costate)
+    {
+        f_state = X[j] - Xp[j];
+        f_costate = (X[j + D] - Xp[j + D]) - P.p[0] * (X[j] - Xd[j]);
+    }
     __device__ static double switching_fn(const socp::ModelParams &P, double a, double b, double t, const double (&X)[S], const double (&Xp)[S])
     {
         return hamiltonian(P, a, b, t, X) - hamiltonian(P, a, b, t, Xp);

@@ -116,3 +116,55 @@ def test_unregistered_id_is_rejected():
     with pytest.raises(capi.SocpError) as e:
         capi.Context(4242)
     assert e.value.code == capi.ERR_UNSUPPORTED
+
+
+def test_interior_free_state_goes_to_the_models_switching_state_hook():
+    """a FREE state mode at an INTERIOR node hands the two residual rows of that component to
+    model::SwitchingStateFunction (shooting.cpp:1535-1538, model.hpp:339-341).  Device models bring it as the optional trait
+    switching_state (the example plugin: a soft way-point, the form of the reference's one user of the hook, vtolUAV.cpp:273-284);
+    a model without the trait gets the default hook's rows -- zeros -- instead of round 3's SOCP_ERR_UNSUPPORTED.  The rows enter the
+    fused residual, the FD rows and the FD Jacobian alike, and a solve with a soft way-point converges."""
+    from socp_amd import capi
+    capi.plugin_load(PLUGIN)
+    ctx = capi.Context(1001, nparams=1)
+    g = 1.0
+    mode_t = [capi.FIXED, capi.FIXED, capi.FIXED]
+    mode_x = np.zeros((3, 2), dtype=np.int32)
+    mode_x[1, 0] = capi.FREE                       # position at the middle node: soft way-point
+    mode_x[1, 1] = capi.CONTINUOUS
+    Xn = np.zeros((3, 4))
+    Xn[1, 0] = 0.7                                 # the way-point
+    Xn[2, 0] = 1.0
+    n = ctx.problem_set(mode_t, mode_x, [0.0, 0.5, 1.0], Xn)
+    assert n == 8
+    rng = np.random.default_rng(2)
+    z = rng.uniform(-1, 1, 8)
+    F = ctx.residual(z)
+    Xend = ctx.integrate_batch(0.0, 0.5, z[None, :4])[0]
+    Xp = z[4:8]
+    assert F[4] == Xend[0] - Xp[0]                                           # state continuous
+    assert F[6] == (Xend[2] - Xp[2]) - g * (Xend[0] - 0.7)                   # costate jump = gain x distance to the way-point
+    assert F[5] == Xend[1] - Xp[1] and F[7] == Xend[3] - Xp[3]               # the CONTINUOUS component beside it
+    rows = ctx.fd_rows(z[None, :])[0]
+    assert np.array_equal(rows[0], F)
+    J = ctx.fd_jacobian(z, F)
+    assert np.isfinite(J).all() and abs(J[6, 6] + 1.0) <= 1e-6               # d row 6 / d p_x(node 1) = -1
+    out = capi.hybrd(lambda v: ctx.residual(v), np.array([0.0, 0.0, -1.0, -1.0, 0.5, 0.5, -1.0, -1.0]), xtol=1e-12, epsfcn=1e-15,
+                     fdjac=lambda x, f, e: ctx.fd_jacobian(x, f, epsfcn=e))
+    assert out["info"] == 1 and np.max(np.abs(ctx.residual(out["x"]))) <= 1e-9
+    ctx.close()
+    # a model without the trait: accepted, rows zero (the default hook is a no-op)
+    gd = capi.Context(capi.MODEL_GODDARD)
+    gd.set_param("mu2", 1.0)
+    mx = np.zeros((3, 7), dtype=np.int32)
+    mx[1] = capi.CONTINUOUS
+    mx[1, 2] = capi.FREE
+    mx[2, 3:] = capi.FREE
+    Xg = np.zeros((3, 14))
+    Xg[0, :7] = [0.999949994, 1e-4, 0.01, 1e-10, 1e-10, 1e-10, 1.0]
+    Xg[2, 0] = 1.01
+    assert gd.problem_set([capi.FIXED, capi.CONTINUOUS, capi.FIXED], mx, [0.0, 0.1, 0.2], Xg) == 28
+    zg = np.concatenate([Xg[0, :7], [-8.1, 7.8e-3, 0.78, -0.48, 5.7e-4, 5.7e-2, 0.0996]] * 2)
+    Fg = gd.residual(zg)
+    assert Fg[14 + 2] == 0.0 and Fg[14 + 2 + 7] == 0.0 and np.all(Fg[[14, 15, 17, 21, 22]] != 0.0)
+    gd.close()
