@@ -396,18 +396,20 @@ __device__ __forceinline__ void segment_residual(const ModelParams &P, const Pro
 #pragma unroll
         for (int j = 0; j < D; j++) {
             const int row = S * (i + 1) + j;
-            if (mx[j] == 0) {                               // FIXED: pin both sides
-                emit(row, X[j] - xd[j]);
-                emit(row + D, Xp[j] - xd[j]);
-            } else if (mx[j] == 1) {                        // FREE: the model's SwitchingStateFunction (shooting.cpp:1535-1538)
-                double fs = 0.0, fc = 0.0;
-                if constexpr (has_switching_state<Mdl>::value) Mdl::switching_state(P, t2, j, X, Xp, xd, fs, fc);
-                emit(row, fs);
-                emit(row + D, fc);
-            } else {                                        // CONTINUOUS
-                emit(row, X[j] - Xp[j]);
-                emit(row + D, X[j + D] - Xp[j + D]);
+            // FIXED pins both sides; CONTINUOUS: state and costate jumps; FREE: the model's SwitchingStateFunction
+            // (shooting.cpp:1535-1538).  Written as selects, with a branch only around the optional hook: a three-way branch here
+            // made the example plugin's residual kernel fault on gfx950 (hipcc 7.2: a scalar load through a clobbered base
+            // register), and selects are what the two-way form compiled to anyway.
+            const int mode = mx[j];
+            const double xdj = xd[j];
+            double fs = 0.0, fc = 0.0;
+            if constexpr (has_switching_state<Mdl>::value) {
+                if (mode == 1) Mdl::switching_state(P, t2, j, X, Xp, xd, fs, fc);
             }
+            const double a = mode == 0 ? X[j] - xdj : (mode == 1 ? fs : X[j] - Xp[j]);
+            const double b = mode == 0 ? Xp[j] - xdj : (mode == 1 ? fc : X[j + D] - Xp[j + D]);
+            emit(row, a);
+            emit(row + D, b);
         }
     }
     if (i == M - 1) {
