@@ -6,6 +6,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -30,6 +31,11 @@ public:
         for (std::thread &t : th_) t.join();
     }
     int size() const { return n_; }
+    // The tasks may throw (the segment workers of the host shooting path run USER model code: ComputeTraj, the boundary
+    // functions, SwitchingStateFunction): the first exception of a batch -- whichever thread raised it -- is kept, the batch is
+    // drained (no task starts after it; the workers are waited for, the job pointer is cleared) and the exception is rethrown on
+    // the CALLING thread, where a throw from the serial path would have surfaced (a throw on a worker called
+    // std::terminate, a throw on the caller unwound while workers still used the stack-local job).
     template <class Body>
     void run(int tasks, Body &&body)
     {
@@ -38,19 +44,39 @@ public:
         std::function<void(int)> fn = body;
         {
             std::lock_guard<std::mutex> lk(m_);
-            job_ = &fn; tasks_ = tasks; next_.store(0); busy_.store(n_ - 1); gen_.fetch_add(1);
+            job_ = &fn; tasks_ = tasks; next_.store(0); busy_.store(n_ - 1); failed_.store(false); error_ = nullptr; gen_.fetch_add(1);
         }
         cv_start_.notify_all();
-        for (int t; (t = next_.fetch_add(1)) < tasks;) fn(t);
+        take_tasks(fn, tasks);
         if (!spin_until([this]() { return busy_.load() == 0; })) {
             std::unique_lock<std::mutex> lk(m_);
             cv_done_.wait(lk, [this]() { return busy_.load() == 0; });
         }
-        std::lock_guard<std::mutex> lk(m_);     // the last worker has left its critical section
-        job_ = nullptr;
+        std::exception_ptr err;
+        {
+            std::lock_guard<std::mutex> lk(m_);     // the last worker has left its critical section
+            job_ = nullptr;
+            err = error_;
+            error_ = nullptr;
+        }
+        if (err) std::rethrow_exception(err);
     }
 
 private:
+    // this thread's share of a batch; an exception ends the batch for everybody (the counter is pushed past the end)
+    void take_tasks(const std::function<void(int)> &fn, int tasks)
+    {
+        for (int t; !failed_.load(std::memory_order_relaxed) && (t = next_.fetch_add(1)) < tasks;) {
+            try {
+                fn(t);
+            } catch (...) {
+                std::lock_guard<std::mutex> lk(m_);
+                if (!error_) error_ = std::current_exception();
+                failed_.store(true);
+                next_.store(tasks);
+            }
+        }
+    }
     // A batch is tens of microseconds of work per thread and the next one follows at once, while waking a parked thread
     // costs 50-100 us: wait actively for a SHORT, bounded time (about 40 us), then park on the condition variable.
     template <class Pred>
@@ -80,8 +106,7 @@ private:
                 std::lock_guard<std::mutex> lk(m_);
                 seen = gen_.load(); fn = job_; tasks = tasks_;
             }
-            if (fn)
-                for (int t; (t = next_.fetch_add(1)) < tasks;) (*fn)(t);
+            if (fn) take_tasks(*fn, tasks);
             bool last;
             {
                 std::lock_guard<std::mutex> lk(m_);
@@ -97,7 +122,8 @@ private:
     const std::function<void(int)> *job_ = nullptr;
     int tasks_ = 0;
     std::atomic<int> next_{0}, busy_{0}, gen_{0};
-    std::atomic<bool> stop_{false};
+    std::atomic<bool> stop_{false}, failed_{false};
+    std::exception_ptr error_;                 // first exception of the batch in hand (guarded by m_)
 };
 
 }  // namespace socp

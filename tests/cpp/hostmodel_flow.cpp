@@ -3,6 +3,9 @@
 // It must still solve through shooting::SolveOCP -- on the host, with a warning -- and the reference-style one-step calls
 // RK4(t, X, dt, function, context) (interceptor.cpp:117) and RK1/RK2/RK4(t, X, dt, modelStruct) must work.
 //   hostmodel_flow <numMulti> [numThread]        (no GPU needed; numThread > 1: segment workers on the host)
+//   hostmodel_flow throws <numThread>            a model whose Model() throws inside one segment: the exception must reach the caller
+//                                                of ResidualAt -- from a segment worker too (numThread > 1) -- and the shooting
+//                                                object must still work afterwards
 //   hostmodel_flow residual                      prints the residual of a 3-segment layout with FREE times (H rows, switching
 //                                                row) and mixed state modes at its initial guess (shooting::ResidualAt)
 // Problem: minimum-energy rest-to-rest transfer of a 1-D double integrator, x' = v, v' = u, cost = int u^2/2 dt;
@@ -10,6 +13,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -30,6 +34,18 @@ public:
     {
         const real u = -X[3];
         return mstate(1, u * u / 2 + X[2] * X[1] + X[3] * u);
+    }
+};
+
+// the same dynamics, but Model() throws while the state's position is beyond a threshold: reached in ONE segment of the layout below
+class lqr_throwing : public lqr_host
+{
+public:
+    real limit = 1e300;
+    virtual mstate Model(real const &t, mstate const &X, int isJac) const
+    {
+        if (X[0] > limit) throw std::out_of_range("lqr_throwing: position beyond the limit");
+        return lqr_host::Model(t, X, isJac);
     }
 };
 
@@ -75,6 +91,30 @@ int main(int argc, char **argv)
         for (size_t k = 0; k < F.size(); k++) std::printf("%s%.17g", k ? ", " : "", F[k]);
         std::printf("]}\n");
         return 0;
+    }
+    if (std::string(argv[1]) == "throws") {
+        // six segments whose node positions are 0, 1, ..., 5; Model() throws beyond 3.5: only the segments starting at nodes 4 and 5
+        // throw, i.e. tasks that the worker threads take when there are several
+        const int M = 6, threads = argc > 2 ? std::atoi(argv[2]) : 1;
+        lqr_throwing m;
+        shooting sh(m, M, threads);
+        sh.SetMode(model::FIXED, std::vector<int>(2, model::FIXED));
+        std::vector<real> vt(M + 1);
+        std::vector<model::mstate> vX(M + 1, model::mstate(4, 0.0));
+        for (int i = 0; i <= M; i++) { vt[i] = 0.1 * i; vX[i][0] = 1.0 * i; }
+        sh.InitShooting(vt, vX);
+        std::vector<real> z;
+        sh.GetParameters(z);
+        const std::vector<real> F0 = sh.ResidualAt(z);                 // no limit yet: the residual evaluates
+        m.limit = 3.5;
+        int caught = 0;
+        try { sh.ResidualAt(z); } catch (const std::out_of_range &) { caught = 1; }
+        int caught_again = 0;
+        try { sh.ResidualAt(z); } catch (const std::out_of_range &) { caught_again = 1; }      // the pool survived the first throw
+        m.limit = 1e300;
+        const std::vector<real> F1 = sh.ResidualAt(z);                 // ... and still computes the same numbers
+        std::printf("{\"threads\": %d, \"caught\": %d, \"caught_again\": %d, \"same_after\": %d}\n", threads, caught, caught_again, (int)(F0 == F1));
+        return (caught && caught_again && F0 == F1) ? 0 : 2;
     }
     const int M = std::atoi(argv[1]);
     const int threads = argc > 2 ? std::atoi(argv[2]) : 1;

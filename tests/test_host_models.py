@@ -33,6 +33,16 @@ def test_host_virtual_model_solves_through_shooting(M):
     assert out.stderr.count("no device dynamics") == 1         # the one-line warning, once
 
 
+@pytest.mark.parametrize("threads", [1, 2, 4])
+def test_exception_in_user_model_code_reaches_the_caller(threads):
+    """the segment workers of the host shooting path (numThread > 1, csrc/host_pool.hpp) run USER model code.  A throw
+    inside it -- on the calling thread or on a worker -- is rethrown to the caller of the evaluation, as it would be from the
+    serial path (round 3: std::terminate from a worker); the pool drains, stays usable, and computes the same numbers afterwards."""
+    out, recs = run("throws", threads)
+    assert out.returncode == 0, (out.returncode, out.stderr[-1000:])
+    assert recs[0] == {"threads": threads, "caught": 1, "caught_again": 1, "same_after": 1}
+
+
 def test_host_residual_rows_against_an_independent_restatement():
     """Every row kind of the host assembly (shooting.cpp:945-990, model.hpp:90-328): FREE interior time ->
     SwitchingTimesFunction row, FREE final time -> H row, FIXED / CONTINUOUS interior state modes, FREE final component."""
