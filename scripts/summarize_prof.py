@@ -40,6 +40,33 @@ def main():
             if i == 0 or "socp::" in r[0]:
                 lines.append(",".join('"%s"' % c if i and j == 0 else c for j, c in enumerate(r)))
     open(os.path.join(root, tag + "_kernel_stats.csv"), "w").write("\n".join(lines) + "\n")
+    # per-dispatch durations of the dominant kernel from the kernel trace: the average WITHOUT the first launch (code-object load,
+    # cold caches) beside the one rocprofv3's own stats file gives, and the HIP-event times of the un-profiled and of the profiled
+    # run of the same command on the same box (bench.py: roofline.kernel_ms) -- what a reader needs to recompute the line's frac
+    traces = sorted(glob.glob(os.path.join(stats_dir, "**", "*_kernel_trace.csv"), recursive=True), key=os.path.getmtime)
+    timing = {"kernel": kernel}
+    for f in traces[-1:]:
+        durs = []
+        for r in csv.DictReader(open(f)):
+            if kernel in r.get("Kernel_Name", "") and float(r.get("Grid_Size", 0) or 0) > 4096:
+                durs.append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6))
+        durs = [d for _, d in sorted(durs)]
+        if durs:
+            timing.update({"calls": len(durs), "ms_each": durs, "avg_ms_all_calls": sum(durs) / len(durs),
+                           "avg_ms_without_first": sum(durs[1:]) / max(1, len(durs) - 1) if len(durs) > 1 else durs[0],
+                           "min_ms": min(durs), "max_ms": max(durs)})
+    for key in ("unprofiled", "profiled"):
+        path = extra.pop(key, None)
+        if path and os.path.exists(path):
+            try:
+                line = [l for l in open(path) if l.startswith("{")][-1]
+                d = json.loads(line)
+                timing[key + "_hip_event_kernel_ms"] = d["roofline"]["kernel_ms"]
+                timing[key + "_ms_per_step"] = d["ms_per_step"]
+                timing[key + "_frac"] = d["roofline"]["frac"]
+            except Exception as exc:
+                timing[key + "_error"] = str(exc)
+    json.dump(timing, open(os.path.join(root, tag + "_timing.json"), "w"), indent=1)
     c = {}
     for d in (fetch_dir, write_dir, sq_dir):
         c.update(counters(d, kernel))
