@@ -251,6 +251,8 @@ template <int NCH>
 __device__ __forceinline__ double panel_core(f64x4 (&S)[NCH], int np, int nch, double *Vl, double *__restrict__ rdiag, int lane, FProf &prof)
 {
     double tau_mine = 0.0, rdiag_mine = 0.0;                                 // lane t (t < 16) keeps tau_t and diag(R)_t
+    double ss_carried = 0.0;                                                 // this lane's share of |its column|^2 below row t, from the last axpy pass
+    bool have_ss = false;
     // a real loop over the panel's columns (unrolled 16 times the body exceeds what the compiler will unroll, and then every
     // "constant" index below becomes a run-time register index, i.e. scratch): t is uniform, lanes and registers are SELECTED
 #pragma unroll 1
@@ -263,22 +265,28 @@ __device__ __forceinline__ double panel_core(f64x4 (&S)[NCH], int np, int nch, d
         if (live) {
             // |column t| over the rows from the diagonal down (row >= t: a question in chunk 0 only); every lane does its own
             // column, the quad of column t is the one that counts.  Four partial sums: the chain of dependent adds is the latency.
-            double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
-            { const double x = (g >= t) ? S[0][0] : 0.0; q0 = x * x; }
-            { const double x = (g + 4 >= t) ? S[0][1] : 0.0; q1 = x * x; }
-            { const double x = (g + 8 >= t) ? S[0][2] : 0.0; q2 = x * x; }
-            { const double x = (g + 12 >= t) ? S[0][3] : 0.0; q3 = x * x; }
+            // (the previous column's axpy pass has already summed the squares of what it wrote: a pass of its own only for the
+            // panel's first column and after a skipped reflector)
+            double mine_ss = ss_carried;
+            if (!have_ss) {
+                double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+                { const double x = (g >= t) ? S[0][0] : 0.0; q0 = x * x; }
+                { const double x = (g + 4 >= t) ? S[0][1] : 0.0; q1 = x * x; }
+                { const double x = (g + 8 >= t) ? S[0][2] : 0.0; q2 = x * x; }
+                { const double x = (g + 12 >= t) ? S[0][3] : 0.0; q3 = x * x; }
 #pragma unroll
-            for (int cb = 0; cb < NCH; cb += kBlk) {                         // (chunks of a block beyond the matrix hold zeros)
-                if (cb < nch) {
+                for (int cb = 0; cb < NCH; cb += kBlk) {                     // (chunks of a block beyond the matrix hold zeros)
+                    if (cb < nch) {
 #pragma unroll
-                    for (int cc = (cb ? cb : 1); cc < cb + kBlk && cc < NCH; cc++) {
-                        q0 = __builtin_fma(S[cc][0], S[cc][0], q0); q1 = __builtin_fma(S[cc][1], S[cc][1], q1);
-                        q2 = __builtin_fma(S[cc][2], S[cc][2], q2); q3 = __builtin_fma(S[cc][3], S[cc][3], q3);
+                        for (int cc = (cb ? cb : 1); cc < cb + kBlk && cc < NCH; cc++) {
+                            q0 = __builtin_fma(S[cc][0], S[cc][0], q0); q1 = __builtin_fma(S[cc][1], S[cc][1], q1);
+                            q2 = __builtin_fma(S[cc][2], S[cc][2], q2); q3 = __builtin_fma(S[cc][3], S[cc][3], q3);
+                        }
                     }
                 }
+                mine_ss = (q0 + q1) + (q2 + q3);
             }
-            const double ss = from_lane(quad_sum((q0 + q1) + (q2 + q3)), 4 * t);
+            const double ss = from_lane(quad_sum(mine_ss), 4 * t);
             bool plain = false;
             if (ss != ss) {
                 ajnorm = ss;                                                 // a NaN in the column: handed on, as MINPACK's enorm does
@@ -337,12 +345,21 @@ __device__ __forceinline__ double panel_core(f64x4 (&S)[NCH], int np, int nch, d
             // v = a / ajnorm + e_t from the diagonal down, in straight-line code: every lane multiplies, all but column t's by exactly 1
             // (a divergent branch around 4 NCH register updates makes the compiler keep two copies of the strip)
             const bool mine = m == t;
-            const double f1 = mine ? s1 : 1.0, f2 = mine ? inv : 1.0;
+            if (s1 != 1.0) {                                                 // (uniform, rare: the column first goes up by 2^600, exactly)
+                const double f1 = mine ? s1 : 1.0;
+#pragma unroll
+                for (int r = 0; r < 4; r++) S[0][r] *= (mine && g + 4 * r >= t) ? s1 : 1.0;
+#pragma unroll
+                for (int cc = 1; cc < NCH; cc++) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) S[cc][r] *= f1;
+                }
+            }
+            const double f2 = mine ? inv : 1.0;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int rr = g + 4 * r;
-                const bool below = mine && rr >= t;
-                const double x = (S[0][r] * (below ? s1 : 1.0)) * (below ? inv : 1.0);
+                const double x = S[0][r] * ((mine && rr >= t) ? inv : 1.0);
                 S[0][r] = (mine && rr == t) ? x + 1.0 : x;
             }
 #pragma unroll
@@ -351,7 +368,7 @@ __device__ __forceinline__ double panel_core(f64x4 (&S)[NCH], int np, int nch, d
 #pragma unroll
                     for (int cc = (cb ? cb : 1); cc < cb + kBlk && cc < NCH; cc++) {
 #pragma unroll
-                        for (int r = 0; r < 4; r++) S[cc][r] = (S[cc][r] * f1) * f2;
+                        for (int r = 0; r < 4; r++) S[cc][r] *= f2;
                     }
                 }
             }
@@ -399,6 +416,8 @@ __device__ __forceinline__ double panel_core(f64x4 (&S)[NCH], int np, int nch, d
             const double dot = quad_sum((d0 + d1) + (d2 + d3));
             const double coef = (m > t) ? dot * tau_t : 0.0;
             wave_lds_fence();                                                // (re-read v below rather than hold 4 NCH more registers)
+            // ... and while the columns are rewritten, the squares of what is written below row t: the next column's norm
+            double n0 = 0.0, n1 = 0.0, n2 = 0.0, n3 = 0.0;
 #pragma unroll
             for (int cb = 0; cb < NCH; cb += kBlk) {
                 if (cb < nch) {
@@ -407,10 +426,29 @@ __device__ __forceinline__ double panel_core(f64x4 (&S)[NCH], int np, int nch, d
                     for (int q = 0; q < 4 * kBlk; q++) v[q] = vp[(16 * cb + 4 * q) * kLdV];
                     SOCP_SCHED_FENCE();
 #pragma unroll
-                    for (int q = 0; q < 4 * kBlk; q++) if (cb + q / 4 < NCH) S[cb + q / 4][q % 4] = __builtin_fma(-coef, v[q], S[cb + q / 4][q % 4]);
+                    for (int q = 0; q < 4 * kBlk; q += 4) {
+                        const int cc = cb + q / 4;
+                        if (cc < NCH) {
+#pragma unroll
+                            for (int r = 0; r < 4; r++) S[cc][r] = __builtin_fma(-coef, v[q + r], S[cc][r]);
+                            if (cc == 0) {
+                                { const double x = (g > t) ? S[0][0] : 0.0; n0 = x * x; }
+                                { const double x = (g + 4 > t) ? S[0][1] : 0.0; n1 = x * x; }
+                                { const double x = (g + 8 > t) ? S[0][2] : 0.0; n2 = x * x; }
+                                { const double x = (g + 12 > t) ? S[0][3] : 0.0; n3 = x * x; }
+                            } else {
+                                n0 = __builtin_fma(S[cc][0], S[cc][0], n0); n1 = __builtin_fma(S[cc][1], S[cc][1], n1);
+                                n2 = __builtin_fma(S[cc][2], S[cc][2], n2); n3 = __builtin_fma(S[cc][3], S[cc][3], n3);
+                            }
+                        }
+                    }
                     SOCP_SCHED_FENCE();
                 }
             }
+            ss_carried = (n0 + n1) + (n2 + n3);
+            have_ss = true;
+        } else {
+            have_ss = false;                                                 // nothing was rewritten: the next column sums its own squares
         }
         prof.add(FP_COL_APPLY, t_apply);
     }
