@@ -48,7 +48,8 @@ def main():
     for f in traces[-1:]:
         durs = []
         for r in csv.DictReader(open(f)):
-            if kernel in r.get("Kernel_Name", "") and float(r.get("Grid_Size", 0) or 0) > 4096:
+            grid = float(r.get("Grid_Size", 0) or 0) or float(r.get("Grid_Size_X", 0) or 0)      # (the trace has one column per dimension)
+            if kernel in r.get("Kernel_Name", "") and grid > 4096:
                 durs.append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6))
         durs = [d for _, d in sorted(durs)]
         if durs:
