@@ -141,6 +141,64 @@ __device__ __forceinline__ void strip_store(const f64x4 (&S)[NCH], double *__res
     }
 }
 
+// |column|_2 of the strip's columns from its registers -- the Jacobian's column norms (MINPACK's acnorm) are taken when a strip is
+// first loaded, at panel 0, where every strip holds whole columns: no pass of its own over the matrix.  QUAD: the panel wave's layout
+// (a column's row groups in one quad) / the MFMA layout (row groups 16 lanes apart).  Plain sum of squares where that is safe, the
+// column's largest entry as scale otherwise (tiny / huge entries, zero columns; a NaN is handed on).  Every lane returns its
+// column's norm.
+template <int NCH, bool QUAD>
+__device__ __forceinline__ double strip_column_norm(const f64x4 (&S)[NCH])
+{
+    double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+#pragma unroll
+    for (int cc = 0; cc < NCH; cc++) {
+        q0 = __builtin_fma(S[cc][0], S[cc][0], q0); q1 = __builtin_fma(S[cc][1], S[cc][1], q1);
+        q2 = __builtin_fma(S[cc][2], S[cc][2], q2); q3 = __builtin_fma(S[cc][3], S[cc][3], q3);
+    }
+    double ss = (q0 + q1) + (q2 + q3);
+    if (QUAD) ss = quad_sum(ss);
+    else { ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32); }
+    if (ss != ss) return ss;
+    if (ss > 1e-280 && ss < 1e280) return sqrt(ss);
+    double amax = 0.0;
+#pragma unroll
+    for (int cc = 0; cc < NCH; cc++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) amax = fmax(amax, fabs(S[cc][r]));
+    }
+    if (QUAD) amax = quad_max(amax);
+    else { amax = fmax(amax, __shfl_xor(amax, 16)); amax = fmax(amax, __shfl_xor(amax, 32)); }
+    if (!(amax > 0 && amax < INFINITY)) return amax;                         // a zero column, or an infinity handed on
+    double s2 = 0.0;
+#pragma unroll
+    for (int cc = 0; cc < NCH; cc++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) { const double x = S[cc][r] / amax; s2 += x * x; }
+    }
+    if (QUAD) s2 = quad_sum(s2);
+    else { s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32); }
+    return amax * sqrt(s2);
+}
+
+// The first 16 rows of a strip are, once the panel whose rows they are has been applied, rows of R for good: they go to the
+// packed R (row i of R: diag, then (i, i + 1 .. n - 1)) and, for the column that carries fvec, to Q^T fvec -- at the moment they are
+// in registers, not in a pass of their own over the finished matrix.  `above`: only the entries strictly right of the diagonal
+// (the panel's own block; a trailing strip lies wholly right of it).
+__device__ __forceinline__ void r_rows_out(const f64x4 &top, double *__restrict__ rpack, double *__restrict__ qtf, int n, int row0, int c0, int g, int m,
+                                           bool above)
+{
+    g = here(g); m = here(m);
+    const int col = c0 + m;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int row = row0 + g + 4 * r;
+        if (row < n && (!above || col > row)) {
+            if (col < n) rpack[row_off(n, row) + (col - row)] = top[r];
+            else if (col == n) qtf[row] = top[r];
+        }
+    }
+}
+
 // The passes over a strip's chunks run in blocks of kBlk chunks behind ONE uniform test per block (is any of it inside the matrix?):
 // with a test per chunk every chunk is a basic block of its own, the LDS reads of one chunk cannot be issued while the previous
 // chunk still computes, and each pass pays an LDS round trip per chunk -- measured: 6 000 cycles per column of the panel, most of
@@ -527,29 +585,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         Work w(ws + (long)p * ws_stride, n, ld, lds);
         double *A = w.A, *rdiag = w.wa1, *acnorm = w.wa2, *Tsave = w.V;
         FProf prof(tid);
-        // ---- column norms of the Jacobian (scaled by the column's largest entry where a plain sum of squares is unsafe), fvec into column n
-        for (int j = tid; j < n; j += 256) {
-            double ss = 0.0, amax = 0.0;
-            int i = 0;
-            for (; i + 8 <= n; i += 8) {
-                double x[8];
-#pragma unroll
-                for (int q = 0; q < 8; q++) x[q] = A[(long)(i + q) * ld + j];
-#pragma unroll
-                for (int q = 0; q < 8; q++) { ss += x[q] * x[q]; amax = fmax(amax, fabs(x[q])); }
-            }
-            for (; i < n; i++) { const double x = A[(long)i * ld + j]; ss += x * x; amax = fmax(amax, fabs(x)); }
-            double nrm = sqrt(ss);
-            if (ss == ss && !(ss > 1e-280 && ss < 1e280)) {
-                nrm = amax;                                                  // zero, or an infinity handed on
-                if (amax > 0 && amax < INFINITY) {
-                    double s2 = 0.0;
-                    for (int k = 0; k < n; k++) { const double x = A[(long)k * ld + j] / amax; s2 += x * x; }
-                    nrm = amax * sqrt(s2);
-                }
-            }
-            acnorm[j] = nrm;
-        }
+        // ---- fvec rides along as column n (the column norms of the Jacobian are taken from the strips as they are first loaded)
         for (int i = tid; i < n; i += 256) A[(long)i * ld + n] = w.fvec[i];
         __syncthreads();
         prof.mark(FP_NORMS);
@@ -561,8 +597,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             f64x4 P[NCH];
             const int np0 = n < 16 ? n : 16, nch0 = (n + 15) >> 4;
             strip_load<NCH>(P, A, ld, n, 0, nch0, 0, n + 1, lane & 3, lane >> 2);          // (column n = fvec rides along when it falls into this strip)
+            {
+                const double nrm = strip_column_norm<NCH, true>(P);
+                if ((lane & 3) == 0 && (lane >> 2) < n) acnorm[lane >> 2] = nrm;
+            }
             const double tau = panel_core<NCH>(P, np0, nch0, lds, rdiag, lane, prof);
             strip_store<NCH>(P, A, ld, n, 0, nch0, 0, n + 1, lane & 3, lane >> 2);
+            r_rows_out(P[0], w.r, w.qtf, n, 0, 0, lane & 3, lane >> 2, true);
+            if (lane < np0) w.r[row_off(n, lane)] = rdiag[lane];
             panel_T<NCH>(nch0, tau, lds, lds + 16 * NCH * kLdV, Gl, Tsave, lane);
         }
         prof.mark(FP_PANEL);
@@ -579,17 +621,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 f64x4 S[NCH];
                 const unsigned long long t_la = prof.stamp();
                 strip_load<NCH>(S, A, ld, n, j0, nch, j0 + 16, n + 1, g, m);
+                if (pi == 0) {
+                    const double nrm = strip_column_norm<NCH, false>(S);
+                    if (g == 0 && 16 + m < n) acnorm[16 + m] = nrm;
+                }
                 strip_apply<NCH>(S, nch, Vc, Tc, lane);
                 prof.add(FP_LA_APPLY, t_la);
                 const unsigned long long t_cv = prof.stamp();
-                // its first 16 rows are rows of R now: they go home; the rest is the next panel, in the panel layout
-                {
-                    const int col = j0 + 16 + here(m);
-                    if (col <= n) {
-#pragma unroll
-                        for (int r = 0; r < 4; r++) A[(long)(j0 + here(g) + 4 * r) * ld + col] = S[0][r];
-                    }
-                }
+                // its first 16 rows are rows of R now (packed R / Q^T fvec); the rest is the next panel, in the panel layout.  (A keeps
+                // nothing of those rows: qform zeroes them.)
+                r_rows_out(S[0], w.r, w.qtf, n, j0, j0 + 16, g, m, false);
                 SOCP_SCHED_FENCE();
 #pragma unroll
                 for (int cc = 0; cc + 1 < NCH; cc++) {                       // chunk by chunk, in place: one strip's worth of registers, not two
@@ -605,6 +646,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 prof.add(FP_COLS, t_cols);
                 const unsigned long long t_st = prof.stamp();
                 strip_store<NCH>(S, A, ld, n, j1, nch - 1, j1, n + 1, lane & 3, lane >> 2);
+                r_rows_out(S[0], w.r, w.qtf, n, j1, j1, lane & 3, lane >> 2, true);
+                if (lane < np1) w.r[row_off(n, j1 + lane)] = rdiag[j1 + lane];
                 prof.add(FP_LA_STORE, t_st);
                 const unsigned long long t_T = prof.stamp();
                 panel_T<NCH>(nch - 1, tau, Vn, Tn, Gl, Tsave + 256 * (pi + 1), lane);
@@ -617,7 +660,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int c0 = first + 16 * slot; c0 <= n; c0 += stride) {
                     f64x4 S[NCH];
                     strip_load<NCH>(S, A, ld, n, j0, nch, c0, n + 1, g, m);
+                    if (pi == 0) {
+                        const double nrm = strip_column_norm<NCH, false>(S);
+                        if (g == 0 && c0 + m < n) acnorm[c0 + m] = nrm;
+                    }
                     strip_apply<NCH>(S, nch, Vc, Tc, lane);
+                    r_rows_out(S[0], w.r, w.qtf, n, j0, c0, g, m, false);
                     strip_store<NCH>(S, A, ld, n, j0, nch, c0, n + 1, g, m);
                 }
                 prof.mark(FP_TRAIL);
@@ -625,13 +673,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             __syncthreads();
             prof.mark(FP_TRAIL_WAIT);
         }
-        // ---- Q^T fvec, R packed by rows (row i: rdiag[i], then A(i, i + 1 .. n - 1)), "singular"
-        for (int i = tid; i < n; i += 256) w.qtf[i] = A[(long)i * ld + n];
+        // ---- (Q^T fvec and the packed R have been written row block by row block as the strips passed) "singular":
         int zero = 0;
-        for (int i = wave; i < n; i += 4) {
-            const long off = row_off(n, i);
-            for (int k = i + lane; k < n; k += 64) w.r[off + (k - i)] = (k == i) ? rdiag[i] : A[(long)i * ld + k];
-        }
         for (int j = tid; j < n; j += 256) zero |= (rdiag[j] == 0) ? 1 : 0;
         const int sing = __syncthreads_or(zero);
         prof.mark(FP_RPACK);
@@ -645,10 +688,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             double *V0 = lds, *T0 = V0 + 16 * NCH * kLdV, *V1 = lds + kPanelDoubles, *T1 = V1 + 16 * NCH * kLdV;
             // the vectors of both panels with rows relative to the LOWER panel's first row (the upper panel's first 16 rows are zero)
             const int nchb = blocks_of(nch) < NCH ? blocks_of(nch) : NCH;                // (rows from the matrix's end to the block's end: zeros)
-            for (int e = tid; e < nchb * 256; e += 256) {
-                const int rr = e >> 4, t = e & 15, row = j0 + rr;
-                V0[rr * kLdV + t] = (rr >= t && t < np_lo && row < n) ? A[(long)row * ld + j0 + t] : 0.0;
-                if (pair) V1[rr * kLdV + t] = (rr - 16 >= t && t < np_hi && row < n) ? A[(long)row * ld + j0 + 16 + t] : 0.0;
+            {
+                // (all of a thread's loads first, then the LDS stores: with load and store in one loop body the loads go out one
+                // at a time, each waiting for the previous store's address arithmetic)
+                const int t = tid & 15, r0 = tid >> 4;
+                double x0[NCH], x1[NCH];
+#pragma unroll
+                for (int it = 0; it < NCH; it++) {
+                    const int rr = r0 + 16 * it, row = j0 + rr;
+                    const bool in = it < nchb && row < n;
+                    x0[it] = (in && rr >= t && t < np_lo) ? A[(long)row * ld + j0 + t] : 0.0;
+                    x1[it] = (pair && in && rr - 16 >= t && t < np_hi) ? A[(long)row * ld + j0 + 16 + t] : 0.0;
+                }
+#pragma unroll
+                for (int it = 0; it < NCH; it++) {
+                    if (it < nchb) {
+                        const int rr = r0 + 16 * it;
+                        V0[rr * kLdV + t] = x0[it];
+                        if (pair) V1[rr * kLdV + t] = x1[it];
+                    }
+                }
             }
             T0[(tid & 15) * 16 + (tid >> 4)] = Tsave[256 * lo + tid];                     // X = T^T
             if (pair) T1[(tid & 15) * 16 + (tid >> 4)] = Tsave[256 * (lo + 1) + tid];
