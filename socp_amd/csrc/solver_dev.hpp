@@ -844,6 +844,67 @@ SOCP_HD bool r1updt(const E &ex, int n, Work &wk)
     return sing;
 }
 
+// The same sweeps for a row of Q in global memory, in pieces of 16 entries = one 128-byte line per thread, fetched with four 16-byte
+// loads and written back the same way.  A thread owns a row, so a wavefront's load touches 64 different lines whatever its width:
+// with 8-byte loads every line is requested sixteen times over, and with a dozen wavefronts per CU walking 64 rows each the lines
+// do not survive in the vector cache between requests.  The ARITHMETIC is rotate_row's -- the same rotations in the same order
+// on the same numbers -- so the result is bit-identical.  `a` must be 16-byte aligned (rows of the solver's matrix are: ld is a
+// multiple of 8 doubles); the pieces are aligned to 16 entries, the ragged ends go through rotate_row's scalar form.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double rotate_row_lines(double *a, const double *c, const double *s, int n, double an, bool first)
+{
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    constexpr int kLine = 16;
+    const int last = n - 2;                                  // the sweeps cover j = 0 .. n - 2
+    if (last < 2 * kLine) return rotate_row(a, c, s, n, an, first);
+    const int top = (last + 1) / kLine * kLine;              // entries [top, last] are the ragged end above the last whole line
+    if (first) {
+        for (int j = last; j >= top; j--) {
+            const double aj = a[j];
+            const double temp = c[j] * aj - s[j] * an;
+            an = s[j] * aj + c[j] * an;
+            a[j] = temp;
+        }
+        for (int j0 = top - kLine; j0 >= 0; j0 -= kLine) {
+            d2 v[kLine / 2];
+#pragma unroll
+            for (int q = 0; q < kLine / 2; q++) v[q] = *reinterpret_cast<const d2 *>(a + j0 + 2 * q);
+#pragma unroll
+            for (int u = kLine - 1; u >= 0; u--) {
+                const double aj = v[u >> 1][u & 1], cj = c[j0 + u], sj = s[j0 + u];
+                const double temp = cj * aj - sj * an;
+                an = sj * aj + cj * an;
+                v[u >> 1][u & 1] = temp;
+            }
+#pragma unroll
+            for (int q = 0; q < kLine / 2; q++) *reinterpret_cast<d2 *>(a + j0 + 2 * q) = v[q];
+        }
+    } else {
+        for (int j0 = 0; j0 < top; j0 += kLine) {
+            d2 v[kLine / 2];
+#pragma unroll
+            for (int q = 0; q < kLine / 2; q++) v[q] = *reinterpret_cast<const d2 *>(a + j0 + 2 * q);
+#pragma unroll
+            for (int u = 0; u < kLine; u++) {
+                const double aj = v[u >> 1][u & 1], cj = c[j0 + u], sj = s[j0 + u];
+                const double temp = cj * aj + sj * an;
+                an = -sj * aj + cj * an;
+                v[u >> 1][u & 1] = temp;
+            }
+#pragma unroll
+            for (int q = 0; q < kLine / 2; q++) *reinterpret_cast<d2 *>(a + j0 + 2 * q) = v[q];
+        }
+        for (int j = top; j <= last; j++) {
+            const double aj = a[j];
+            const double temp = c[j] * aj + s[j] * an;
+            an = -s[j] * aj + c[j] * an;
+            a[j] = temp;
+        }
+    }
+    return an;
+}
+#endif
+
 // minpack.cpp: r1mpyq on Q (n x n, row-major here) and on qtf, with the rotations of the last r1updt (f7, f4) decoded into
 // f0 .. f3
 template <class E>
@@ -859,8 +920,13 @@ SOCP_HD void r1mpyq_all(const E &ex, int n, int ld, Work &wk)
     SOCP_PAR_FOR(i, 0, n) {                                  // a row of Q goes through all rotations on its own
         double *a = wk.A + (long)i * ld;
         double an = a[n - 1];
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SOCP_SOLVER_NARROW_ROWS)
+        an = rotate_row_lines(a, c1, s1, n, an, true);       // (whole cache lines per thread; the same arithmetic)
+        an = rotate_row_lines(a, c2, s2, n, an, false);
+#else
         an = rotate_row(a, c1, s1, n, an, true);
         an = rotate_row(a, c2, s2, n, an, false);
+#endif
         a[n - 1] = an;
     }
     if (ex.tid == ex.nt - 1) {                               // qtf is the one-row case (on the thread least likely to own a row)
