@@ -572,8 +572,10 @@ __device__ __forceinline__ double to_quad_layout(double x, int lane)
 
 // One workgroup of 256 threads per problem.  LDS (doubles): two panels' V[16 NCH][kLdV] and T[256] (qrfac: the panel being applied and
 // the next one being factorised -- look-ahead; qform: the two panels applied in one pass), Gl[256]
-template <int NCH>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void factor_fast_kernel(Config c, State *states, double *ws, long ws_stride, const int *__restrict__ list, int count)
+// WPE: wavefronts per SIMD the registers are budgeted for -- 2 for the 16-chunk strip (128 of 256 VGPRs are the strip), more for the
+// smaller strips: the kernel is latency-bound, other problems' wavefronts are what fills its waits
+template <int NCH, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void factor_fast_kernel(Config c, State *states, double *ws, long ws_stride, const int *__restrict__ list, int count)
 {
     extern __shared__ double lds[];
     constexpr int kPanelDoubles = 16 * NCH * kLdV + 256;
@@ -759,15 +761,15 @@ hipError_t raise_lds_limit_fast()
     return e;
 }
 
-template <int NCH>
+template <int NCH, int WPE>
 hipError_t launch_nch(hipStream_t st, const PoolDev &pool, const int *d_list, int count)
 {
     const size_t lds_bytes = sizeof(double) * (size_t)(2 * (16 * NCH * kLdV + 256) + 256);
     if (lds_bytes > 65536) {
-        const hipError_t raised = raise_lds_limit_fast<factor_fast_kernel<NCH>>();
+        const hipError_t raised = raise_lds_limit_fast<factor_fast_kernel<NCH, WPE>>();
         if (raised != hipSuccess) return raised;
     }
-    hipLaunchKernelGGL(factor_fast_kernel<NCH>, dim3((unsigned)count), dim3(256), lds_bytes, st, pool.cfg, pool.states, pool.ws, pool.ws_stride, d_list, count);
+    hipLaunchKernelGGL((factor_fast_kernel<NCH, WPE>), dim3((unsigned)count), dim3(256), lds_bytes, st, pool.cfg, pool.states, pool.ws, pool.ws_stride, d_list, count);
     return hipGetLastError();
 }
 
@@ -801,11 +803,17 @@ hipError_t launch_factor_fast(hipStream_t st, const PoolDev &pool, const int *d_
     const int n = pool.cfg.n;
     if (!fast_factor_applies(n) || pool.cfg.ld < n + 1) return hipErrorInvalidValue;
     // the strip's register count follows the problem size: 16 rows per chunk
-    if (n <= 64) return launch_nch<4>(st, pool, d_list, count);
-    if (n <= 96) return launch_nch<6>(st, pool, d_list, count);
-    if (n <= 128) return launch_nch<8>(st, pool, d_list, count);
-    if (n <= 192) return launch_nch<12>(st, pool, d_list, count);
-    return launch_nch<16>(st, pool, d_list, count);
+#ifndef SOCP_FACTOR_WPE_SMALL
+#define SOCP_FACTOR_WPE_SMALL 4
+#endif
+#ifndef SOCP_FACTOR_WPE_MID
+#define SOCP_FACTOR_WPE_MID 3
+#endif
+    if (n <= 64) return launch_nch<4, SOCP_FACTOR_WPE_SMALL>(st, pool, d_list, count);
+    if (n <= 96) return launch_nch<6, SOCP_FACTOR_WPE_SMALL>(st, pool, d_list, count);
+    if (n <= 128) return launch_nch<8, SOCP_FACTOR_WPE_MID>(st, pool, d_list, count);
+    if (n <= 192) return launch_nch<12, 2>(st, pool, d_list, count);
+    return launch_nch<16, 2>(st, pool, d_list, count);
 }
 
 }  // namespace devsolver
