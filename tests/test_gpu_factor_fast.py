@@ -21,7 +21,7 @@ def _problems(n, count, seed):
     return J, b
 
 
-@pytest.mark.parametrize("n", [39, 48, 64, 65, 85, 127, 128, 129, 200, 253, 256])
+@pytest.mark.parametrize("n", [39, 48, 64, 65, 85, 96, 97, 127, 128, 129, 192, 193, 200, 253, 256])
 def test_fast_factor_equals_the_order_preserving_one_to_rounding(n):
     from socp_amd import capi
     J, b = _problems(n, 3, 100 + n)
