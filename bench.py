@@ -41,6 +41,10 @@ Objects in the JSON line beside the contract's fields (N = 1; `--lean` drops the
                   latency floor.  At N = 1 every leg carries `predicted` (wall / speedup / efficiency at 2, 4, 8 GPUs read off
                   this run's own one-GPU curve, `sweep_curve_one_gpu`); at N > 1 `expected` (from the curve recorded under
                   profiles/) and measured_over_expected.
+  sweep_config5   STRONG scaling of BASELINE configs[4]: 16 384 starts of the 253-unknown interceptor problem (21 segments, adaptive
+                  Dormand-Prince, tol 1e-8; Newton solvers on the device with the matrix-core Jacobian refresh) sharded the same
+                  way -- 2048 per rank at N = 8.  PARITY UNPINNED (Boost and Eigen are absent: integrator and model are restated
+                  from the published algorithm / the reference's text).  `predicted` / `expected` from its own one-GPU curve.
   cpu_baseline    B1: the reference's own model::ComputeTraj (oracle/_ref, kind "reference") or the C oracle (kind
                   "port") on this box's host cores, bounded sample.  cpu_baseline.b0 = "as shipped": the reference's
                   shooting.cpp + its per-call std::threads, bound to this library's hybrd (oracle/_ref/link), one
@@ -109,7 +113,12 @@ def parse_args(argv=None):
                     help="the `sweep_xl` leg: the same sweep with this many starts in total (default 64 x --sweep-starts = 4 194 304): "
                          "a rank's share at N = 8 is still 524 288 starts, i.e. throughput-bound -- the leg on which near-linear strong "
                          "scaling to 8 GPUs can show at all; 0 skips it")
+    ap.add_argument("--sweep-c5-starts", type=int, default=None,
+                    help="the `sweep_config5` leg: this many starts IN TOTAL of the 253-unknown interceptor problem under the adaptive "
+                         "integrator (BASELINE configs[4]; parity unpinned), sharded over the ranks; default 16384 (0 = skip; --lean skips it)")
     args = ap.parse_args(argv)
+    if args.sweep_c5_starts is None:
+        args.sweep_c5_starts = 0 if args.lean else 16384
     if args.sweep_starts is None:
         args.sweep_starts = 0 if args.lean else 65536
     if args.sweep_large_starts is None:
@@ -501,49 +510,76 @@ def predictions(curve, total, wall_1=None):
     return out
 
 
-def recorded_sweep_curve(rk4_steps, max_rounds):
+def annotate_legs(legs, curve, source, world, skip):
+    """`predicted` (N = 1) / `expected` (N > 1) of every strong-scaling leg from the one-GPU curve of its family."""
+    for name, r in legs.items():
+        if name == skip:
+            r["note"] = "curve point only: the block a rank of 8 gets of the full leg"
+            continue
+        if curve:
+            if world == 1:
+                r["predicted"] = predictions(curve, r["total_starts"], r["wall_s"])
+            else:
+                w = predict_wall(curve, r["starts_per_gpu"])
+                w1 = predict_wall(curve, r["total_starts"])
+                r["expected"] = {"wall_s": w, "one_gpu_wall_s": w1, "speedup": w1 / w if w and w1 else None,
+                                 "measured_over_expected": r["wall_s"] / w if w else None}
+            r["prediction_source"] = source
+
+
+def recorded_sweep_curve(rk4_steps, max_rounds, key="curve"):
     """The one-GPU sweep curve of the last profiled run (profiles/sweep_curve_latest.json, written from a bench line by
     scripts/profile_bench.sh): what an N > 1 run -- which has no one-GPU leg of its own -- states as its expectation."""
     path = os.path.join(ROOT, "profiles", "sweep_curve_latest.json")
     try:
         with open(path) as f:
             c = json.load(f)
-        if c.get("rk4_steps") == rk4_steps and c.get("max_rounds") == max_rounds:
-            return [(int(a), float(b)) for a, b in c["curve"]], "profiles/sweep_curve_latest.json (RECORDED on one GPU: %s)" % c.get("source", "?")
+        if key != "curve" or (c.get("rk4_steps") == rk4_steps and c.get("max_rounds") == max_rounds):
+            return [(int(a), float(b)) for a, b in c[key]], "profiles/sweep_curve_latest.json (RECORDED on one GPU: %s)" % c.get("source", "?")
     except Exception:
         pass
     return None, None
 
 
-def sweep_leg(torch, dist, capi, args, world, rank, local_rank, dev, use_dist, total=None):
+def sweep_leg(torch, dist, capi, args, world, rank, local_rank, dev, use_dist, total=None, family="goddard"):
     """BASELINE config 4 at N GPUs as STRONG scaling: a fixed total of `total` independent starts of the n = 14 single-shooting
     problem (1e4 RK4 steps, full Newton solves in lock-step, throughput flavour, round budget --sweep-max-rounds), sharded in
     contiguous blocks (socp_amd/sweep.py), no data-path exchange, one all_gather of the result records.  Wall time = barrier to
-    barrier, max over ranks.  Returned on rank 0."""
+    barrier, max over ranks.  Returned on rank 0.  family = "config5": BASELINE config 5 instead -- the 253-unknown interceptor
+    problem under the adaptive integrator (parity unpinned), no round budget."""
     from socp_amd import sweep
-    ctx = capi.Context(capi.MODEL_GODDARD, device=local_rank)
-    ctx.set_params(GODDARD_PARAMS)
-    ctx.set_step_number(args.rk4_steps)
-    ctx.set_variant(capi.VARIANT_LANE_FAST)
-    sweep.goddard_single_shooting_problem(ctx)
-    total = args.sweep_starts if total is None else total
-    base = min(total, max(args.sweep_starts, 1))
-    Z0 = sweep.goddard_starts(base, 1e-3)
-    if total > base:
-        # the large leg: the SURVEY 8d table repeated, block b with its costates moved by 1e-7 b (distinct starts, same basin)
-        reps = -(-total // base)
-        Z0 = np.concatenate([Z0 * np.concatenate([np.ones(7), np.full(7, 1.0 + 1e-7 * b)])[None, :] for b in range(reps)])[:total]
     stats = {}
+    if family == "config5":
+        ctx, Z0, kw = sweep.interceptor_config5_sweep(total, variant="fast", device=local_rank)
+        workload = ("interceptor_M21_n%d multi-start sweep, adaptive Dormand-Prince tol 1e-8, full Newton solves on the device "
+                    "(BASELINE configs[4] class; PARITY UNPINNED: Boost / Eigen absent)" % Z0.shape[1])
+        rk4_steps, max_rounds = None, 0
+    else:
+        ctx = capi.Context(capi.MODEL_GODDARD, device=local_rank)
+        ctx.set_params(GODDARD_PARAMS)
+        ctx.set_step_number(args.rk4_steps)
+        ctx.set_variant(capi.VARIANT_LANE_FAST)
+        sweep.goddard_single_shooting_problem(ctx)
+        total = args.sweep_starts if total is None else total
+        base = min(total, max(args.sweep_starts, 1))
+        Z0 = sweep.goddard_starts(base, 1e-3)
+        if total > base:
+            # the large leg: the SURVEY 8d table repeated, block b with its costates moved by 1e-7 b (distinct starts, same basin)
+            reps = -(-total // base)
+            Z0 = np.concatenate([Z0 * np.concatenate([np.ones(7), np.full(7, 1.0 + 1e-7 * b)])[None, :] for b in range(reps)])[:total]
+        kw = dict(kind=capi.CHAIN_PLAIN, xtol=1e-8, max_rounds=args.sweep_max_rounds)
+        workload = "goddard_single_shooting_n14 multi-start sweep, full Newton solves (BASELINE configs[3] class)"
+        rk4_steps, max_rounds = args.rk4_steps, args.sweep_max_rounds
 
     def solve_block(Zb):
-        r = ctx.chains_solve(Zb, kind=capi.CHAIN_PLAIN, xtol=1e-8, max_rounds=args.sweep_max_rounds)
+        r = ctx.chains_solve(Zb, **kw)
         stats.update(r["stats"])
         r["rounds"] = r["stats"]["rounds"]
         return r
     # warm-up, untimed: what a process pays once (the context's second stream, the copy engines' start-up: socp_ctx_warm_up) and
     # one small sweep (kernel modules)
     ctx.warm_up()
-    ctx.chains_solve(Z0[:64], kind=capi.CHAIN_PLAIN, xtol=1e-8, max_rounds=4)
+    ctx.chains_solve(Z0[:64], **dict(kw, max_rounds=4))
     c0 = ctx.counters()[0]
     if use_dist:
         dist.barrier()
@@ -560,9 +596,9 @@ def sweep_leg(torch, dist, capi, args, world, rank, local_rank, dev, use_dist, t
         dist.all_reduce(wall[1:], op=dist.ReduceOp.SUM)
     ctx.close()
     info = table[:, -2].astype(int)
-    return {"workload": "goddard_single_shooting_n14 multi-start sweep, full Newton solves (BASELINE configs[3] class)", "scaling": "strong",
-            "total_starts": total, "n_gpus": world, "starts_per_gpu": -(-total // world), "rk4_steps": args.rk4_steps, "xtol": 1e-8,
-            "max_rounds": args.sweep_max_rounds, "wall_s": float(wall[0]), "solves_per_s": total / float(wall[0]),
+    return {"workload": workload, "scaling": "strong",
+            "total_starts": total, "n_gpus": world, "starts_per_gpu": -(-total // world), "rk4_steps": rk4_steps, "xtol": 1e-8,
+            "max_rounds": max_rounds, "wall_s": float(wall[0]), "solves_per_s": total / float(wall[0]),
             "trajectories": int(wall[1]), "trajectories_per_s": float(wall[1]) / float(wall[0]),
             "converged": int(np.sum(info == 1)), "stopped_by_round_limit": int(np.sum(info == -3)), "rounds_rank0": int(stats.get("rounds", 0)),
             "note": "a sweep's wall time is (rounds of its slowest start) x (one trajectory latency + host work per round) while a "
@@ -646,6 +682,14 @@ def main():
     for name, total in leg_sizes:
         if total > 0 and args.sweep_starts > 0:
             legs[name] = sweep_leg(torch, dist, capi, args, world, rank, local_rank, dev, use_dist, total=total)
+    # BASELINE config 5 the same way (its own one-GPU curve: the full leg and, at N = 1, the block a rank of 8 gets)
+    legs_c5 = {}
+    c5_sizes = [("sweep_config5", args.sweep_c5_starts)]
+    if world == 1 and not args.lean and args.sweep_c5_starts >= 8:
+        c5_sizes.insert(0, ("sweep_config5_eighth", args.sweep_c5_starts // 8))
+    for name, total in c5_sizes:
+        if total > 0:
+            legs_c5[name] = sweep_leg(torch, dist, capi, args, world, rank, local_rank, dev, use_dist, total=total, family="config5")
 
     status = 0
     if rank == 0:
@@ -695,20 +739,16 @@ def main():
                                                        "proportional above the largest"}
             else:
                 curve, source = recorded_sweep_curve(args.rk4_steps, args.sweep_max_rounds)
-            for name, r in legs.items():
-                if name == "sweep_eighth":
-                    r["note"] = "curve point only: the block a rank of 8 gets of the `sweep` leg"
-                    continue
-                if curve:
-                    if world == 1:
-                        r["predicted"] = predictions(curve, r["total_starts"], r["wall_s"])
-                    else:
-                        w = predict_wall(curve, r["starts_per_gpu"])
-                        w1 = predict_wall(curve, r["total_starts"])
-                        r["expected"] = {"wall_s": w, "one_gpu_wall_s": w1, "speedup": w1 / w if w and w1 else None,
-                                         "measured_over_expected": r["wall_s"] / w if w else None}
-                    r["prediction_source"] = source
+            annotate_legs(legs, curve, source, world, skip="sweep_eighth")
             out.update(legs)
+        if legs_c5:
+            if world == 1:
+                curve5, source5 = sorted((r["total_starts"], r["wall_s"]) for r in legs_c5.values()), "this run"
+                out.setdefault("sweep_curve_one_gpu", {})["curve_config5"] = curve5
+            else:
+                curve5, source5 = recorded_sweep_curve(None, None, key="curve_config5")
+            annotate_legs(legs_c5, curve5, source5, world, skip="sweep_config5_eighth")
+            out.update(legs_c5)
         if ranks_seen != list(range(world)):
             sys.stderr.write("bench.py: records of ranks %s, expected 0..%d\n" % (ranks_seen, world - 1))
             status = 1

@@ -39,9 +39,9 @@ python3 - <<'PY'
 import json
 d = json.load(open("gpurun_out/profiles_r04/r04_bench.json"))
 print("bench", d["value"], d["roofline"]["frac"], d["exact"]["value"], d["cpu_baseline"]["value"], d["cpu_baseline"]["p1"]["value"],
-      {k: round(d[k]["wall_s"], 3) for k in ("sweep", "sweep_large", "sweep_xl")}, d["north_star_128"]["fast"]["jacobian_ms"])
+      {k: round(d[k]["wall_s"], 3) for k in ("sweep", "sweep_large", "sweep_xl", "sweep_config5")}, d["north_star_128"]["fast"]["jacobian_ms"])
 c = d["sweep_curve_one_gpu"]
-json.dump({"curve": c["curve"], "rk4_steps": c["rk4_steps"], "max_rounds": c["max_rounds"],
+json.dump({"curve": c["curve"], "curve_config5": c.get("curve_config5", []), "rk4_steps": c["rk4_steps"], "max_rounds": c["max_rounds"],
            "source": "profiles/r04_bench_final.json (python bench.py, N = 1, one MI355X)"},
           open("gpurun_out/profiles_r04/sweep_curve_latest.json", "w"), indent=1)
 PY

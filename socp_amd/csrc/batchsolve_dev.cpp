@@ -67,6 +67,22 @@ struct Piece {
 using Pinned = Piece;
 using Dev = Piece;
 
+// Chain lists into ascending order.  A round's request lists are read off lists that were ascending themselves, so they are a few
+// ascending runs (one per inner pass): merged in O(n) instead of sorted (4 M starts: two sorts per round were 1 s of a 22 s sweep).
+void sort_runs(std::vector<int> &v)
+{
+    size_t runs = 1;
+    for (size_t i = 1; i < v.size(); i++) runs += v[i] < v[i - 1];
+    if (runs == 1) return;
+    if (runs > 4) { std::sort(v.begin(), v.end()); return; }
+    auto mid = std::is_sorted_until(v.begin(), v.end());
+    while (mid != v.end()) {
+        auto next = std::is_sorted_until(mid, v.end());
+        std::inplace_merge(v.begin(), mid, next);
+        mid = next;
+    }
+}
+
 }  // namespace
 
 constexpr int kDeviceEngineAllocFailed = -1000;      // to socp_chains_solve (batchsolve.cpp): the arenas did not fit, nothing has run
@@ -319,7 +335,7 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
             if (!reqJc.empty() && rc == SOCP_OK) {
                 // Jacobians from cached rows, no trajectories: slots -> staging (gather), differences, into the solvers' matrices;
                 // those chains go straight back into the advance loop (their factorisation)
-                std::sort(reqJc.begin(), reqJc.end());
+                sort_runs(reqJc);
                 const int chunk = std::max(1, std::min(capS, jlaunch));
                 for (size_t j0 = 0; j0 < reqJc.size() && rc == SOCP_OK; j0 += (size_t)chunk) {
                     const int kc = (int)std::min<size_t>((size_t)chunk, reqJc.size() - j0);
@@ -368,8 +384,8 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
         }
         if (rc != SOCP_OK) break;
         // chain order keeps the batches those of the host engine (a restarted chain's request arrives in a later inner pass)
-        std::sort(reqF.begin(), reqF.end());
-        std::sort(reqJ.begin(), reqJ.end());
+        sort_runs(reqF);
+        sort_runs(reqJ);
         const int kF = (int)reqF.size(), kJ = (int)reqJ.size();
         if (kF == 0 && kJ == 0) break;
         if (opt->max_rounds > 0 && rounds >= opt->max_rounds) {

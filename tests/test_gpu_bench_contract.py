@@ -19,7 +19,7 @@ def _line(out):
 
 def test_bench_line_contract():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--starts", "4096",
-                          "--cpu-seconds", "2", "--sweep-starts", "2048"], capture_output=True, text=True, timeout=900)
+                          "--cpu-seconds", "2", "--sweep-starts", "2048", "--sweep-c5-starts", "512"], capture_output=True, text=True, timeout=900)
     d = _line(out)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "exact", "parity", "single_problem",
@@ -72,6 +72,11 @@ def test_bench_line_contract():
         assert set(pr) == {"2", "4", "8"} and pr["2"]["wall_s"] >= pr["4"]["wall_s"] >= pr["8"]["wall_s"] > 0
         assert pr["8"]["speedup"] <= 8.0 + 1e-9 and leg["prediction_source"] == "this run"
     assert abs(xl["predicted"]["8"]["wall_s"] - big["wall_s"]) <= 1e-9 * big["wall_s"]          # a rank's block of 8 IS the large leg
+    # BASELINE config 5 as a strong-scaling leg of its own family (parity unpinned, and labelled so), with its own one-GPU curve
+    c5 = d["sweep_config5"]
+    assert c5["total_starts"] == 512 and c5["scaling"] == "strong" and c5["converged"] >= 500 and "UNPINNED" in c5["workload"]
+    assert [q[0] for q in d["sweep_curve_one_gpu"]["curve_config5"]] == [64, 512] and d["sweep_config5_eighth"]["total_starts"] == 64
+    assert set(c5["predicted"]) == {"2", "4", "8"} and abs(c5["predicted"]["8"]["wall_s"] - d["sweep_config5_eighth"]["wall_s"]) <= 1e-12
     g = c["gpu_ratios"]
     assert c["median"] <= c["value"] and c["p1"]["median"] <= c["p1"]["value"]
     assert abs(g["headline_over_16xP1"] - d["value"] / (16 * c["p1"]["value"])) <= 1e-9 * g["headline_over_16xP1"]
@@ -86,7 +91,7 @@ def test_gpus_2_really_runs_two_ranks():
     """`python bench.py --gpus 2` (no launcher): the parent starts two ranks; here both share device 0 and the collectives
     run over gloo (a one-GPU box), the code path is otherwise the N > 1 path of the driver."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-device0",
-                          "--steps", "2", "--warmup", "1", "--starts", "1024", "--rk4-steps", "1000", "--sweep-starts", "301"],
+                          "--steps", "2", "--warmup", "1", "--starts", "1024", "--rk4-steps", "1000", "--sweep-starts", "301", "--sweep-c5-starts", "65"],
                          capture_output=True, text=True, timeout=900)
     d = _line(out)
     # the sweep leg at N = 2: a FIXED total (odd: blocks of 151 + 150), every start reported once
@@ -100,6 +105,9 @@ def test_gpus_2_really_runs_two_ranks():
     # 1000-step trajectories: a tenth of the flops per trajectory, so the fraction stays below 1 whatever the step count
     assert d["roofline"]["flop_per_trajectory"] == 1170.0 * 1000 and 0 < d["roofline"]["frac"] <= 1.0
     assert d["sweep_xl"]["total_starts"] == 64 * 301 and "sweep_eighth" not in d
+    c5 = d["sweep_config5"]
+    assert c5["n_gpus"] == 2 and c5["total_starts"] == 65 and c5["starts_per_gpu"] == 33 and c5["converged"] >= 60
+    assert "sweep_config5_eighth" not in d
 
 
 def test_rccl_code_path_with_one_rank():
@@ -107,10 +115,11 @@ def test_rccl_code_path_with_one_rank():
     all_reduce(MAX) of the timing and all_gather of the result records on DEVICE tensors.  A one-GPU box cannot host two RCCL
     ranks, so this runs that exact code with a world of one (--force-dist); the two-rank plumbing is the gloo test above."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--lean", "--steps", "2", "--warmup", "1",
-                          "--starts", "1024", "--rk4-steps", "1000", "--cpu-seconds", "0", "--sweep-starts", "200"],
+                          "--starts", "1024", "--rk4-steps", "1000", "--cpu-seconds", "0", "--sweep-starts", "200", "--sweep-c5-starts", "48"],
                          capture_output=True, text=True, timeout=900)
     d = _line(out)
     # the sweep leg's barrier / all_reduce(MAX, SUM) / gather over RCCL too (a world of one)
     assert d["sweep"]["total_starts"] == 200 and d["sweep"]["n_gpus"] == 1 and d["sweep"]["converged"] >= 195
+    assert d["sweep_config5"]["total_starts"] == 48 and d["sweep_config5"]["converged"] >= 44
     assert d["n_gpus"] == 1 and d["ranks_reported"] == 1 and d["finite_jacobians"] == [1024]
     assert abs(d["value"] - 1024 * 15 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
