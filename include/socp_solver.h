@@ -168,6 +168,19 @@ int socp_chains_solve_ex(struct socp_ctx *ctx, int P, const socp_chain_options *
                          const double *x_goal, double *Zout, int *info, int *nfev_last, int *nfev_total, int *njev_last,
                          int *solves, double *b_reached, double *param_final, double *fnorm, socp_chain_stats *stats);
 
+/* ---- the device engine's workspace.  socp_chains_solve with the solvers on the device takes ONE device allocation and ONE pinned host
+ * allocation per call (32 GB + 1.8 GB for 4 M chains of n = 14; 26 GB for 16 384 of n = 253).  They are KEPT for the next call on that
+ * device instead of being returned (one pair per device, grown when a call needs more, never shrunk): returning and taking tens of GB
+ * costs 0.7-1 s per call on this platform -- freed device memory is cleared before it is handed out again, and an allocation that
+ * follows a large free waits for that (measured: a 4.3 GB arena 756 ms after a 32 GB one was freed, 0.4 ms otherwise).  A second
+ * engine call on the same device while the first is running takes private allocations.  SOCP_WORKSPACE_CACHE=0 turns the keeping
+ * off.  No reference counterpart (the reference allocates std::vectors per callback, shooting.cpp:784-799).
+ *
+ * socp_workspace_release: frees what is kept for `device` (< 0: every device) and not in use; returns the number of bytes freed.
+ * socp_workspace_cached_bytes: device + pinned bytes currently kept for `device` (< 0: all). */
+double socp_workspace_release(int device);
+double socp_workspace_cached_bytes(int device);
+
 /* ---- multi-GPU sweep from C++ (SURVEY 8e level 1; north_star: "a continuation/multi-start outer loop shards independent
  * shooting problems across the 8 GPUs of one node with a trivial gather").  The reference has no counterpart: its continuation
  * loops (shooting.cpp:598-778) solve one problem at a time on one thread; what is kept is its plugin surface -- the problem is

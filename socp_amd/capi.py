@@ -145,10 +145,24 @@ def lib():
             getattr(L, name).restype = _dp
         L.socp_hybr_trust_region.argtypes = [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.socp_hybr_trust_region.restype = None
+        L.socp_workspace_release.argtypes = [C.c_int]
+        L.socp_workspace_release.restype = C.c_double
+        L.socp_workspace_cached_bytes.argtypes = [C.c_int]
+        L.socp_workspace_cached_bytes.restype = C.c_double
         L.socp_qr_factor_batch.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _ip, C.POINTER(C.c_double)]
         L.socp_ctx_get_variant.argtypes = [_vp]
         _lib = L
     return _lib
+
+
+def workspace_release(device=-1):
+    """socp_workspace_release (include/socp_solver.h): frees the device engine's kept arenas of `device` (< 0: all); bytes freed."""
+    return lib().socp_workspace_release(int(device))
+
+
+def workspace_cached_bytes(device=-1):
+    """socp_workspace_cached_bytes: device + pinned bytes the device engine keeps for its next call on `device` (< 0: all)."""
+    return lib().socp_workspace_cached_bytes(int(device))
 
 
 def qr_factor_batch(J, b, flavour=FACTOR_FAST, reps=1, device=-1, outputs=True):

@@ -41,6 +41,7 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
 // throughput factorisation exists for size n, and the code with which it reports "could not allocate, nothing has run yet"
 double socp_chains_device_bytes(const socp_ctx *ctx, int P, const socp_chain_options *opt, bool per_chain_params, bool per_chain_bounds);
 bool socp_chains_fast_factor_applies(int n);
+double socp_workspace_reusable_device_bytes(int device);
 constexpr int kDeviceEngineAllocFailed = -1000;
 
 namespace {
@@ -167,7 +168,8 @@ extern "C" int socp_chains_solve_ex(socp_ctx *ctx, int P, const socp_chain_optio
                 const double need = socp_chains_device_bytes(ctx, P, opt, params != nullptr || kind == SOCP_CHAIN_PARAM,
                                                              kind == SOCP_CHAIN_DATA || time_goal != nullptr || x_goal != nullptr);
                 if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(socp_ctx_device(ctx)) != hipSuccess ||
-                    hipMemGetInfo(&free_b, &total_b) != hipSuccess || need > 0.9 * (double)free_b)
+                    hipMemGetInfo(&free_b, &total_b) != hipSuccess ||
+                    need > 0.9 * ((double)free_b + socp_workspace_reusable_device_bytes(socp_ctx_device(ctx))))
                     solver = SOCP_SOLVER_HOST;
                 if (prev >= 0) (void)hipSetDevice(prev);
             }

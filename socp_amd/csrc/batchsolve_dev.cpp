@@ -27,6 +27,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "chains_common.hpp"
@@ -37,24 +39,84 @@ namespace {
 using socp::devsolver::PoolDev;
 using socp::devsolver::State;
 
+// What is kept between calls (include/socp_solver.h "the device engine's workspace"): per device one block of device memory and
+// one of pinned host memory.  Never destroyed (a static destructor would call into a HIP runtime that may be gone already).
+struct KeptBlock {
+    void *p = nullptr;
+    size_t cap = 0;
+    bool busy = false;
+};
+struct Workspaces {
+    std::mutex m;
+    std::map<int, KeptBlock> dev, host;
+};
+Workspaces &workspaces()
+{
+    static Workspaces *w = new Workspaces;
+    return *w;
+}
+bool keep_workspaces()
+{
+    static const bool on = [] { const char *e = std::getenv("SOCP_WORKSPACE_CACHE"); return !(e && e[0] == '0'); }();
+    return on;
+}
+hipError_t raw_alloc(void **p, size_t bytes, bool host) { return host ? hipHostMalloc(p, bytes, hipHostMallocDefault) : hipMalloc(p, bytes); }
+void raw_free(void *p, bool host) { if (p) (void)(host ? hipHostFree(p) : hipFree(p)); }
+
 // The engine's buffers: ONE device allocation and ONE pinned host allocation, carved into aligned pieces (thirty-odd separate
-// hipMalloc / hipHostMalloc calls were 5 of the 6-8 ms a call spent before its first launch).
+// hipMalloc / hipHostMalloc calls were 5 of the 6-8 ms a call spent before its first launch).  The allocation comes from -- and goes
+// back to -- the kept block of its device when that is free.
 struct Arena {
     char *base = nullptr;
     size_t used = 0, cap = 0;
-    bool pinned = false;
+    bool pinned = false, kept = false;
+    int device = 0;
     static size_t pad(size_t bytes) { return (bytes + 255) / 256 * 256; }
     size_t plan(size_t bytes) { const size_t at = used; used += pad(bytes ? bytes : 8); return at; }
-    bool alloc(bool host)
+    bool alloc(bool host, int dev)
     {
         pinned = host;
+        device = dev;
         cap = used ? used : 256;
         void *p = nullptr;
-        const hipError_t e = host ? hipHostMalloc(&p, cap, hipHostMallocDefault) : hipMalloc(&p, cap);
+        if (keep_workspaces()) {
+            Workspaces &w = workspaces();
+            std::lock_guard<std::mutex> lock(w.m);
+            KeptBlock &b = (host ? w.host : w.dev)[dev];
+            if (!b.busy) {
+                if (b.cap < cap) {
+                    // grow: the new block first (the old one is cleared in the background once freed; an allocation right behind a
+                    // large free waits for that), the other order only when both do not fit
+                    if (raw_alloc(&p, cap, host) != hipSuccess) {
+                        (void)hipGetLastError();
+                        raw_free(b.p, host);
+                        b.p = nullptr; b.cap = 0; p = nullptr;
+                        if (raw_alloc(&p, cap, host) != hipSuccess) return false;
+                    } else {
+                        raw_free(b.p, host);
+                    }
+                    b.p = p; b.cap = cap;
+                }
+                b.busy = true;
+                kept = true;
+                base = static_cast<char *>(b.p);
+                return true;
+            }
+        }
+        const hipError_t e = raw_alloc(&p, cap, host);
         base = static_cast<char *>(p);
         return e == hipSuccess;
     }
-    ~Arena() { if (base) (void)(pinned ? hipHostFree(base) : hipFree(base)); }
+    ~Arena()
+    {
+        if (kept) {
+            Workspaces &w = workspaces();
+            std::lock_guard<std::mutex> lock(w.m);
+            (pinned ? w.host : w.dev)[device].busy = false;
+        } else {
+            raw_free(base, pinned);
+        }
+    }
 };
 struct Piece {
     size_t at = 0;
@@ -118,6 +180,46 @@ double socp_chains_device_bytes(const socp_ctx *ctx, int P, const socp_chain_opt
     int S = 0;
     socp_ctx_dims(ctx, nullptr, &S, nullptr);
     return EnginePlan(n, P, nodes, S, nparams + 2).device_bytes(P, per_chain_params, per_chain_bounds);
+}
+
+extern "C" double socp_workspace_cached_bytes(int device)
+{
+    Workspaces &w = workspaces();
+    std::lock_guard<std::mutex> lock(w.m);
+    double total = 0;
+    for (auto *table : {&w.dev, &w.host})
+        for (auto &kv : *table)
+            if (device < 0 || kv.first == device) total += (double)kv.second.cap;
+    return total;
+}
+
+extern "C" double socp_workspace_release(int device)
+{
+    Workspaces &w = workspaces();
+    std::lock_guard<std::mutex> lock(w.m);
+    double freed = 0;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    for (int host = 0; host < 2; host++)
+        for (auto &kv : host ? w.host : w.dev) {
+            KeptBlock &b = kv.second;
+            if ((device >= 0 && kv.first != device) || b.busy || !b.p) continue;
+            if (hipSetDevice(kv.first) != hipSuccess) { (void)hipGetLastError(); continue; }
+            raw_free(b.p, host != 0);
+            freed += (double)b.cap;
+            b.p = nullptr; b.cap = 0;
+        }
+    if (prev >= 0) (void)hipSetDevice(prev);
+    return freed;
+}
+
+// device memory the engine could take on `device` beyond what hipMemGetInfo calls free: its own kept block, when not in use
+double socp_workspace_reusable_device_bytes(int device)
+{
+    Workspaces &w = workspaces();
+    std::lock_guard<std::mutex> lock(w.m);
+    auto it = w.dev.find(device);
+    return (it != w.dev.end() && !it->second.busy) ? (double)it->second.cap : 0.0;
 }
 
 bool socp_chains_fast_factor_applies(int n) { return socp::devsolver::fast_factor_applies(n); }
@@ -227,9 +329,9 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
             {&dIdxB, spec_on ? intsB : 0, false}, {&hIdxA, spec_on ? intsB : 0, true}, {&hIdxB, spec_on ? intsB : 0, true}};
         for (auto &e : plan) e.piece->plan(e.host ? host_arena : dev_arena, e.bytes);
         const double t0 = ms_since(t_begin);
-        bool ok = dev_arena.alloc(false);
+        bool ok = dev_arena.alloc(false, socp_ctx_device(ctx));
         const double t1 = ms_since(t_begin);
-        ok = ok && host_arena.alloc(true);
+        ok = ok && host_arena.alloc(true, socp_ctx_device(ctx));
         const double t2 = ms_since(t_begin);
         void *aux = nullptr;
         if (ok) ok = socp_ctx_aux_stream(ctx, &aux) == SOCP_OK;              // the context's second stream (created on its first use: ~6 ms)

@@ -310,3 +310,33 @@ def test_trial_launches_that_exceed_the_chip_shrink_their_workgroups():
     host, dev = both(ctx, Z0, kind=capi.CHAIN_PLAIN, xtol=1e-10)
     assert np.sum(dev["info"] == 1) >= 4000
     ctx.close()
+
+
+def test_kept_workspace_changes_no_result():
+    """The device engine keeps its arenas between calls (include/socp_solver.h, socp_workspace_*): a call that runs in a block an
+    earlier, larger, different sweep left behind gives the bits of a call on fresh memory; release returns what was kept."""
+    from socp_amd import capi, sweep
+    capi.workspace_release()
+    assert capi.workspace_cached_bytes() == 0
+    ctx = capi.Context(capi.MODEL_GODDARD)
+    ctx.set_params(sweep.GODDARD_PARAMS)
+    ctx.set_step_number(10)
+    ctx.set_variant(capi.VARIANT_LANE_FAST)
+    n = sweep.goddard_multiple_shooting_problem(ctx, 6)
+    Z0 = sweep.goddard_multiple_shooting_starts(ctx, sweep.goddard_starts(48, 0.05), 6)
+    kw = dict(kind=capi.CHAIN_PLAIN, xtol=1e-10)
+    fresh = {s: ctx.chains_solve(Z0[:16], solver=s, **kw) for s in (capi.SOLVER_DEVICE, capi.SOLVER_DEVICE_FAST)}
+    small = capi.workspace_cached_bytes()
+    assert small > 16 * n * n * 8
+    big = ctx.chains_solve(Z0 * (1 + 1e-3), solver=capi.SOLVER_DEVICE, **kw)             # a larger sweep of other numbers: the block grows
+    grown = capi.workspace_cached_bytes()
+    assert grown > small and np.all(big["info"] == 1)
+    for s, ref in fresh.items():
+        again = ctx.chains_solve(Z0[:16], solver=s, **kw)                                 # now in the big block's leftovers
+        for k in KEYS:
+            assert np.array_equal(ref[k], again[k], equal_nan=True), (s, k)
+        assert capi.workspace_cached_bytes() == grown                                     # grown, never shrunk
+    assert capi.workspace_release(0) == grown and capi.workspace_cached_bytes() == 0
+    after = ctx.chains_solve(Z0[:16], solver=capi.SOLVER_DEVICE, **kw)
+    assert np.array_equal(after["z"], fresh[capi.SOLVER_DEVICE]["z"])
+    ctx.close()
