@@ -129,7 +129,10 @@ typedef struct socp_chain_options {
                                  time at n = 253) in its THROUGHPUT flavour -- blocked Householder, compact-WY panels of 16, trailing
                                  updates on the FP64 matrix cores, free summation order (kernels_factor_fast.hip): iterates equal the
                                  host solver's to rounding, NOT bit for bit; converged solutions within north_star's 1e-8.  Sizes
-                                 39 <= n <= 256, otherwise it is DEVICE.  AUTO picks it instead of DEVICE on a context whose arithmetic
+                                 39 <= n <= 256, otherwise it is DEVICE.  From n = 192 up this flavour also leaves Q as factorised
+                                 between refreshes: Broyden's rotations (r1mpyq) are kept as a list and applied to the vector
+                                 Q0^T f instead of to the matrix (rounding-level again; SOCP_SOLVER_LAZY_Q=0|1: never / always).
+                                 AUTO picks it instead of DEVICE on a context whose arithmetic
                                  flavour is the throughput one (SOCP_VARIANT_LANE_FAST: its trajectories differ from the reference
                                  order's at rounding level already); on a reference-order context AUTO never does.
                                  Environment SOCP_CHAINS_SOLVER=host|device|device_fast overrides. */

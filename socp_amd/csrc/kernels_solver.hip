@@ -26,7 +26,9 @@ __global__ void start_kernel(Config c, State *states, double *ws, long ws_stride
 #ifdef SOCP_SOLVER_WAVES          // A/B: cap the registers so that this many wavefronts fit a SIMD (the compiler then spills)
 #define SOCP_SOLVER_OCCUPANCY __attribute__((amdgpu_waves_per_eu(SOCP_SOLVER_WAVES, SOCP_SOLVER_WAVES)))
 #else
-#define SOCP_SOLVER_OCCUPANCY
+// three wavefronts per SIMD (168 registers) for the instantiations that can have them: the function sits at 163-171 registers
+// depending on what else is inlined into it, and 171 would silently cost a third of the occupancy; the compiler spills the excess
+#define SOCP_SOLVER_OCCUPANCY __attribute__((amdgpu_waves_per_eu(MAXT <= 256 ? 3 : (MAXT <= 512 ? 2 : 4))))
 #endif
 template <int MAXT>
 __global__ __launch_bounds__(MAXT) SOCP_SOLVER_OCCUPANCY void advance_kernel(Config c, State *states, double *ws, long ws_stride, const int *__restrict__ list,

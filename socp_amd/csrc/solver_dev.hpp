@@ -42,6 +42,7 @@ enum Request { RQ_DONE = 0, RQ_FVEC = 1, RQ_JAC = 2 };
 struct Config {
     int n, ld, maxfev, mode, analytic;
     double xtol, epsfcn, factor;
+    int lazy_q = 0;    // throughput flavour: Broyden's rotations are kept as a list and Q stays as factorised (see lazy_capacity)
 };
 
 // per-problem iteration state (Core of minpack.cpp)
@@ -50,6 +51,7 @@ struct State {
     int req;           // Request left pending by the last advance
     int eval_sel;      // RQ_FVEC: 0 -> evaluate at x, result to fvec; 1 -> evaluate at wa2 (trial point), result to wa4
     int pad;           // 1: the Jacobian in A has already been factorised by the factor kernel (sing holds its flag)
+    int lazy, pad2;    // lazy_q: rank-1 updates since A was last brought up to date (their rotations are in the V area)
     double delta, xnorm, fnorm, pnorm;
 };
 
@@ -905,18 +907,11 @@ __device__ __forceinline__ double rotate_row_lines(double *a, const double *c, c
 }
 #endif
 
-// minpack.cpp: r1mpyq on Q (n x n, row-major here) and on qtf, with the rotations of the last r1updt (f7, f4) decoded into
-// f0 .. f3
+// every row of Q through the two rotation sweeps whose cosines / sines are in f0 .. f3 (a row per thread, no barrier inside)
 template <class E>
-SOCP_HD void r1mpyq_all(const E &ex, int n, int ld, Work &wk)
+SOCP_HD void rotate_all_rows(const E &ex, int n, int ld, Work &wk)
 {
-    double *c1 = wk.f[0], *s1 = wk.f[1], *c2 = wk.f[2], *s2 = wk.f[3];
-    ex.sync();
-    SOCP_PAR_FOR(j, 0, n - 1) {
-        decode_rotation(wk.f[7][j], c1[j], s1[j]);
-        decode_rotation(wk.f[4][j], c2[j], s2[j]);
-    }
-    ex.sync();
+    const double *c1 = wk.f[0], *s1 = wk.f[1], *c2 = wk.f[2], *s2 = wk.f[3];
     SOCP_PAR_FOR(i, 0, n) {                                  // a row of Q goes through all rotations on its own
         double *a = wk.A + (long)i * ld;
         double an = a[n - 1];
@@ -929,12 +924,104 @@ SOCP_HD void r1mpyq_all(const E &ex, int n, int ld, Work &wk)
 #endif
         a[n - 1] = an;
     }
+}
+
+// minpack.cpp: r1mpyq on Q (n x n, row-major here) and on qtf, with the rotations of the last r1updt (f7, f4) decoded into
+// f0 .. f3
+template <class E>
+SOCP_HD void r1mpyq_all(const E &ex, int n, int ld, Work &wk)
+{
+    double *c1 = wk.f[0], *s1 = wk.f[1], *c2 = wk.f[2], *s2 = wk.f[3];
+    ex.sync();
+    SOCP_PAR_FOR(j, 0, n - 1) {
+        decode_rotation(wk.f[7][j], c1[j], s1[j]);
+        decode_rotation(wk.f[4][j], c2[j], s2[j]);
+    }
+    ex.sync();
+    rotate_all_rows(ex, n, ld, wk);
     if (ex.tid == ex.nt - 1) {                               // qtf is the one-row case (on the thread least likely to own a row)
         double *a = wk.qtf;
         double an = a[n - 1];
         an = rotate_row(a, c1, s1, n, an, true);
         an = rotate_row(a, c2, s2, n, an, false);
         a[n - 1] = an;
+    }
+    ex.sync();
+}
+
+// ---- Q kept as factorised (Config::lazy_q; the throughput flavour only: results move at rounding level).  hybrd needs Q in ONE
+// place, Q^T f of the trial residual in Broyden's update, and pays for keeping it current with r1mpyq on the whole matrix after
+// every trial step: n^2 doubles read and n^2 written, a quarter of a trial step's memory traffic.  With
+// Q_k = Q_0 G_1 ... G_k (G_u = the 2 (n - 1) rotations of update u), Q_k^T f = G_k^T ... G_1^T (Q_0^T f): the rotations of the
+// updates since the last refresh are kept -- decoded, 4 n doubles per update, in the workspace area of the packed Householder
+// vectors, which only the order-preserving blocked factorisation uses -- and applied to the VECTOR Q_0^T f (what r1mpyq does to
+// its one-row argument qtf anyway).  When the list is full the updates are applied to the matrix after all (lazy_flush).
+SOCP_HD int lazy_capacity(int n)
+{
+    const long room = ((long)n * (n + 1) / 2) / (4L * n);
+    return (int)(room > 16 ? 16 : room);
+}
+SOCP_HD bool lazy_applies(const Config &c) { return c.lazy_q != 0 && lazy_capacity(c.n) >= 2; }
+
+// u <- G_count^T ... G_1^T u, by one thread (a serial chain through u[n - 1]); everyone returns with u complete
+template <class E>
+SOCP_HD void lazy_apply_to_vector(const E &ex, int n, const Work &wk, int count, double *u)
+{
+    ex.sync();
+    if (ex.tid == 0) {
+        double an = u[n - 1];
+#pragma unroll 1
+        for (int k = 0; k < count; k++) {
+            const double *c1 = wk.V + (long)k * 4 * n, *s1 = c1 + n, *c2 = s1 + n, *s2 = c2 + n;
+            an = rotate_row(u, c1, s1, n, an, true);
+            an = rotate_row(u, c2, s2, n, an, false);
+        }
+        u[n - 1] = an;
+    }
+    ex.sync();
+}
+
+// the rotations of the r1updt that has just run (encodings in f7, f4) -> slot `slot` of the list; qtf goes through them now
+template <class E>
+SOCP_HD void lazy_store(const E &ex, int n, Work &wk, int slot)
+{
+    double *c1 = wk.V + (long)slot * 4 * n, *s1 = c1 + n, *c2 = s1 + n, *s2 = c2 + n;
+    ex.sync();
+    SOCP_PAR_FOR(j, 0, n - 1) {
+        decode_rotation(wk.f[7][j], c1[j], s1[j]);
+        decode_rotation(wk.f[4][j], c2[j], s2[j]);
+    }
+    ex.sync();
+    if (ex.tid == ex.nt - 1) {
+        double *a = wk.qtf;
+        double an = a[n - 1];
+        an = rotate_row(a, c1, s1, n, an, true);
+        an = rotate_row(a, c2, s2, n, an, false);
+        a[n - 1] = an;
+    }
+    ex.sync();
+}
+
+// the list is full: Q <- Q G_1 ... G_count -- r1mpyq `count` times over, each update's tables brought to f0 .. f3 first (the row
+// loop is r1mpyq_all's: with the tables read from the list in global memory it took 254 registers instead of 166)
+template <class E>
+SOCP_HD void lazy_flush(const E &ex, int n, int ld, Work &wk, int count)
+{
+#pragma unroll 1
+    for (int k = 0; k < count; k++) {
+        const double *t = wk.V + (long)k * 4 * n;
+        ex.sync();                                           // f0 .. f3 are no longer read (the previous update's rows are done)
+        SOCP_PAR_FOR(j, 0, n - 1) { wk.f[0][j] = t[j]; wk.f[1][j] = t[n + j]; wk.f[2][j] = t[2 * n + j]; wk.f[3][j] = t[3 * n + j]; }
+        ex.sync();
+        // (the narrow row sweep: a second copy of the line-wide one in this function took the kernel from 166 to 255 registers, and
+        // a full list is rare -- a refresh usually comes first)
+        SOCP_PAR_FOR(i, 0, n) {
+            double *a = wk.A + (long)i * ld;
+            double an = a[n - 1];
+            an = rotate_row(a, wk.f[0], wk.f[1], n, an, true);
+            an = rotate_row(a, wk.f[2], wk.f[3], n, an, false);
+            a[n - 1] = an;
+        }
     }
     ex.sync();
 }
@@ -1016,6 +1103,7 @@ struct Machine {
             if (s.delta == 0) s.delta = c.factor;
         }
         s.sing = sing ? 1 : 0;
+        s.lazy = 0;                                          // A holds the Q of THIS factorisation
         ex.sync();
         if (c.mode != 2) SOCP_PAR_FOR(j, 0, n) w.diag[j] = max_of(w.diag[j], w.wa2[j]);
         ex.sync();
@@ -1073,17 +1161,37 @@ struct Machine {
         // Broyden rank-1 update of (Q, R, Q^T f): v -> f4, u -> f5 (r1updt's inputs)
         prof.mark(PF_TRIAL_HEAD, ex.tid);
         const double pnorm = s.pnorm;
-        SOCP_PAR_FOR(j, 0, n) {
-            const double sum = dot_run(f4c, w.A + j, c.ld, 0, n, 0.0);
-            w.f[4][j] = (sum - pr[j]) / pnorm;
-            w.f[5][j] = w.diag[j] * ((w.diag[j] * pc[j]) / pnorm);
-            if (ratio >= p0001) w.qtf[j] = sum;
+        const bool lazy = lazy_applies(c);
+        if (lazy && s.lazy > 0) {
+            // A is the Q of the last factorisation: Q^T f = (the updates since) applied to A^T f
+            double *u = w.f[6];                              // (r1updt sets every entry of its w = f6 before reading it)
+            SOCP_PAR_FOR(j, 0, n) u[j] = dot_run(f4c, w.A + j, c.ld, 0, n, 0.0);
+            lazy_apply_to_vector(ex, n, w, s.lazy, u);
+            SOCP_PAR_FOR(j, 0, n) {
+                const double sum = u[j];
+                w.f[4][j] = (sum - pr[j]) / pnorm;
+                w.f[5][j] = w.diag[j] * ((w.diag[j] * pc[j]) / pnorm);
+                if (ratio >= p0001) w.qtf[j] = sum;
+            }
+        } else {
+            SOCP_PAR_FOR(j, 0, n) {
+                const double sum = dot_run(f4c, w.A + j, c.ld, 0, n, 0.0);
+                w.f[4][j] = (sum - pr[j]) / pnorm;
+                w.f[5][j] = w.diag[j] * ((w.diag[j] * pc[j]) / pnorm);
+                if (ratio >= p0001) w.qtf[j] = sum;
+            }
         }
         ex.sync();
         prof.mark(PF_QTW, ex.tid);
         s.sing = r1updt(ex, n, w) ? 1 : 0;
         prof.mark(PF_R1UPDT, ex.tid);
-        r1mpyq_all(ex, n, c.ld, w);
+        if (lazy) {
+            if (s.lazy == lazy_capacity(n)) { lazy_flush(ex, n, c.ld, w, s.lazy); s.lazy = 0; }
+            lazy_store(ex, n, w, s.lazy);
+            s.lazy += 1;
+        } else {
+            r1mpyq_all(ex, n, c.ld, w);
+        }
         prof.mark(PF_R1MPYQ, ex.tid);
         s.jeval = 0;
         request_trial();

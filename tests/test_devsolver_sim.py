@@ -235,3 +235,44 @@ def test_norm_usual_case_and_general_case_are_minpacks(sim):
         got = sim.sim_enorm(11, x.ctypes.data_as(_dp), 1)
         want = _minpack_enorm(x)
         assert (np.isnan(got) and np.isnan(want)) or got == want, (bad, got, want)
+
+
+@pytest.mark.parametrize("n", [8, 15, 16, 33, 64, 130])
+def test_q_kept_as_factorised_moves_iterates_at_rounding_level_only(sim, n):
+    """Config::lazy_q (the throughput flavour of the device solver: Broyden's rotations kept as a list, Q^T f formed from the Q of the last
+    refresh): the same mathematics, so the same info and evaluation counts and the same solution to rounding; R and Q^T f -- which are
+    updated eagerly either way -- agree to rounding too.  Sizes with list capacities 1 (lazy off), 2, 4, 8, 16: with xtol = 1e-13 the solves
+    take more Broyden updates between refreshes than the small lists hold, so the flush to the matrix runs as well."""
+    sim.sim_lazy_capacity.argtypes = [C.c_int]
+    cap = sim.sim_lazy_capacity(n)
+    assert cap == min(16, (n + 1) // 8)
+    rng = np.random.default_rng(n)
+    A = rng.normal(size=(n, n)) + 3 * np.eye(n)
+    b = rng.normal(size=n)
+
+    def f(x):
+        return A @ x + 0.3 * np.sin(x) * np.roll(x, 1) - b
+    x0 = rng.normal(size=n)
+    for xtol in (1e-8, 1e-13):
+        eager = sim_solve(sim, f, None, x0, xtol, 1.0, analytic=False)
+        lazy = sim_solve(sim, f, None, x0, xtol, 1.0, analytic=False, blocked=2)
+        if cap < 2:
+            same(lazy, eager)                                   # no room for a list: the eager code runs
+            continue
+        # (the systems of n = 15 and n = 64 end with info 4 after hundreds of evaluations -- on both sides; R is not compared: once
+        # |f| is at rounding level Broyden's update divides noise by the step length and the factors drift apart, eagerly or not)
+        assert lazy["info"] == eager["info"] and abs(lazy["nfev"] - eager["nfev"]) <= 0.02 * eager["nfev"]
+        scale = np.max(np.abs(eager["x"]))
+        if eager["info"] == 1:
+            assert np.max(np.abs(lazy["x"] - eager["x"])) <= 1e-12 * scale
+            assert np.linalg.norm(lazy["fvec"]) <= 10 * max(np.linalg.norm(eager["fvec"]), 1e-14)
+        else:
+            assert np.max(np.abs(lazy["x"] - eager["x"])) <= 1e-4 * scale
+
+
+def test_q_kept_as_factorised_on_the_analytic_cases(sim):
+    for name, f, x0 in CASES:
+        eager = sim_solve(sim, f, None, x0, 1e-8, 1.0, analytic=False)
+        lazy = sim_solve(sim, f, None, x0, 1e-8, 1.0, analytic=False, blocked=2)
+        assert lazy["info"] == eager["info"], name
+        assert np.allclose(lazy["x"], eager["x"], rtol=1e-9, atol=1e-12), name

@@ -138,3 +138,32 @@ def test_engine_config5_interceptor_sweep():
     assert np.all(exact["info"] == 1)
     _same_solutions(exact, fast)
     ctx.close()
+
+
+@pytest.mark.parametrize("M,P,spread", [(6, 200, 0.05), (9, 120, 0.05)])
+def test_engine_with_q_kept_as_factorised(M, P, spread, monkeypatch):
+    """Config::lazy_q on the device (solver_dev.hpp: Broyden's rotations kept as a list, Q^T f from the Q of the last refresh; what the
+    throughput flavour does by itself from n = 192 up -- the config-5 test above runs it -- forced here on n = 85 / 127, where the lists are
+    short (10 / 16 updates) and long solves fill them, so the flush to the matrix runs too): info and solve counts equal, converged
+    unknowns within 1e-8 of the bit-equal solver -- and of the same flavour with the eager update."""
+    from socp_amd import capi, sweep
+    ctx = capi.Context(capi.MODEL_GODDARD)
+    ctx.set_params(sweep.GODDARD_PARAMS)
+    ctx.set_step_number(10)
+    ctx.set_variant(capi.VARIANT_LANE_FAST)
+    sweep.goddard_multiple_shooting_problem(ctx, M)
+    Z0 = sweep.goddard_multiple_shooting_starts(ctx, sweep.goddard_starts(P, spread), M)
+    kw = dict(kind=capi.CHAIN_PLAIN, xtol=1e-10)
+    exact = ctx.chains_solve(Z0, solver=capi.SOLVER_DEVICE, **kw)
+    monkeypatch.setenv("SOCP_SOLVER_LAZY_Q", "0")
+    eager = ctx.chains_solve(Z0, solver=capi.SOLVER_DEVICE_FAST, **kw)
+    monkeypatch.setenv("SOCP_SOLVER_LAZY_Q", "1")
+    lazy = ctx.chains_solve(Z0, solver=capi.SOLVER_DEVICE_FAST, **kw)
+    monkeypatch.delenv("SOCP_SOLVER_LAZY_Q")
+    default = ctx.chains_solve(Z0, solver=capi.SOLVER_DEVICE_FAST, **kw)
+    assert np.array_equal(default["z"], eager["z"])                     # below n = 192 the eager update is what runs
+    assert not np.array_equal(lazy["z"], eager["z"])                    # (the switch did switch: rounding differs)
+    _same_solutions(exact, lazy)
+    _same_solutions(eager, lazy)
+    assert np.max(lazy["nfev_total"]) > 150                             # long solves are among them: lists of 10 / 16 updates overflow
+    ctx.close()

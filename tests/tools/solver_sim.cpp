@@ -12,18 +12,21 @@ using namespace socp::devsolver;
 
 extern "C" {
 // the device solver's norm (its branch-free usual case and the general three-accumulator loop behind it)
+int sim_lazy_capacity(int n) { return lazy_capacity(n); }
 double sim_enorm(int n, const double *x, long stride) { return enorm(n, x, stride); }
 
 typedef int (*sim_fcn)(int n, const double *x, double *fvec);
 typedef int (*sim_jac)(int n, const double *x, const double *fvec, double *fjac_colmajor);
 
-// returns info; outputs as hybrd leaves them (fjac = Q column-major, r packed by rows).  blocked != 0: the Jacobian refreshes go
-// through factor_blocked (panels + column blocks) instead of factor
+// returns info; outputs as hybrd leaves them (fjac = Q column-major, r packed by rows).  blocked == 1: the Jacobian refreshes go
+// through factor_blocked (panels + column blocks) instead of factor; blocked == 2: Config::lazy_q (Q kept as factorised, Broyden's
+// rotations as a list: the throughput flavour -- fjac then comes back as of the last refresh / flush)
 int sim_solve(int n, double *x, double *fvec, double xtol, int maxfev, double epsfcn, double factor, int analytic, sim_fcn fcn, sim_jac jac,
               int *nfev, int *njev, double *fjac, double *r, double *qtf, double *diag, int blocked)
 {
     Config c;
     c.n = n; c.ld = ld_for(n); c.maxfev = maxfev; c.mode = 1; c.analytic = analytic; c.xtol = xtol; c.epsfcn = epsfcn; c.factor = factor;
+    c.lazy_q = blocked == 2 ? 1 : 0;
     std::vector<double> ws((size_t)ws_doubles(n, c.ld), 0.0), J((size_t)n * n), lds((size_t)blocked_lds_doubles(n), 0.0);
     State st;
     std::memset(&st, 0, sizeof(st));
@@ -34,7 +37,7 @@ int sim_solve(int n, double *x, double *fvec, double xtol, int maxfev, double ep
     for (;;) {
         {
             Machine<SerialExec> m(ex, c, st, ws.data());
-            if (blocked) { m.blocked_panel = lds.data(); m.blocked_block = lds.data() + (size_t)n * kPanel; }
+            if (blocked == 1) { m.blocked_panel = lds.data(); m.blocked_block = lds.data() + (size_t)n * kPanel; }
             m.advance(flag);
         }
         if (st.req == RQ_DONE) break;
