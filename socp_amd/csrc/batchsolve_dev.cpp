@@ -284,8 +284,8 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
     pool.cfg.n = n; pool.cfg.ld = socp::devsolver::ld_for(n); pool.cfg.maxfev = opt->maxfev; pool.cfg.mode = 1;
     pool.cfg.analytic = opt->analytic_jac ? 1 : 0; pool.cfg.xtol = opt->xtol; pool.cfg.epsfcn = opt->epsfcn; pool.cfg.factor = opt->factor;
     // the throughput flavour of LARGE problems also keeps Q as factorised between refreshes (solver_dev.hpp: lazy_capacity): it saves
-    // a quarter of a trial step's memory traffic and adds a serial chain of 2 (n - 1) rotations per update in the list -- measured
-    // (profiles/r04_lazy_q_ab.txt): n = 253 -9 % of a sweep's wall time, n = 85 / 127 +9 ... +15 %.  SOCP_SOLVER_LAZY_Q=0 / 1: never / always.
+    // a quarter of a trial step's memory traffic -- measured (profiles/r04_lazy_q_ab.txt): n = 253 -9 ... -11 % of a sweep's wall
+    // time, n = 85 / 127 nothing (their Q is small: r1mpyq is not what they wait for).  SOCP_SOLVER_LAZY_Q=0 / 1: never / always.
     if (fast_factor) {
         const char *e = std::getenv("SOCP_SOLVER_LAZY_Q");
         pool.cfg.lazy_q = e ? (e[0] == '0' ? 0 : 1) : (n >= 192 ? 1 : 0);

@@ -963,11 +963,76 @@ SOCP_HD int lazy_capacity(int n)
 }
 SOCP_HD bool lazy_applies(const Config &c) { return c.lazy_q != 0 && lazy_capacity(c.n) >= 2; }
 
-// u <- G_count^T ... G_1^T u, by one thread (a serial chain through u[n - 1]); everyone returns with u complete
+#if defined(__HIP_DEVICE_COMPILE__)
+// One sweep of r1mpyq's n - 1 rotations through a VECTOR u, by the whole workgroup.  Rotation q touches u[j] and the running last
+// entry `an` only (first sweep: j = n - 2 - q, an' = s u[j] + c an; second sweep: j = q, an' = -s u[j] + c an), so `an` goes
+// through a chain of affine maps x -> c x + (+-s u[j]) whose composition is associative: every thread composes the maps of its
+// chunk of rotations, an exclusive scan over the threads (shuffles inside a wavefront, LDS across them) gives each its incoming
+// `an`, and the chunk is then walked again with numbers.  2 chunk + 6 shuffle steps instead of n - 1 dependent ones on one thread.
+// red: 2 doubles of LDS per wavefront.  Returns the outgoing `an` (the same in every thread); u is complete when it returns.
+struct Affine {
+    double a, b;
+};
+__device__ __forceinline__ Affine affine_after(const Affine &first, const Affine &then) { return {then.a * first.a, then.a * first.b + then.b}; }
+
+template <bool FIRST>
+__device__ __forceinline__ double sweep_scan(const BlockExec &ex, int n, double *u, const double *c, const double *s, double an, double *red)
+{
+    const int m = n - 1;
+    const int chunk = (m + ex.nt - 1) / ex.nt;
+    const int q0 = ex.tid * chunk, q1 = (q0 + chunk < m) ? q0 + chunk : m;
+    Affine mine{1.0, 0.0};
+    for (int q = q0; q < q1; q++) {
+        const int j = FIRST ? m - 1 - q : q;
+        const double sj = s[j], uj = u[j];
+        mine = affine_after(mine, Affine{c[j], FIRST ? sj * uj : -(sj * uj)});
+    }
+    Affine incl = mine;
+    const int lane = ex.tid & 63, wave = ex.tid >> 6, nw = (ex.nt + 63) >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const Affine o{__shfl_up(incl.a, d), __shfl_up(incl.b, d)};
+        if (lane >= d) incl = affine_after(o, incl);
+    }
+    if (lane == 63) { red[2 * wave] = incl.a; red[2 * wave + 1] = incl.b; }
+    ex.sync();
+    Affine before{1.0, 0.0};
+    for (int w = 0; w < wave; w++) before = affine_after(before, Affine{red[2 * w], red[2 * w + 1]});
+    Affine total = before;
+    for (int w = wave; w < nw; w++) total = affine_after(total, Affine{red[2 * w], red[2 * w + 1]});
+    Affine left{__shfl_up(incl.a, 1), __shfl_up(incl.b, 1)};
+    if (lane == 0) left = Affine{1.0, 0.0};
+    const Affine pre = affine_after(before, left);
+    double a0 = pre.a * an + pre.b;                          // `an` as this thread's chunk finds it
+    for (int q = q0; q < q1; q++) {
+        const int j = FIRST ? m - 1 - q : q;
+        const double cj = c[j], sj = s[j], uj = u[j];
+        if (FIRST) { u[j] = cj * uj - sj * a0; a0 = sj * uj + cj * a0; }
+        else       { u[j] = cj * uj + sj * a0; a0 = -(sj * uj) + cj * a0; }
+    }
+    ex.sync();                                               // u complete, red free again
+    return total.a * an + total.b;
+}
+#endif
+
+// u <- G_count^T ... G_1^T u; everyone returns with u complete.  Device: every sweep as a scan (sweep_scan; red = f7, free between
+// r1updt calls); host simulation: the serial chain through u[n - 1] as r1mpyq writes it (rounding differs between the two)
 template <class E>
 SOCP_HD void lazy_apply_to_vector(const E &ex, int n, const Work &wk, int count, double *u)
 {
     ex.sync();
+#if defined(__HIP_DEVICE_COMPILE__)
+    double an = u[n - 1];
+    ex.sync();                                               // (everyone has read it before anyone's sweep can finish)
+#pragma unroll 1
+    for (int k = 0; k < count; k++) {
+        const double *c1 = wk.V + (long)k * 4 * n, *s1 = c1 + n, *c2 = s1 + n, *s2 = c2 + n;
+        an = sweep_scan<true>(ex, n, u, c1, s1, an, wk.f[7]);
+        an = sweep_scan<false>(ex, n, u, c2, s2, an, wk.f[7]);
+    }
+    if (ex.tid == 0) u[n - 1] = an;
+    ex.sync();
+#else
     if (ex.tid == 0) {
         double an = u[n - 1];
 #pragma unroll 1
@@ -979,6 +1044,7 @@ SOCP_HD void lazy_apply_to_vector(const E &ex, int n, const Work &wk, int count,
         u[n - 1] = an;
     }
     ex.sync();
+#endif
 }
 
 // the rotations of the r1updt that has just run (encodings in f7, f4) -> slot `slot` of the list; qtf goes through them now
@@ -992,6 +1058,13 @@ SOCP_HD void lazy_store(const E &ex, int n, Work &wk, int slot)
         decode_rotation(wk.f[4][j], c2[j], s2[j]);
     }
     ex.sync();
+#if defined(__HIP_DEVICE_COMPILE__)
+    double an = wk.qtf[n - 1];
+    ex.sync();
+    an = sweep_scan<true>(ex, n, wk.qtf, c1, s1, an, wk.f[7]);      // (the encodings in f7 are decoded: it is scratch now)
+    an = sweep_scan<false>(ex, n, wk.qtf, c2, s2, an, wk.f[7]);
+    if (ex.tid == 0) wk.qtf[n - 1] = an;
+#else
     if (ex.tid == ex.nt - 1) {
         double *a = wk.qtf;
         double an = a[n - 1];
@@ -999,6 +1072,7 @@ SOCP_HD void lazy_store(const E &ex, int n, Work &wk, int slot)
         an = rotate_row(a, c2, s2, n, an, false);
         a[n - 1] = an;
     }
+#endif
     ex.sync();
 }
 
