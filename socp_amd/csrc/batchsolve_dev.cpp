@@ -81,25 +81,31 @@ struct Arena {
         void *p = nullptr;
         if (keep_workspaces()) {
             Workspaces &w = workspaces();
-            std::lock_guard<std::mutex> lock(w.m);
-            KeptBlock &b = (host ? w.host : w.dev)[dev];
-            if (!b.busy) {
-                if (b.cap < cap) {
-                    // grow: the new block first (the old one is cleared in the background once freed; an allocation right behind a
-                    // large free waits for that), the other order only when both do not fit
-                    if (raw_alloc(&p, cap, host) != hipSuccess) {
-                        (void)hipGetLastError();
-                        raw_free(b.p, host);
-                        b.p = nullptr; b.cap = 0; p = nullptr;
-                        if (raw_alloc(&p, cap, host) != hipSuccess) return false;
-                    } else {
-                        raw_free(b.p, host);
-                    }
-                    b.p = p; b.cap = cap;
-                }
-                b.busy = true;
+            KeptBlock *b = nullptr;
+            {
+                std::lock_guard<std::mutex> lock(w.m);
+                KeptBlock &slot = (host ? w.host : w.dev)[dev];          // (std::map: the reference stays valid)
+                if (!slot.busy) { slot.busy = true; b = &slot; }
+            }
+            if (b) {
+                // the block is this call's now; growing it happens OUTSIDE the lock (tens of GB take up to a second, and the threads
+                // of socp_sweep_solve -- one per device -- all arrive here at once)
                 kept = true;
-                base = static_cast<char *>(b.p);
+                if (b->cap < cap) {
+                    // the new block first (the old one is cleared in the background once freed; an allocation right behind a large
+                    // free waits for that), the other order only when both do not fit
+                    void *const old = b->p;                  // (nobody else touches a busy slot; its fields change under the lock only,
+                                                             // socp_workspace_cached_bytes reads them)
+                    bool ok = raw_alloc(&p, cap, host) == hipSuccess;
+                    if (!ok) (void)hipGetLastError();
+                    raw_free(old, host);
+                    if (!ok) { p = nullptr; ok = raw_alloc(&p, cap, host) == hipSuccess; }
+                    std::lock_guard<std::mutex> lock(w.m);
+                    b->p = ok ? p : nullptr;
+                    b->cap = ok ? cap : 0;
+                    if (!ok) return false;                   // (~Arena hands the empty slot back)
+                }
+                base = static_cast<char *>(b->p);
                 return true;
             }
         }
