@@ -148,6 +148,7 @@ def test_chain_engine_out_of_memory_exits_cleanly():
     L.socp_ctx_get_stream.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     before = C.c_void_p()
     assert L.socp_ctx_get_stream(ctx.h, C.byref(before)) == 0
+    capi.workspace_release()                       # (the engine keeps its arenas between calls: this test is about a call that finds no memory)
     free0, total = torch.cuda.mem_get_info()
     #  the test owns the card: it sizes its reservation from what is free NOW, so it is meaningless -- and would fail for
     # reasons that are not the code's -- while another process holds a large part of the memory; the GPU suite runs in one process
@@ -175,6 +176,7 @@ def test_chain_engine_out_of_memory_exits_cleanly():
     assert np.all(r["info"] == 1) and r["stats"]["speculative_rounds"] == 0 and r["stats"]["jacobians_from_cache"] == 0
     del hog
     torch.cuda.empty_cache()
+    capi.workspace_release()                       # (what the engine calls that DID run have kept)
     free1, _ = torch.cuda.mem_get_info()
     assert free1 >= free0 - (64 << 20)                                              # nothing of the failed call is still allocated
     ok = ctx.chains_solve(Z0, kind=capi.CHAIN_PLAIN, xtol=1e-8, solver=capi.SOLVER_DEVICE)
