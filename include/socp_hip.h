@@ -120,6 +120,9 @@ int socp_ctx_has_variational(const socp_ctx *ctx);
 
 /* counters since creation: trajectories integrated, kernel launches */
 int socp_ctx_counters(const socp_ctx *ctx, long long *trajectories, long long *launches);
+/* adds to them: what a clone of `ctx` (socp_ctx_clone) integrated on its behalf -- the second group of chains of a large
+ * socp_chains_solve call runs on one -- counts as ctx's */
+void socp_ctx_add_counters(socp_ctx *ctx, long long trajectories, long long launches);
 
 /* ---- batched trajectory integration ------------------------------------------------------ */
 /* replaces: shooting::Move -> model::ComputeTraj -> ModelInt -> odeTools::integrate -> RK4

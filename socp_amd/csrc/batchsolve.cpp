@@ -36,13 +36,15 @@
 int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt, const double *Z0, const double *params,
                              const double *goal, const double *time_prev, const double *x_prev, const double *time_goal,
                              const double *x_goal, double *Zout, int *info, int *nfev_last, int *nfev_total, int *njev_last,
-                             int *solves, double *b_reached, double *param_final, double *fnorm, socp_chain_stats *stats, int fast_factor);
+                             int *solves, double *b_reached, double *param_final, double *fnorm, socp_chain_stats *stats, int fast_factor,
+                             int workspace_slot);
 // ... what it allocates on the device for P chains of this context's problem (one plan, shared with the allocation itself), whether the
 // throughput factorisation exists for size n, and the code with which it reports "could not allocate, nothing has run yet"
 double socp_chains_device_bytes(const socp_ctx *ctx, int P, const socp_chain_options *opt, bool per_chain_params, bool per_chain_bounds);
 bool socp_chains_fast_factor_applies(int n);
 double socp_workspace_reusable_device_bytes(int device);
 constexpr int kDeviceEngineAllocFailed = -1000;
+using clk_t = std::chrono::steady_clock;
 
 namespace {
 
@@ -180,8 +182,64 @@ extern "C" int socp_chains_solve_ex(socp_ctx *ctx, int P, const socp_chain_optio
         }
         if (solver == SOCP_SOLVER_DEVICE || solver == SOCP_SOLVER_DEVICE_FAST) {
             const int fast = (solver == SOCP_SOLVER_DEVICE_FAST && socp_chains_fast_factor_applies(n)) ? 1 : 0;
-            const int rc = socp_chains_solve_device(ctx, P, opt, Z0, params, goal, time_prev, x_prev, time_goal, x_goal, Zout, info, nfev_last, nfev_total,
-                                                    njev_last, solves, b_reached, param_final, fnorm, stats, fast);
+            // LARGE sweeps run as two groups of chains side by side -- two host threads, the second on a clone of the context, each
+            // with its own engine call on its half of the chains: while one group's trajectory launches keep the chip busy, the other's
+            // host logic, state read-back and solver kernels proceed.  Measured on 1 M starts of n = 14, 10^4 steps
+            // (scripts/probes/two_groups_probe.py): 5.36 -> 5.03 s; four groups no better.  A chain only ever meets its own group, so
+            // its iterates are those of one call (with a round budget the ROUND in which a chain is served can differ, as it does
+            // between any two batch sizes).  SOCP_CHAINS_DEVICE_GROUPS=1|2 overrides.
+            int G = (P >= 262144 && !opt->analytic_jac) ? 2 : 1;
+            if (const char *e = std::getenv("SOCP_CHAINS_DEVICE_GROUPS")) G = std::max(1, std::min(4, std::atoi(e)));
+            if (opt->analytic_jac || G > P) G = 1;
+            int rc = SOCP_OK;
+            if (G == 1) {
+                rc = socp_chains_solve_device(ctx, P, opt, Z0, params, goal, time_prev, x_prev, time_goal, x_goal, Zout, info, nfev_last, nfev_total,
+                                              njev_last, solves, b_reached, param_final, fnorm, stats, fast, 0);
+            } else {
+                const int nodes = socp_problem_num_nodes(ctx);
+                const clk_t::time_point t_groups = clk_t::now();
+                std::vector<int> grc(G, SOCP_OK);
+                std::vector<socp_chain_stats> gst(G);
+                std::vector<socp_ctx *> gctx(G, nullptr);
+                gctx[0] = ctx;
+                for (int g = 1; g < G && rc == SOCP_OK; g++) rc = socp_ctx_clone(ctx, socp_ctx_device(ctx), &gctx[g]);
+                if (rc == SOCP_OK) {
+                    auto work = [&](int g) {
+                        const int lo = (int)((long long)P * g / G), hi = (int)((long long)P * (g + 1) / G);
+                        auto at = [&](const double *a, size_t width) { return a ? a + (size_t)lo * width : nullptr; };
+                        auto ati = [&](int *a) { return a ? a + lo : nullptr; };
+                        auto atd = [&](double *a) { return a ? a + lo : nullptr; };
+                        std::memset(&gst[g], 0, sizeof(gst[g]));
+                        grc[g] = socp_chains_solve_device(gctx[g], hi - lo, opt, Z0 + (size_t)lo * n, at(params, nparams), at(goal, 1), at(time_prev, nodes),
+                                                          at(x_prev, (size_t)nodes * S), at(time_goal, nodes), at(x_goal, (size_t)nodes * S),
+                                                          Zout + (size_t)lo * n, info + lo, ati(nfev_last), ati(nfev_total), ati(njev_last), ati(solves),
+                                                          atd(b_reached), atd(param_final), atd(fnorm), &gst[g], fast, g);
+                    };
+                    std::vector<std::thread> th;
+                    for (int g = 1; g < G; g++) th.emplace_back(work, g);
+                    work(0);
+                    for (std::thread &t : th) t.join();
+                    for (int g = 0; g < G; g++) if (grc[g] != SOCP_OK && (rc == SOCP_OK || rc == kDeviceEngineAllocFailed)) rc = grc[g];
+                }
+                for (int g = 1; g < G; g++) {
+                    if (!gctx[g]) continue;
+                    long long traj = 0, launches = 0;
+                    socp_ctx_counters(gctx[g], &traj, &launches);
+                    socp_ctx_add_counters(ctx, traj, launches);
+                    socp_ctx_destroy(gctx[g]);
+                }
+                if (stats && rc == SOCP_OK) {
+                    std::memset(stats, 0, sizeof(*stats));
+                    for (int g = 0; g < G; g++) {
+                        stats->rounds = std::max(stats->rounds, gst[g].rounds);
+                        stats->speculative_rounds = std::max(stats->speculative_rounds, gst[g].speculative_rounds);
+                        stats->jacobians_launched += gst[g].jacobians_launched;
+                        stats->jacobians_from_cache += gst[g].jacobians_from_cache;
+                        stats->restarts += gst[g].restarts;
+                    }
+                    stats->wall_ms = std::chrono::duration<double, std::milli>(clk_t::now() - t_groups).count();
+                }
+            }
             if (rc != kDeviceEngineAllocFailed) return rc;
             // the arena did not fit after all (another process took the memory since the estimate): nothing has run.  AUTO made the
             // choice, so AUTO takes the other engine; a caller who asked for the device solvers gets the error.

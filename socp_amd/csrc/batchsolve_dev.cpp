@@ -46,9 +46,10 @@ struct KeptBlock {
     size_t cap = 0;
     bool busy = false;
 };
+constexpr int kSlotsPerDevice = 4;                   // concurrent engine calls per device that find a kept block (chain groups)
 struct Workspaces {
     std::mutex m;
-    std::map<int, KeptBlock> dev, host;
+    std::map<int, KeptBlock> dev, host;              // key: device * kSlotsPerDevice + slot
 };
 Workspaces &workspaces()
 {
@@ -70,13 +71,13 @@ struct Arena {
     char *base = nullptr;
     size_t used = 0, cap = 0;
     bool pinned = false, kept = false;
-    int device = 0;
+    int key = 0;
     static size_t pad(size_t bytes) { return (bytes + 255) / 256 * 256; }
     size_t plan(size_t bytes) { const size_t at = used; used += pad(bytes ? bytes : 8); return at; }
-    bool alloc(bool host, int dev)
+    bool alloc(bool host, int dev, int slot)
     {
         pinned = host;
-        device = dev;
+        key = dev * kSlotsPerDevice + (slot < 0 ? 0 : slot % kSlotsPerDevice);
         cap = used ? used : 256;
         void *p = nullptr;
         if (keep_workspaces()) {
@@ -84,8 +85,8 @@ struct Arena {
             KeptBlock *b = nullptr;
             {
                 std::lock_guard<std::mutex> lock(w.m);
-                KeptBlock &slot = (host ? w.host : w.dev)[dev];          // (std::map: the reference stays valid)
-                if (!slot.busy) { slot.busy = true; b = &slot; }
+                KeptBlock &kb = (host ? w.host : w.dev)[key];            // (std::map: the reference stays valid)
+                if (!kb.busy) { kb.busy = true; b = &kb; }
             }
             if (b) {
                 // the block is this call's now; growing it happens OUTSIDE the lock (tens of GB take up to a second, and the threads
@@ -118,7 +119,7 @@ struct Arena {
         if (kept) {
             Workspaces &w = workspaces();
             std::lock_guard<std::mutex> lock(w.m);
-            (pinned ? w.host : w.dev)[device].busy = false;
+            (pinned ? w.host : w.dev)[key].busy = false;
         } else {
             raw_free(base, pinned);
         }
@@ -171,7 +172,7 @@ struct EnginePlan {
     }
     double device_bytes(int P, bool pp_params, bool pp_bound) const
     {
-        double b = (double)P * (sizeof(double) * (double)ws_stride + sizeof(State) + 6.0 * rowB) + 5.0 * intsB + (double)jacB * jlaunch;
+        double b = (double)P * (sizeof(double) * (double)ws_stride + sizeof(State) + 6.0 * rowB) + 6.0 * intsB + (double)jacB * jlaunch;
         if (pp_params) b += 2.0 * parB;
         if (pp_bound) b += 2.0 * (timeB + nodeB);
         b += 2.0 * (double)P * rowB * (rowB / sizeof(double) + 1);          // (upper bound: a cache slot per chain and as much staging)
@@ -195,7 +196,7 @@ extern "C" double socp_workspace_cached_bytes(int device)
     double total = 0;
     for (auto *table : {&w.dev, &w.host})
         for (auto &kv : *table)
-            if (device < 0 || kv.first == device) total += (double)kv.second.cap;
+            if (device < 0 || kv.first / kSlotsPerDevice == device) total += (double)kv.second.cap;
     return total;
 }
 
@@ -209,8 +210,8 @@ extern "C" double socp_workspace_release(int device)
     for (int host = 0; host < 2; host++)
         for (auto &kv : host ? w.host : w.dev) {
             KeptBlock &b = kv.second;
-            if ((device >= 0 && kv.first != device) || b.busy || !b.p) continue;
-            if (hipSetDevice(kv.first) != hipSuccess) { (void)hipGetLastError(); continue; }
+            if ((device >= 0 && kv.first / kSlotsPerDevice != device) || b.busy || !b.p) continue;
+            if (hipSetDevice(kv.first / kSlotsPerDevice) != hipSuccess) { (void)hipGetLastError(); continue; }
             raw_free(b.p, host != 0);
             freed += (double)b.cap;
             b.p = nullptr; b.cap = 0;
@@ -224,18 +225,21 @@ double socp_workspace_reusable_device_bytes(int device)
 {
     Workspaces &w = workspaces();
     std::lock_guard<std::mutex> lock(w.m);
-    auto it = w.dev.find(device);
-    return (it != w.dev.end() && !it->second.busy) ? (double)it->second.cap : 0.0;
+    double total = 0;
+    for (auto &kv : w.dev)
+        if (kv.first / kSlotsPerDevice == device && !kv.second.busy) total += (double)kv.second.cap;
+    return total;
 }
 
 bool socp_chains_fast_factor_applies(int n) { return socp::devsolver::fast_factor_applies(n); }
 
 // Same contract as socp_chains_solve_ex (include/socp_solver.h); called from there when the device solvers are chosen.
-// fast_factor: the Jacobian refreshes go through the throughput factorisation (kernels_factor_fast.hip).
+// fast_factor: the Jacobian refreshes go through the throughput factorisation (kernels_factor_fast.hip).  workspace_slot: which of the
+// device's kept blocks this call may take (chain groups run side by side: batchsolve.cpp).
 int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt, const double *Z0, const double *params,
                              const double *goal, const double *time_prev, const double *x_prev, const double *time_goal,
                              const double *x_goal, double *Zout, int *info, int *nfev_last, int *nfev_total, int *njev_last,
-                             int *solves, double *b_reached, double *param_final, double *fnorm, socp_chain_stats *stats, int fast_factor)
+                             int *solves, double *b_reached, double *param_final, double *fnorm, socp_chain_stats *stats, int fast_factor, int workspace_slot)
 {
     using clk = std::chrono::steady_clock;
     const clk::time_point t_begin = clk::now();
@@ -322,19 +326,19 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
     const bool spec_on = speculate != 0;
     // the most residual requests a round evaluates as FD batches: all P when forced, else what one wavefront per SIMD holds
     const int capS = !spec_on ? 0 : (speculate > 0 ? P : (int)std::min<long>(P, std::max<long>(1, (long)num_simd * 64 / ((long)(n + 1) * segs))));
-    Dev dWs, dStates, dList, dFlags, dListF, dListJ, dX, dF, dJx, dJf, dJ, dRes, dPF, dTF, dXF, dPJ, dTJ, dXJ, dSlots, dStage, dIdxA, dIdxB;
+    Dev dWs, dStates, dList, dListS, dFlags, dListF, dListJ, dX, dF, dJx, dJf, dJ, dRes, dPF, dTF, dXF, dPJ, dTJ, dXJ, dSlots, dStage, dIdxA, dIdxB;
     Pinned hIdxA, hIdxB;
-    Pinned hStates, hList, hFlags, hListF, hListJ, hX, hRes, hPF, hTF, hXF, hPJ, hTJ, hXJ;
+    Pinned hStates, hList, hListS, hFlags, hListF, hListJ, hX, hRes, hPF, hTF, hXF, hPJ, hTJ, hXJ;
     Arena dev_arena, host_arena;
     {
         const size_t intsB = plan_sizes.intsB, parB = plan_sizes.parB, timeB = plan_sizes.timeB, nodeB = plan_sizes.nodeB;
         struct { Piece *piece; size_t bytes; bool host; } plan[] = {
-            {&dWs, sizeof(double) * pool.ws_stride * P, false}, {&dStates, sizeof(State) * P, false}, {&dList, intsB, false},
+            {&dWs, sizeof(double) * pool.ws_stride * P, false}, {&dStates, sizeof(State) * P, false}, {&dList, intsB, false}, {&dListS, intsB, false},
             {&dFlags, intsB, false}, {&dListF, intsB, false}, {&dListJ, intsB, false}, {&dX, rowB * P, false}, {&dF, rowB * P, false},
             {&dJx, rowB * P, false}, {&dJf, rowB * P, false}, {&dJ, jacB * jlaunch, false}, {&dRes, 2 * rowB * P, false},
             {&dPF, pp_params ? parB : 0, false}, {&dPJ, pp_params ? parB : 0, false}, {&dTF, pp_bound ? timeB : 0, false},
             {&dTJ, pp_bound ? timeB : 0, false}, {&dXF, pp_bound ? nodeB : 0, false}, {&dXJ, pp_bound ? nodeB : 0, false},
-            {&hStates, sizeof(State) * P, true}, {&hList, intsB, true}, {&hFlags, intsB, true}, {&hListF, intsB, true},
+            {&hStates, sizeof(State) * P, true}, {&hList, intsB, true}, {&hListS, intsB, true}, {&hFlags, intsB, true}, {&hListF, intsB, true},
             {&hListJ, intsB, true}, {&hX, rowB * P, true}, {&hRes, 2 * rowB * P, true}, {&hPF, pp_params ? parB : 0, true},
             {&hPJ, pp_params ? parB : 0, true}, {&hTF, pp_bound ? timeB : 0, true}, {&hTJ, pp_bound ? timeB : 0, true},
             {&hXF, pp_bound ? nodeB : 0, true}, {&hXJ, pp_bound ? nodeB : 0, true},
@@ -342,9 +346,9 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
             {&dIdxB, spec_on ? intsB : 0, false}, {&hIdxA, spec_on ? intsB : 0, true}, {&hIdxB, spec_on ? intsB : 0, true}};
         for (auto &e : plan) e.piece->plan(e.host ? host_arena : dev_arena, e.bytes);
         const double t0 = ms_since(t_begin);
-        bool ok = dev_arena.alloc(false, socp_ctx_device(ctx));
+        bool ok = dev_arena.alloc(false, socp_ctx_device(ctx), workspace_slot);
         const double t1 = ms_since(t_begin);
-        ok = ok && host_arena.alloc(true, socp_ctx_device(ctx));
+        ok = ok && host_arena.alloc(true, socp_ctx_device(ctx), workspace_slot);
         const double t2 = ms_since(t_begin);
         void *aux = nullptr;
         if (ok) ok = socp_ctx_aux_stream(ctx, &aux) == SOCP_OK;              // the context's second stream (created on its first use: ~6 ms)
@@ -376,12 +380,15 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
     int adv_jac = 0;                     // the first adv_jac entries of `adv` are chains whose pending request was a Jacobian
     auto start_chains = [&](const std::vector<int> &list) {
         if (list.empty()) return;
-        std::memcpy(hList.p, list.data(), sizeof(int) * list.size());
-        hip_ok(hipMemcpyAsync(dList.p, hList.p, sizeof(int) * list.size(), hipMemcpyHostToDevice, main_stream));
+        // its OWN list buffers: the copy below is asynchronous and the advance loop refills hList right after this returns -- with
+        // the same chains when nothing else is waiting for an advance, but with cached-Jacobian chains in front of them when the
+        // speculative rows are on (found in round 4: continuation chains restarted from the wrong list, iterates changed)
+        std::memcpy(hListS.p, list.data(), sizeof(int) * list.size());
+        hip_ok(hipMemcpyAsync(dListS.p, hListS.p, sizeof(int) * list.size(), hipMemcpyHostToDevice, main_stream));
         // the start kernel reads the rows straight from the pinned buffer (it is mapped into the device's address space): a
         // hipMemcpyAsync of these 4 MB held the calling thread for 7 ms at the first start of 4096 chains.  hX is not written
         // again before the next stream synchronise.
-        hip_ok(socp::devsolver::launch_start(main_stream, pool, dList.i(), (int)list.size(), hX.d()));
+        hip_ok(socp::devsolver::launch_start(main_stream, pool, dListS.i(), (int)list.size(), hX.d()));
     };
 
     {

@@ -415,6 +415,12 @@ int socp_ctx_counters(const socp_ctx *c, long long *trajectories, long long *lau
     return SOCP_OK;
 }
 
+// batchsolve.cpp: what a clone of `c` integrated on its behalf (chain groups) counts as c's
+void socp_ctx_add_counters(socp_ctx *c, long long trajectories, long long launches)
+{
+    if (c) { c->n_traj += trajectories; c->n_launch += launches; }
+}
+
 /* ---- trajectories ------------------------------------------------------------------------ */
 
 int socp_integrate_batch_dev(socp_ctx *c, int B, const double *d_t0, const double *d_tf,

@@ -620,3 +620,26 @@ def test_config5_interceptor_solve_sweep():
         roots[variant] = r["z"][0]
         ctx.close()
     assert np.max(np.abs(roots["fast"] - roots["exact"])) / np.max(np.abs(roots["exact"])) <= 1e-8
+
+
+@pytest.mark.parametrize("solver", ["host", "device"])
+def test_speculative_rows_with_continuation_chains_that_restart_at_different_times(solver):
+    """Speculative FD rows and chains of SEVERAL solves each (round 4: with the solvers on the device a restarted chain's start list
+    shared a pinned buffer with the advance list, which differs from it exactly when cached Jacobians are waiting -- chains were
+    restarted from the wrong list and their iterates changed; one chain alone, or no speculation, hid it): nine KD chains with their
+    own goals, one of them bisecting 50 times, every output equal with the rows never / always / automatically speculated."""
+    from socp_amd import capi
+    ctx = make_ctx("exact")
+    goddard_m6(ctx)
+    goals = np.array([310.0, 250.0, 400.0, 310.0, 120.0, 5000.0, 310.0, 600.0, 280.0])
+    P = len(goals)
+    Z0 = np.tile(STAGE2_INIT, (P, 1))
+    Z0[3, 7:14] *= 1 + 1e-6
+    which = capi.SOLVER_HOST if solver == "host" else capi.SOLVER_DEVICE
+    kw = dict(kind=capi.CHAIN_PARAM, param_index=KD, step=0.4, goal=goals, params=np.tile(PARAMS0, (P, 1)), xtol=1e-6, solver=which)
+    runs = {s: ctx.chains_solve(Z0, speculate=s, **kw) for s in (0, 1, -1)}
+    for s in (1, -1):
+        for key in ("z", "info", "nfev", "nfev_total", "solves", "b_reached", "param_final", "fnorm"):
+            assert np.array_equal(runs[0][key], runs[s][key], equal_nan=True), (s, key)
+    assert runs[1]["stats"]["jacobians_from_cache"] > 0 and np.max(runs[0]["solves"]) > 20
+    ctx.close()

@@ -340,3 +340,49 @@ def test_kept_workspace_changes_no_result():
     after = ctx.chains_solve(Z0[:16], solver=capi.SOLVER_DEVICE, **kw)
     assert np.array_equal(after["z"], fresh[capi.SOLVER_DEVICE]["z"])
     ctx.close()
+
+
+def test_two_groups_of_chains_side_by_side_change_no_result(monkeypatch):
+    """Large sweeps on the device solvers run as two groups of chains on two host threads, the second on a clone of the context
+    (batchsolve.cpp; by itself from 262 144 chains up, forced here): a chain only meets its own group, so every output is the
+    one-group output bit for bit -- plain sweeps and parameter chains with their per-chain arrays --, the statistics add up and the
+    clone's trajectories are counted on the caller's context."""
+    from socp_amd import capi, sweep
+    from test_gpu_chains import STAGE2_INIT, PARAMS0, KD, goddard_m6, make_ctx
+    ctx = capi.Context(capi.MODEL_GODDARD)
+    ctx.set_params(sweep.GODDARD_PARAMS)
+    ctx.set_step_number(10)
+    ctx.set_variant(capi.VARIANT_LANE_FAST)
+    sweep.goddard_multiple_shooting_problem(ctx, 6)
+    Z0 = sweep.goddard_multiple_shooting_starts(ctx, sweep.goddard_starts(301, 0.05), 6)
+    for solver in (capi.SOLVER_DEVICE, capi.SOLVER_DEVICE_FAST):
+        monkeypatch.setenv("SOCP_CHAINS_DEVICE_GROUPS", "1")
+        c0 = ctx.counters()[0]
+        one = ctx.chains_solve(Z0, kind=capi.CHAIN_PLAIN, xtol=1e-10, solver=solver)
+        c1 = ctx.counters()[0]
+        for G in ("2", "3"):
+            monkeypatch.setenv("SOCP_CHAINS_DEVICE_GROUPS", G)
+            c2 = ctx.counters()[0]
+            two = ctx.chains_solve(Z0, kind=capi.CHAIN_PLAIN, xtol=1e-10, solver=solver)
+            for k in KEYS:
+                assert np.array_equal(one[k], two[k], equal_nan=True), (solver, G, k)
+            assert two["stats"]["jacobians_launched"] + two["stats"]["jacobians_from_cache"] == \
+                one["stats"]["jacobians_launched"] + one["stats"]["jacobians_from_cache"]
+            assert two["stats"]["rounds"] <= one["stats"]["rounds"]
+            assert ctx.counters()[0] - c2 >= 0.9 * (c1 - c0)             # (speculative FD batches depend on the group size: not equal)
+    ctx.close()
+    # continuation chains with per-chain parameters and goals: the per-chain arrays are offset per group
+    ctx = make_ctx("exact")
+    goddard_m6(ctx)
+    goals = np.array([310.0, 250.0, 400.0, 310.0, 120.0, 5000.0, 310.0, 600.0, 280.0])
+    P = len(goals)
+    Z0 = np.tile(STAGE2_INIT, (P, 1))
+    Z0[3, 7:14] *= 1 + 1e-6
+    kw = dict(kind=capi.CHAIN_PARAM, param_index=KD, step=0.4, goal=goals, params=np.tile(PARAMS0, (P, 1)), xtol=1e-6, solver=capi.SOLVER_DEVICE)
+    monkeypatch.setenv("SOCP_CHAINS_DEVICE_GROUPS", "1")
+    one = ctx.chains_solve(Z0, **kw)
+    monkeypatch.setenv("SOCP_CHAINS_DEVICE_GROUPS", "2")
+    two = ctx.chains_solve(Z0, **kw)
+    for k in KEYS:
+        assert np.array_equal(one[k], two[k], equal_nan=True), k
+    ctx.close()
