@@ -643,3 +643,34 @@ def test_speculative_rows_with_continuation_chains_that_restart_at_different_tim
             assert np.array_equal(runs[0][key], runs[s][key], equal_nan=True), (s, key)
     assert runs[1]["stats"]["jacobians_from_cache"] > 0 and np.max(runs[0]["solves"]) > 20
     ctx.close()
+
+
+def test_engines_agree_on_seeded_random_mixtures_of_chains(monkeypatch):
+    """Differential test of the lock-step engines' bookkeeping (request lists, restarts, cached rows, groups): seeded random
+    mixtures of KD continuation chains -- numbers of chains, goals (some unreachable: dozens of bisections), continuation steps --
+    solved by the host engine without speculative rows (the baseline: bit-equal to the sequential loop, tests above) and by the
+    device engine with the rows never / always / automatically speculated and the chains in one, two or three groups.  Every
+    output of every chain must be the baseline's, bit for bit."""
+    from socp_amd import capi
+    ctx = make_ctx("exact")
+    goddard_m6(ctx)
+    rng = np.random.default_rng(20250905)
+    keys = ("z", "info", "nfev", "nfev_total", "solves", "b_reached", "param_final", "fnorm")
+    for trial in range(6):
+        P = int(rng.integers(2, 24))
+        goals = rng.choice([120.0, 250.0, 280.0, 310.0, 400.0, 600.0, 2500.0], size=P)
+        Z0 = np.tile(STAGE2_INIT, (P, 1))
+        Z0[:, 7:14] *= 1 + 1e-6 * rng.uniform(-1, 1, (P, 7))
+        step = float(rng.choice([1.0, 0.4, 0.25]))
+        kw = dict(kind=capi.CHAIN_PARAM, param_index=KD, step=step, step_min=1e-2, goal=goals, params=np.tile(PARAMS0, (P, 1)), xtol=1e-6)
+        monkeypatch.setenv("SOCP_CHAINS_DEVICE_GROUPS", "1")
+        base = ctx.chains_solve(Z0, solver=capi.SOLVER_HOST, speculate=0, **kw)
+        for speculate, groups in ((0, "1"), (1, "1"), (-1, "2"), (1, "3"), (0, "2")):
+            monkeypatch.setenv("SOCP_CHAINS_DEVICE_GROUPS", groups)
+            r = ctx.chains_solve(Z0, solver=capi.SOLVER_DEVICE, speculate=speculate, **kw)
+            for k in keys:
+                assert np.array_equal(base[k], r[k], equal_nan=True), (trial, P, step, speculate, groups, k)
+        r = ctx.chains_solve(Z0, solver=capi.SOLVER_HOST, speculate=1, **kw)
+        for k in keys:
+            assert np.array_equal(base[k], r[k], equal_nan=True), (trial, "host speculate=1", k)
+    ctx.close()
