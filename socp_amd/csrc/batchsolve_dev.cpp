@@ -6,7 +6,7 @@
 // per-column / per-row operation order kept, so every chain follows the host engine's iterates bit for bit):
 //
 //   per round:  advance kernel (all chains that received what they asked for)
-//               -> states back to the host (48 B per chain: which request is pending)
+//               -> the advanced chains' status back to the host (24 B each: which request is pending, counters)
 //               -> host: request lists in chain order, homotopy logic of chains whose solve ended (restart / retire)
 //               -> gather the evaluation points on the device, ONE residual launch, ONE Jacobian launch (two streams),
 //                  scatter the results into the problems' workspaces (the Jacobian transposed into the solver's row-major
@@ -38,6 +38,7 @@ namespace {
 
 using socp::devsolver::PoolDev;
 using socp::devsolver::State;
+using socp::devsolver::Status;
 
 // What is kept between calls (include/socp_solver.h "the device engine's workspace"): per device one block of device memory and
 // one of pinned host memory.  Never destroyed (a static destructor would call into a HIP runtime that may be gone already).
@@ -172,7 +173,7 @@ struct EnginePlan {
     }
     double device_bytes(int P, bool pp_params, bool pp_bound) const
     {
-        double b = (double)P * (sizeof(double) * (double)ws_stride + sizeof(State) + 6.0 * rowB) + 6.0 * intsB + (double)jacB * jlaunch;
+        double b = (double)P * (sizeof(double) * (double)ws_stride + sizeof(State) + sizeof(Status) + 6.0 * rowB) + 6.0 * intsB + (double)jacB * jlaunch;
         if (pp_params) b += 2.0 * parB;
         if (pp_bound) b += 2.0 * (timeB + nodeB);
         b += 2.0 * (double)P * rowB * (rowB / sizeof(double) + 1);          // (upper bound: a cache slot per chain and as much staging)
@@ -326,19 +327,19 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
     const bool spec_on = speculate != 0;
     // the most residual requests a round evaluates as FD batches: all P when forced, else what one wavefront per SIMD holds
     const int capS = !spec_on ? 0 : (speculate > 0 ? P : (int)std::min<long>(P, std::max<long>(1, (long)num_simd * 64 / ((long)(n + 1) * segs))));
-    Dev dWs, dStates, dList, dListS, dFlags, dListF, dListJ, dX, dF, dJx, dJf, dJ, dRes, dPF, dTF, dXF, dPJ, dTJ, dXJ, dSlots, dStage, dIdxA, dIdxB;
+    Dev dWs, dStates, dStatus, dList, dListS, dFlags, dListF, dListJ, dX, dF, dJx, dJf, dJ, dRes, dPF, dTF, dXF, dPJ, dTJ, dXJ, dSlots, dStage, dIdxA, dIdxB;
     Pinned hIdxA, hIdxB;
-    Pinned hStates, hList, hListS, hFlags, hListF, hListJ, hX, hRes, hPF, hTF, hXF, hPJ, hTJ, hXJ;
+    Pinned hStatus, hList, hListS, hFlags, hListF, hListJ, hX, hRes, hPF, hTF, hXF, hPJ, hTJ, hXJ;
     Arena dev_arena, host_arena;
     {
         const size_t intsB = plan_sizes.intsB, parB = plan_sizes.parB, timeB = plan_sizes.timeB, nodeB = plan_sizes.nodeB;
         struct { Piece *piece; size_t bytes; bool host; } plan[] = {
-            {&dWs, sizeof(double) * pool.ws_stride * P, false}, {&dStates, sizeof(State) * P, false}, {&dList, intsB, false}, {&dListS, intsB, false},
+            {&dWs, sizeof(double) * pool.ws_stride * P, false}, {&dStates, sizeof(State) * P, false}, {&dStatus, sizeof(Status) * P, false}, {&dList, intsB, false}, {&dListS, intsB, false},
             {&dFlags, intsB, false}, {&dListF, intsB, false}, {&dListJ, intsB, false}, {&dX, rowB * P, false}, {&dF, rowB * P, false},
             {&dJx, rowB * P, false}, {&dJf, rowB * P, false}, {&dJ, jacB * jlaunch, false}, {&dRes, 2 * rowB * P, false},
             {&dPF, pp_params ? parB : 0, false}, {&dPJ, pp_params ? parB : 0, false}, {&dTF, pp_bound ? timeB : 0, false},
             {&dTJ, pp_bound ? timeB : 0, false}, {&dXF, pp_bound ? nodeB : 0, false}, {&dXJ, pp_bound ? nodeB : 0, false},
-            {&hStates, sizeof(State) * P, true}, {&hList, intsB, true}, {&hListS, intsB, true}, {&hFlags, intsB, true}, {&hListF, intsB, true},
+            {&hStatus, sizeof(Status) * P, true}, {&hList, intsB, true}, {&hListS, intsB, true}, {&hFlags, intsB, true}, {&hListF, intsB, true},
             {&hListJ, intsB, true}, {&hX, rowB * P, true}, {&hRes, 2 * rowB * P, true}, {&hPF, pp_params ? parB : 0, true},
             {&hPJ, pp_params ? parB : 0, true}, {&hTF, pp_bound ? timeB : 0, true}, {&hTJ, pp_bound ? timeB : 0, true},
             {&hXF, pp_bound ? nodeB : 0, true}, {&hXJ, pp_bound ? nodeB : 0, true},
@@ -360,7 +361,10 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
     }
     pool.states = static_cast<State *>(dStates.p);
     pool.ws = dWs.d();
-    State *hS = static_cast<State *>(hStates.p);
+    // what the host knows of every chain's state machine: refreshed after each advance for the chains that were advanced (the others
+    // have not changed), from a compact record gathered on the device
+    std::vector<Status> hS(P, Status{0, 0, 0, 0, 0, 0});
+    const Status *const hNew = static_cast<const Status *>(hStatus.p);
 
     // per chain: where its request's FD rows sit in the staging area (-1: none), what the solver's iteration counter and the kind of
     // the request were when they were staged, and for which iteration counter the rows in its slot are the rows at x (-1: none).
@@ -418,10 +422,12 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
             hip_ok(socp::devsolver::launch_advance(main_stream, pool, dList.i(), adv_jac, dFlags.i(), true));
             hip_ok(socp::devsolver::launch_advance(main_stream, pool, dList.i() + adv_jac, count - adv_jac, dFlags.i() + adv_jac, false));
             adv_jac = 0;
-            hip_ok(hipMemcpyAsync(hStates.p, dStates.p, sizeof(State) * P, hipMemcpyDeviceToHost, main_stream));
+            hip_ok(socp::devsolver::launch_gather_status(main_stream, pool, dList.i(), count, static_cast<Status *>(dStatus.p)));
+            hip_ok(hipMemcpyAsync(hStatus.p, dStatus.p, sizeof(Status) * count, hipMemcpyDeviceToHost, main_stream));
             hip_ok(hipStreamSynchronize(main_stream));
             t_adv += ms_since(ta);
             if (rc != SOCP_OK) break;
+            for (int k = 0; k < count; k++) hS[adv[k]] = hNew[k];
             const clk::time_point th = clk::now();
             done.clear();
             if (spec_on) {

@@ -354,6 +354,25 @@ hipError_t launch_scatter_jac(hipStream_t st, const PoolDev &pool, const int *d_
     return hipGetLastError();
 }
 
+// what the host needs to know about the problems it has just advanced: six integers each, in list order (the whole State array --
+// 96 B per problem, advanced or not -- was 400 MB per pass for 4 M chains)
+__global__ __launch_bounds__(256) void gather_status_kernel(const State *__restrict__ states, const int *__restrict__ list, int count, Status *__restrict__ out)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    const State &s = states[list[k]];
+    Status r;
+    r.req = s.req; r.iter = s.iter; r.eval_sel = s.eval_sel; r.info = s.info; r.nfev = s.nfev; r.njev = s.njev;
+    out[k] = r;
+}
+
+hipError_t launch_gather_status(hipStream_t st, const PoolDev &pool, const int *d_list, int count, Status *d_out)
+{
+    if (count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_status_kernel, dim3((count + 255) / 256), dim3(256), 0, st, pool.states, d_list, count, d_out);
+    return hipGetLastError();
+}
+
 hipError_t launch_gather_result(hipStream_t st, const PoolDev &pool, const int *d_list, int count, double *d_out)
 {
     if (count <= 0) return hipSuccess;

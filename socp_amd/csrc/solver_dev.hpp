@@ -55,6 +55,11 @@ struct State {
     double delta, xnorm, fnorm, pnorm;
 };
 
+// the part of it the lock-step engine reads back after every advance (kernels_solver.hip: gather_status_kernel)
+struct Status {
+    int req, iter, eval_sel, info, nfev, njev;
+};
+
 constexpr int kVectors = 16;
 SOCP_HD long ws_doubles(int n, int ld) { return (((long)n * ld + (long)n * (n + 1) + (long)kVectors * n) + 7) / 8 * 8; }
 SOCP_HD int ld_for(int n) { return (n + 1 + 7) / 8 * 8; }

@@ -19,6 +19,8 @@ struct PoolDev {
 int threads_for(int n);            // workgroup size of the per-problem kernels: n + 1 columns rounded up to whole waves, <= 1024
 
 // problems list[0 .. count): (re)start from X0[k][n] (k = position in the list)
+// the Status of problems list[0 .. count) -> d_out[0 .. count), in list order
+hipError_t launch_gather_status(hipStream_t st, const PoolDev &pool, const int *d_list, int count, Status *d_out);
 hipError_t launch_start(hipStream_t st, const PoolDev &pool, const int *d_list, int count, const double *d_X0);
 // advance the state machines of list[0 .. count); d_flags[k] (may be null = 0): what the pending evaluation returned.
 // factor_phase: every problem of the list has just received a Jacobian (its advance is a factorisation)
