@@ -24,13 +24,19 @@ __global__ void start_kernel(Config c, State *states, double *ws, long ws_stride
 // MAXT: the workgroup size the instantiation is built for -- without it the compiler budgets registers for 1024 threads
 // (128 VGPRs) and spills the rest of this large function to scratch.
 #ifdef SOCP_SOLVER_WAVES          // A/B: cap the registers so that this many wavefronts fit a SIMD (the compiler then spills)
-#define SOCP_SOLVER_OCCUPANCY __attribute__((amdgpu_waves_per_eu(SOCP_SOLVER_WAVES, SOCP_SOLVER_WAVES)))
+#define SOCP_SOLVER_OCCUPANCY __attribute__((amdgpu_waves_per_eu(SOCP_SOLVER_WAVES + 0 * WPE, SOCP_SOLVER_WAVES)))
 #else
-// three wavefronts per SIMD (168 registers) for the instantiations that can have them: the function sits at 163-171 registers
-// depending on what else is inlined into it, and 171 would silently cost a third of the occupancy; the compiler spills the excess
-#define SOCP_SOLVER_OCCUPANCY __attribute__((amdgpu_waves_per_eu(MAXT <= 256 ? 3 : (MAXT <= 512 ? 2 : 4))))
+// FOUR wavefronts per SIMD (128 registers) for the instantiations that can have them.  Left alone the function takes 163-171
+// registers (three wavefronts, or silently two); its trial rounds are serial chains that wait on memory, so what
+// a SIMD gets done is proportional to the wavefronts it holds, and the two dozen registers the compiler spills cost less than the
+// fourth wavefront brings -- measured (scripts/probes/solver_waves_ab.sh; 3 / 4 / 5 / 6 wavefronts): config 5, 2048 starts 0.0234 /
+// 0.0221 / 0.0222 / 0.0222 s; KD chains 4096: 0.0340 / 0.0312 / 0.0316 / 0.0320 s, 16 384: 0.096 / 0.093 / 0.091 / 0.089 s;
+// M = 9, 10 steps: 0.227 / 0.2215 / 0.225 / 0.229 s.
+// The launches that hold problems with a fresh Jacobian keep three: their order-preserving factor sweeps are bandwidth, and the
+// spills cost them 7 % (2048 x (n = 253), bit-equal solver: 0.080 -> 0.086 s with four).  WPE: 4 = trial launches, 3 = factor launches.
+#define SOCP_SOLVER_OCCUPANCY __attribute__((amdgpu_waves_per_eu(MAXT <= 256 ? WPE : (MAXT <= 512 ? 2 : 4))))
 #endif
-template <int MAXT>
+template <int MAXT, int WPE>
 __global__ __launch_bounds__(MAXT) SOCP_SOLVER_OCCUPANCY void advance_kernel(Config c, State *states, double *ws, long ws_stride, const int *__restrict__ list,
                                                        const int *__restrict__ flags, int count, int lds_matrix_doubles)
 {
@@ -214,28 +220,35 @@ hipError_t launch_advance(hipStream_t st, const PoolDev &pool, const int *d_list
         } else if (!factor_phase && threads > 64) {
             int dev = 0, cus = 0;
             if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) {
-                const long slots = (long)cus * 4 * 3;                        // wavefronts resident at this kernel's register count
+                const long slots = (long)cus * 4 * 3;                        // (three per SIMD: the rule was measured with that; with the four the
+                                                                             // kernel is now built for, 2048 x (n = 253) would get 128 threads -- 5 % slower)
                 const long waves = slots / count;                            // ... per problem, if all are to be resident
                 const int fit = (int)(waves < 1 ? 1 : waves) * 64;
                 if (fit < threads) threads = fit;
             }
         }
     }
-#define SOCP_LAUNCH_ADVANCE(MAXT)                                                                                                          \
+#define SOCP_LAUNCH_ADVANCE_W(MAXT, WPE)                                                                                                   \
     do {                                                                                                                                   \
         if (lds_bytes > 65536) {                                                                                                           \
-            const hipError_t raised = raise_lds_limit<advance_kernel<MAXT>>();                                                             \
+            const hipError_t raised = raise_lds_limit<advance_kernel<MAXT, WPE>>();                                                        \
             if (raised != hipSuccess) return raised;                                                                                       \
         }                                                                                                                                  \
-        hipLaunchKernelGGL(advance_kernel<MAXT>, dim3(grid), dim3(threads), lds_bytes, st, pool.cfg, pool.states, pool.ws, pool.ws_stride, \
-                           d_list, d_flags, count, lds_matrix);                                                                            \
+        hipLaunchKernelGGL((advance_kernel<MAXT, WPE>), dim3(grid), dim3(threads), lds_bytes, st, pool.cfg, pool.states, pool.ws,          \
+                           pool.ws_stride, d_list, d_flags, count, lds_matrix);                                                            \
+    } while (0)
+#define SOCP_LAUNCH_ADVANCE(MAXT)                                                                                                          \
+    do {                                                                                                                                   \
+        if (factor_phase) SOCP_LAUNCH_ADVANCE_W(MAXT, 3);                                                                                  \
+        else SOCP_LAUNCH_ADVANCE_W(MAXT, 4);                                                                                               \
     } while (0)
     if (threads <= 64) SOCP_LAUNCH_ADVANCE(64);
     else if (threads <= 128) SOCP_LAUNCH_ADVANCE(128);
     else if (threads <= 256) SOCP_LAUNCH_ADVANCE(256);
-    else if (threads <= 512) SOCP_LAUNCH_ADVANCE(512);
-    else SOCP_LAUNCH_ADVANCE(1024);
+    else if (threads <= 512) SOCP_LAUNCH_ADVANCE_W(512, 3);
+    else SOCP_LAUNCH_ADVANCE_W(1024, 3);
 #undef SOCP_LAUNCH_ADVANCE
+#undef SOCP_LAUNCH_ADVANCE_W
     return hipGetLastError();
 }
 
