@@ -210,10 +210,12 @@ extern "C" int socp_chains_solve_ex(socp_ctx *ctx, int P, const socp_chain_optio
                         auto ati = [&](int *a) { return a ? a + lo : nullptr; };
                         auto atd = [&](double *a) { return a ? a + lo : nullptr; };
                         std::memset(&gst[g], 0, sizeof(gst[g]));
+                        try {                                // (a group runs on its own thread: nothing may leave it but a status)
                         grc[g] = socp_chains_solve_device(gctx[g], hi - lo, opt, Z0 + (size_t)lo * n, at(params, nparams), at(goal, 1), at(time_prev, nodes),
                                                           at(x_prev, (size_t)nodes * S), at(time_goal, nodes), at(x_goal, (size_t)nodes * S),
                                                           Zout + (size_t)lo * n, info + lo, ati(nfev_last), ati(nfev_total), ati(njev_last), ati(solves),
                                                           atd(b_reached), atd(param_final), atd(fnorm), &gst[g], fast, g);
+                        } catch (...) { grc[g] = SOCP_ERR_ARG; }   // (host memory for the chains' tables: std::bad_alloc)
                     };
                     std::vector<std::thread> th;
                     for (int g = 1; g < G; g++) th.emplace_back(work, g);
