@@ -24,6 +24,13 @@ template <class M> struct has_custom_traj<M, std::void_t<decltype(M::kCustomTraj
 // initialised, then reused) scratch vector holds.
 template <class M, class = void> struct has_switching_state : std::false_type {};
 template <class M> struct has_switching_state<M, std::void_t<decltype(&M::switching_state)>> : std::true_type {};
+// optional trait switching_state_jac(P, t, j, X, Xp, Xd, dfs_dX, dfs_dXp, dfc_dX, dfc_dXp): the same hook with isJac = 1 (hybrj path,
+// shooting.cpp:1524-1538) -- the partial derivatives of the two rows of component j with respect to the state before (X) and after
+// (Xp) the node, S entries each.  var_assemble_kernel chains them through the sensitivity block and forms the free-time column the
+// way MultipleShootingFunction does for its own rows (d/dX . f(X) + d/dXp . f(Xp)).  Without it the rows of the analytic Jacobian
+// are zero: the reference's default hook is a no-op on a block its caller has just zeroed.
+template <class M, class = void> struct has_switching_state_jac : std::false_type {};
+template <class M> struct has_switching_state_jac<M, std::void_t<decltype(&M::switching_state_jac)>> : std::true_type {};
 template <class M, class = void> struct has_custom_final : std::false_type {};
 template <class M> struct has_custom_final<M, std::void_t<decltype(M::kCustomFinal)>> : std::bool_constant<M::kCustomFinal> {};
 
@@ -397,9 +404,14 @@ __device__ __forceinline__ void segment_residual(const ModelParams &P, const Pro
         for (int j = 0; j < D; j++) {
             const int row = S * (i + 1) + j;
             // FIXED pins both sides; CONTINUOUS: state and costate jumps; FREE: the model's SwitchingStateFunction
-            // (shooting.cpp:1535-1538).  Written as selects, with a branch only around the optional hook: a three-way branch here
-            // made the example plugin's residual kernel fault on gfx950 (hipcc 7.2: a scalar load through a clobbered base
-            // register), and selects are what the two-way form compiled to anyway.
+            // (shooting.cpp:1535-1538).  Written as selects -- ONE store per row through ONE pointer, a branch only around the
+            // optional hook.  As a three-way branch with an emit() pair in every arm (commit 08f2e7a) hipcc 7.2 mis-compiled the
+            // example plugin's residual kernel: the backend sank the `emit(row + D, .)` store of component 1 to the join and left
+            // its ADDRESS register undefined on the all-CONTINUOUS path (LLVM IR correct, ISA not: profiles/r05_fault_08f2e7a_isa.txt).
+            // An all-CONTINUOUS wave then stored through whatever the register held last -- component 0's X[0] - Xp[0], i.e.
+            // address 0 for a continuous iterate (the fault seen), an arbitrary address for a discontinuous one (no fault, a
+            // stray write).  scripts/isa_store_audit.py looks for that shape in every kernel's ISA; tests/test_gpu_plugin.py
+            // compares whole guarded output buffers on a discontinuous iterate.
             const int mode = mx[j];
             const double xdj = xd[j];
             double fs = 0.0, fc = 0.0;

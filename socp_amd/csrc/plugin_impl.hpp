@@ -20,6 +20,12 @@
 //       // node's desired state.  Without it those rows are zero (the reference's default hook is a no-op).
 //       __device__ static void switching_state(const socp::ModelParams &P, double t, int j, const double (&X)[S], const double (&Xp)[S],
 //                                              const double *Xd, double &f_state, double &f_costate);
+//       // OPTIONAL -- the same hook with isJac = 1 (hybrj path, shooting.cpp:1524-1538): partial derivatives of those two rows with
+//       // respect to X and Xp (arrays arrive zeroed; fill the nonzeros).  The library chains them through the sensitivity block and
+//       // forms the free-time column like MultipleShootingFunction does for its own rows.  Without it: zero rows.
+//       __device__ static void switching_state_jac(const socp::ModelParams &P, double t, int j, const double (&X)[S], const double (&Xp)[S],
+//                                                  const double *Xd, double (&dfs_dX)[S], double (&dfs_dXp)[S],
+//                                                  double (&dfc_dX)[S], double (&dfc_dXp)[S]);
 //       // OPTIONAL -- variational equations, for classes with modelOrder = 1 (hybrj; model.hpp:104-120,149-183):
 //       __device__ static double aug_rhs(const socp::ModelParams &P, double t, int e, const double *Y);
 //                 // element e of Model(t, Y, isJac = 1), Y = [X(S) ; R(S x S)], R[k][i] at Y[S (k+1) + i]  

@@ -284,26 +284,48 @@ __global__ void var_assemble_kernel(ModelParams P, ProblemDev pb, int np, const 
         for (int k = 0; k < S; k++) { Xs[k] = Xtf[k]; Xp[k] = z[index + k]; }
         Mdl::rhs(P, 0, 0, t2, Xs, fxt);
         Mdl::rhs(P, 0, 0, t2, Xp, fxp);
+        // Rows of shooting::MultipleShootingFunction with isJac = 1 (shooting.cpp:1524-1555).  Each entry is ONE store through ONE
+        // pointer with the value selected by the mode -- not a store per arm of a three-way divergent branch, the shape hipcc 7.2
+        // mis-compiled in segment_residual (integrator.hpp; profiles/r05_fault_08f2e7a_isa.txt).
+        //   FIXED      row j: dX(t2-)_j/dz_prev                 row j + D: e_j on the node's own block
+        //   CONTINUOUS row j: dX_j/dz_prev, -e_j                row j + D: dX_{j+D}/dz_prev, -e_{j+D}
+        //   FREE       the model's SwitchingStateFunction(..., isJac = 1): optional trait switching_state_jac, else zero rows
+        //              (the default hook is a no-op on a block the caller has just zeroed, shooting.cpp:1067,1535-1538)
         for (int j = 0; j < D; j++) {
-            if (mx[j] == 0) {                                                 // FIXED (shooting.cpp:1524-1533)
-                for (int c = 0; c < S; c++) {
-                    J(index + j, index - S + c) = Xtf[S * (j + 1) + c];
-                    J(index + j + D, index + c) = ident(j, c);
-                    J(index + j, index + c) = 0.0;
-                    J(index + j + D, index - S + c) = 0.0;
+            const int mode = mx[j];
+            const bool fixed = mode == 0, free_ = mode == 1;
+            double aX[S], aP[S], bX[S], bP[S];                                // FREE only: partials of the two rows
+            bool hook = false;
+            if constexpr (has_switching_state_jac<Mdl>::value) {
+                if (free_) {
+#pragma unroll
+                    for (int k = 0; k < S; k++) aX[k] = aP[k] = bX[k] = bP[k] = 0.0;
+                    Mdl::switching_state_jac(P, t2, j, Xs, Xp, pb.xnode + (i + 1) * S, aX, aP, bX, bP);
+                    hook = true;
                 }
-                if (col_t >= 0) { J(index + j, col_t) = fxt[j]; J(index + j + D, col_t) = fxp[j]; }
-            } else if (mx[j] == 1) {
-                // FREE: SwitchingStateFunction(..., isJac = 1), a no-op by default on a block the caller has just zeroed
-                // (shooting.cpp:1067,1535-1538): the rows stay zero.  (No Jacobian form of the device trait: FD path only.)
-            } else {                                                          // CONTINUOUS (:1544-1555)
-                for (int c = 0; c < S; c++) {
-                    J(index + j, index - S + c) = Xtf[S * (j + 1) + c];
-                    J(index + j, index + c) = -ident(j, c);
-                    J(index + j + D, index - S + c) = Xtf[S * (j + D + 1) + c];
-                    J(index + j + D, index + c) = -ident(j + D, c);
+            }
+            for (int c = 0; c < S; c++) {
+                double ha = 0, hb = 0, hap = 0, hbp = 0;                      // the hook's rows chained through dX(t2-)/dz_prev
+                if constexpr (has_switching_state_jac<Mdl>::value) {
+                    if (hook) {
+                        for (int k = 0; k < S; k++) { ha += aX[k] * Xtf[S * (k + 1) + c]; hb += bX[k] * Xtf[S * (k + 1) + c]; }
+                        hap = aP[c]; hbp = bP[c];
+                    }
                 }
-                if (col_t >= 0) { J(index + j, col_t) = fxt[j] - fxp[j]; J(index + j + D, col_t) = fxt[j + D] - fxp[j + D]; }
+                const double sj = Xtf[S * (j + 1) + c], sjd = Xtf[S * (j + D + 1) + c];
+                J(index + j, index - S + c) = free_ ? ha : sj;
+                J(index + j, index + c) = fixed ? 0.0 : (free_ ? hap : -ident(j, c));
+                J(index + j + D, index - S + c) = fixed ? 0.0 : (free_ ? hb : sjd);
+                J(index + j + D, index + c) = fixed ? ident(j, c) : (free_ ? hbp : -ident(j + D, c));
+            }
+            if (col_t >= 0) {
+                double ta = 0, tb = 0;                                        // the free-time column of the hook's rows
+                if constexpr (has_switching_state_jac<Mdl>::value) {
+                    if (hook)
+                        for (int k = 0; k < S; k++) { ta += aX[k] * fxt[k] + aP[k] * fxp[k]; tb += bX[k] * fxt[k] + bP[k] * fxp[k]; }
+                }
+                J(index + j, col_t) = fixed ? fxt[j] : (free_ ? ta : fxt[j] - fxp[j]);
+                J(index + j + D, col_t) = fixed ? fxp[j] : (free_ ? tb : fxt[j + D] - fxp[j + D]);
             }
         }
         if (col_t >= 0) {

@@ -56,6 +56,13 @@ struct Lqr1D {
         f_state = X[j] - Xp[j];
         f_costate = (X[j + D] - Xp[j + D]) - P.p[0] * (X[j] - Xd[j]);
     }
+    // ... and its Jacobian form (isJac = 1): the partial derivatives of the two rows above
+    __device__ static void switching_state_jac(const socp::ModelParams &P, double, int j, const double (&)[S], const double (&)[S], const double *,
+                                               double (&dfs_dX)[S], double (&dfs_dXp)[S], double (&dfc_dX)[S], double (&dfc_dXp)[S])
+    {
+        dfs_dX[j] = 1.0; dfs_dXp[j] = -1.0;
+        dfc_dX[j + D] = 1.0; dfc_dXp[j + D] = -1.0; dfc_dX[j] = -P.p[0];
+    }
     __device__ static double switching_fn(const socp::ModelParams &P, double a, double b, double t, const double (&X)[S], const double (&Xp)[S])
     {
         return hamiltonian(P, a, b, t, X) - hamiltonian(P, a, b, t, Xp);
