@@ -27,8 +27,10 @@
 // Sizes: 39 <= n <= 256 (fast_factor_applies: the strip of a panel must fit the registers of one wavefront); others keep `factor`.
 #include <algorithm>
 #include <atomic>
+#include <utility>
 
 #include "solver_launch.hpp"
+#include "wave_reduce.hpp"
 
 namespace socp {
 namespace devsolver {
@@ -120,8 +122,10 @@ __device__ __forceinline__ void strip_load(f64x4 (&S)[NCH], const double *__rest
         }
     }
 }
+// (`skip`: that many chunks at the top are not written -- rows that have left as rows of R; 0, 1 or 2, uniform)
 template <int NCH>
-__device__ __forceinline__ void strip_store(const f64x4 (&S)[NCH], double *__restrict__ A, int ld, int n, int row0, int nch, int c0, int colmax, int g, int m)
+__device__ __forceinline__ void strip_store(const f64x4 (&S)[NCH], double *__restrict__ A, int ld, int n, int row0, int nch, int c0, int colmax, int g, int m,
+                                            int skip = 0)
 {
     g = here(g); m = here(m);
     const int col = c0 + m;
@@ -130,7 +134,9 @@ __device__ __forceinline__ void strip_store(const f64x4 (&S)[NCH], double *__res
     const long step = 4L * ld;
 #pragma unroll
     for (int cc = 0; cc < NCH; cc++) {
-        if (cc + 1 < nch) {
+        if (cc < skip) {
+            p += 4 * step;
+        } else if (cc + 1 < nch) {
 #pragma unroll
             for (int r = 0; r < 4; r++) { *p = S[cc][r]; p += step; }
         } else if (cc + 1 == nch) {
@@ -514,6 +520,194 @@ __device__ __forceinline__ double panel_core(f64x4 (&S)[NCH], int np, int nch, d
     return tau_mine;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The panel in the ROW layout (round 5).  panel_core above keeps a column's four row groups in a quad of lanes, so every column
+// step costs every lane a dot product and an axpy over its 4 NCH entries PLUS the reflector read back from LDS twice (192 LDS
+// operations per column): 110 000 cycles per panel at n = 253, and the chain panel -> apply -> panel was what a problem's time was
+// made of (profiles/r05a_factor_phases.txt).  Here a lane owns ROWS: P[q][m] = entry (64 q + lane, m) of the 16-column panel, all
+// sixteen columns of a row in one lane's registers.  A column step is then
+//     x_k  = (own rows') a_T . a_k  for the columns k >= T                NQ (16 - T) multiply-adds, no data movement
+//     w_k  = wave-wide sums of the x_k, ALL OF THEM in one batched reduction (wave_reduce.hpp: 63 instructions), value k -> quad k
+//     |a_T| = sqrt(w_T);  v = a_T / |a_T| + e_T;  v . a_k = w_k / |a_T| + a_Tk  (the row-T entry: e_T's share, fetched through LDS)
+//     a_k -= tau (v . a_k) v                                               NQ (15 - T) multiply-adds, the coefficient of
+//                                                                          column k read from quad k (v_readlane)
+// -- one reduction per column instead of a norm AND a dot product, nothing read back from LDS.  The squares are summed
+// unscaled; a column whose sum leaves 1e-280 .. 1e280 (tiny / huge entries, a zero column) is rescaled by a power of two --
+// exactly -- and the step repeated (uniform branch, rare); a NaN is handed on as MINPACK's enorm does.
+template <int NCH> struct Rows { static constexpr int NQ = (NCH + 3) / 4; };
+
+// strip in the MFMA layout -> LDS tile[row][kLdV], rows counted from chunk FIRST of the strip
+template <int NCH, int FIRST>
+__device__ __forceinline__ void strip_to_tile(const f64x4 (&S)[NCH], double *tile, int lane)
+{
+    lane = here(lane);
+    double *p = tile + (lane >> 4) * kLdV + (lane & 15);
+#pragma unroll
+    for (int cc = FIRST; cc < NCH; cc++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) p[(16 * (cc - FIRST) + 4 * r) * kLdV] = S[cc][r];
+    }
+}
+// ... and back into registers, a lane per row: rows from 16 (NCH - FIRST) on are zero
+template <int NCH, int FIRST>
+__device__ __forceinline__ void tile_to_rows(double (&P)[Rows<NCH>::NQ][16], const double *tile, int lane)
+{
+    lane = here(lane);
+#pragma unroll
+    for (int q = 0; q < Rows<NCH>::NQ; q++) {
+        const int row = 64 * q + lane;
+        const bool in = row < 16 * (NCH - FIRST);
+        const double *p = tile + row * kLdV;
+#pragma unroll
+        for (int m = 0; m < 16; m++) P[q][m] = in ? p[m] : 0.0;
+    }
+}
+// the factorised panel's V for the matrix cores: tile[row][m] = v_m(row) from the diagonal down, zero above it, zero for a column
+// that is no reflector (alive bit clear)
+// FIRST = 1: the tile's rows are counted from 16 rows ABOVE the panel's first row (the second panel of a pair: the strips meet both
+// panels at one offset); those 16 rows are zero
+template <int NCH, int FIRST>
+__device__ __forceinline__ void rows_to_tile_V(const double (&P)[Rows<NCH>::NQ][16], unsigned alive, double *tile, int lane)
+{
+    lane = here(lane);
+    if (FIRST && lane < 16) {
+#pragma unroll
+        for (int m = 0; m < 16; m++) tile[lane * kLdV + m] = 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < Rows<NCH>::NQ; q++) {
+        const int row = 64 * q + lane;
+        if (row < 16 * (NCH - FIRST)) {
+            double *p = tile + (row + 16 * FIRST) * kLdV;
+#pragma unroll
+            for (int m = 0; m < 16; m++) p[m] = (((alive >> m) & 1u) && (q > 0 || row >= m)) ? P[q][m] : 0.0;
+        }
+    }
+}
+template <int NCH>
+__device__ __forceinline__ void tile_to_strip(f64x4 (&S)[NCH], const double *tile, int lane)
+{
+    lane = here(lane);
+    const double *p = tile + (lane >> 4) * kLdV + (lane & 15);
+#pragma unroll
+    for (int cc = 0; cc < NCH; cc++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) S[cc][r] = p[(16 * cc + 4 * r) * kLdV];
+    }
+}
+// rows of R from the panel's own block (strictly right of the diagonal; column n = Q^T fvec): the panel's first 16 rows are lanes 0 .. 15
+__device__ __forceinline__ void r_rows_from_rows(const double (&top)[16], double *__restrict__ rpack, double *__restrict__ qtf, int n, int j0, int lane)
+{
+    lane = here(lane);
+    const int row = j0 + lane;
+    if (lane < 16 && row < n) {
+        double *out = rpack + row_off(n, row) - row;
+#pragma unroll
+        for (int m = 1; m < 16; m++) {
+            const int col = j0 + m;
+            if (m > lane) {
+                if (col < n) out[col] = top[m];
+                else if (col == n) qtf[row] = top[m];
+            }
+        }
+    }
+}
+
+template <int NQ, int T>
+__device__ __forceinline__ double panel_dots(const double (&a)[NQ], const double (&P)[NQ][16], int lane)
+{
+    double x[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        if (k < T) { x[k] = 0.0; continue; }
+        // (k == T: the column with itself -- `a`, not P, which differs from it by the power-of-two rescaling of the rare path)
+        double s = a[0] * (k == T ? a[0] : P[0][k]);
+#pragma unroll
+        for (int q = 1; q < NQ; q++) s = __builtin_fma(a[q], k == T ? a[q] : P[q][k], s);
+        x[k] = s;
+    }
+    return reduce16(x, lane);
+}
+
+template <int NQ, int T>
+__device__ __forceinline__ void panel_step(double (&P)[NQ][16], int np, double *rowbuf, int lane, double &tau_mine, double &rdiag_mine, unsigned &alive)
+{
+    if (T >= np) return;                                                     // (uniform)
+    lane = here(lane);
+    // row T of the panel -- final since step T - 1 -- for the quads of its columns: lane T -> LDS -> lane l takes entry l >> 2
+    if (lane == T) {
+#pragma unroll
+        for (int k = T + 1; k < 16; k++) rowbuf[k] = P[0][k];
+    }
+    double a[NQ];                                                            // column T from its diagonal down
+#pragma unroll
+    for (int q = 0; q < NQ; q++) a[q] = (q == 0 && lane < T) ? 0.0 : P[q][T];
+    double w = panel_dots<NQ, T>(a, P, lane);
+    double ss = from_lane(w, 4 * T);
+    double scale = 1.0, unscale = 1.0;
+    if (!(ss > 1e-280 && ss < 1e280) && ss == ss) {
+        // (uniform, rare) a zero column, or squares outside the exponent range: a power of two brings the largest entry into [1/2, 1)
+        double amax = 0.0;
+#pragma unroll
+        for (int q = 0; q < NQ; q++) amax = fmax(amax, fabs(a[q]));
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) amax = fmax(amax, __shfl_xor(amax, off));
+        if (amax == 0.0) return;                                             // no reflector: tau = 0, diag(R) = 0, the column stays (zeros)
+        if (amax < INFINITY) {
+            int e = 0;
+            (void)frexp(amax, &e);
+            scale = ldexp(1.0, -e);
+            unscale = ldexp(1.0, e);
+#pragma unroll
+            for (int q = 0; q < NQ; q++) a[q] *= scale;
+            w = panel_dots<NQ, T>(a, P, lane);
+            ss = from_lane(w, 4 * T);
+        }
+    }
+    double ajnorm = ss * rsqrt_in_range(ss);
+    const double ajj = from_lane(P[0][T], T) * scale;
+    if (ajj < 0) ajnorm = -ajnorm;
+    const double inv = rcp_in_range(ajnorm);
+    const double tau = rcp_in_range(__builtin_fma(ajj, inv, 1.0));           // 1 / v_T, v_T in [1, 2]: ajnorm carries a(T, T)'s sign
+    if (lane == T) { tau_mine = tau; rdiag_mine = -ajnorm * unscale; }
+    alive |= 1u << T;
+    wave_lds_fence();
+    const double coef = __builtin_fma(w, inv, rowbuf[lane >> 2]) * tau;      // (v . a_k) tau in quad k (k > T)
+    wave_lds_fence();
+    double v[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) v[q] = a[q] * inv;
+    v[0] = (lane == T) ? v[0] + 1.0 : v[0];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) P[q][T] = (q == 0 && lane < T) ? P[q][T] : v[q];
+#pragma unroll
+    for (int k = T + 1; k < 16; k++) {
+        const double c = -from_lane(coef, 4 * k);
+#pragma unroll
+        for (int q = 0; q < NQ; q++) P[q][k] = __builtin_fma(c, v[q], P[q][k]);
+    }
+}
+
+template <int NQ, int... T>
+__device__ __forceinline__ void panel_steps(double (&P)[NQ][16], int np, double *rowbuf, int lane, double &tau_mine, double &rdiag_mine, unsigned &alive,
+                                            std::integer_sequence<int, T...>)
+{
+    (panel_step<NQ, T>(P, np, rowbuf, lane, tau_mine, rdiag_mine, alive), ...);
+}
+
+// Factorises the 16-column panel held in the row layout (np of its columns are reflectors): R above the diagonal and the vectors
+// from the diagonal down in P, rdiag[0 .. np) to memory, the alive mask (which columns ARE reflectors); returns tau_t in lane t.
+// `scratch`: 16 doubles of LDS (the row hand-over).
+template <int NCH>
+__device__ __forceinline__ double panel_rows(double (&P)[Rows<NCH>::NQ][16], int np, double *scratch, double *__restrict__ rdiag, int lane, unsigned &alive)
+{
+    double tau_mine = 0.0, rdiag_mine = 0.0;
+    alive = 0u;
+    panel_steps<Rows<NCH>::NQ>(P, np, scratch, lane, tau_mine, rdiag_mine, alive, std::make_integer_sequence<int, 16>());
+    if (here(lane) < np) rdiag[lane] = rdiag_mine;
+    return tau_mine;
+}
+
 // ... and the panel's T of  H_first .. H_last = I - V T V^T: G = V^T V on the matrix cores, then larft's recurrence
 // T(i, t) = -tau_t sum_{k = i}^{t - 1} T(i, k) G(k, t), T(t, t) = tau_t.  Called AFTER the strip has gone home: with the strip's
 // 4 NCH registers still live beside it the recurrence spilled a hundred registers per panel, and those round trips to scratch
@@ -591,87 +785,105 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         for (int i = tid; i < n; i += 256) A[(long)i * ld + n] = w.fvec[i];
         __syncthreads();
         prof.mark(FP_NORMS);
-        // ---- qrfac with look-ahead.  Panel 0 by wave 0; then, while panel pi goes through the trailing strips on three
-        // wavefronts, the fourth takes the strip that is the NEXT panel, applies panel pi to it and factorises it on the spot
-        // (the strip never leaves its registers between the two): the serial part hides behind the updates.
+        // ---- qrfac, TWO panels per pass over the trailing matrix (round 5; round 4 ran one panel per pass with a look-ahead wavefront:
+        // a trailing element was read and written once per 16 reflectors, 11 of the launch's 22 GB).  For the panels pp, pp + 1:
+        //   [A] one wavefront factorises panel pp (row layout, panel_rows) -> V, T into buffer 0;
+        //   [C] one wavefront takes the strip that is panel pp + 1 through panel pp and factorises it -> buffer 1 (its rows counted
+        //       from panel pp's first row: 16 zero rows on top, so one strip of registers meets both panels at the same offsets);
+        //   [E] all four wavefronts take the strips right of both panels through pp and pp + 1 in ONE load / store.
+        // The wavefronts take turns at [A] and [C] (two workgroups share a CU: their serial parts should not share a SIMD).
         const int npanels = (n + 15) >> 4;
-        if (wave == 0) {
-            f64x4 P[NCH];
-            const int np0 = n < 16 ? n : 16, nch0 = (n + 15) >> 4;
-            strip_load<NCH>(P, A, ld, n, 0, nch0, 0, n + 1, lane & 3, lane >> 2);          // (column n = fvec rides along when it falls into this strip)
-            {
-                const double nrm = strip_column_norm<NCH, true>(P);
-                if ((lane & 3) == 0 && (lane >> 2) < n) acnorm[lane >> 2] = nrm;
-            }
-            const double tau = panel_core<NCH>(P, np0, nch0, lds, rdiag, lane, prof);
-            strip_store<NCH>(P, A, ld, n, 0, nch0, 0, n + 1, lane & 3, lane >> 2);
-            r_rows_out(P[0], w.r, w.qtf, n, 0, 0, lane & 3, lane >> 2, true);
-            if (lane < np0) w.r[row_off(n, lane)] = rdiag[lane];
-            panel_T<NCH>(nch0, tau, lds, lds + 16 * NCH * kLdV, Gl, Tsave, lane);
-        }
-        prof.mark(FP_PANEL);
-        __syncthreads();
-        prof.mark(FP_PANEL_WAIT);
-        for (int pi = 0; pi < npanels; pi++) {
-            const int j0 = 16 * pi, nch = (n - j0 + 15) >> 4;
-            double *Vc = lds + (pi & 1) * kPanelDoubles, *Tc = Vc + 16 * NCH * kLdV;
-            double *Vn = lds + ((pi + 1) & 1) * kPanelDoubles, *Tn = Vn + 16 * NCH * kLdV;
-            const bool has_next = pi + 1 < npanels;
-            const int ahead = (pi + 1) & 3;                                  // the wavefront that runs ahead (they take turns: two workgroups
-                                                                             // share a CU, their serial parts should not share a SIMD)
-            if (has_next && wave == ahead) {
+        double *V0 = lds, *T0 = V0 + 16 * NCH * kLdV, *V1 = lds + kPanelDoubles, *T1 = V1 + 16 * NCH * kLdV;
+        for (int pp = 0; pp < npanels; pp += 2) {
+            const int j0 = 16 * pp, j1 = j0 + 16, nch = (n - j0 + 15) >> 4;
+            const bool two = pp + 1 < npanels;
+            const int wa = pp & 3, wb = (pp + 1) & 3;                        // (pp is even: wa in {0, 2}, wb in {1, 3})
+            if (wave == wa) {
                 f64x4 S[NCH];
-                const unsigned long long t_la = prof.stamp();
-                strip_load<NCH>(S, A, ld, n, j0, nch, j0 + 16, n + 1, g, m);
-                if (pi == 0) {
+                const int np0 = (n - j0 < 16) ? n - j0 : 16;
+                strip_load<NCH>(S, A, ld, n, j0, nch, j0, n + 1, g, m);      // (column n = fvec rides along when it falls into this strip)
+                if (pp == 0) {
                     const double nrm = strip_column_norm<NCH, false>(S);
-                    if (g == 0 && 16 + m < n) acnorm[16 + m] = nrm;
+                    if (g == 0 && m < n) acnorm[m] = nrm;
                 }
-                strip_apply<NCH>(S, nch, Vc, Tc, lane);
-                prof.add(FP_LA_APPLY, t_la);
-                const unsigned long long t_cv = prof.stamp();
-                // its first 16 rows are rows of R now (packed R / Q^T fvec); the rest is the next panel, in the panel layout.  (A keeps
-                // nothing of those rows: qform zeroes them.)
-                r_rows_out(S[0], w.r, w.qtf, n, j0, j0 + 16, g, m, false);
-                SOCP_SCHED_FENCE();
-#pragma unroll
-                for (int cc = 0; cc + 1 < NCH; cc++) {                       // chunk by chunk, in place: one strip's worth of registers, not two
-#pragma unroll
-                    for (int r = 0; r < 4; r++) S[cc][r] = to_quad_layout(S[cc + 1][r], lane);
-                    SOCP_SCHED_FENCE();
-                }
-                S[NCH - 1] = f64x4{0, 0, 0, 0};
-                const int j1 = j0 + 16, np1 = (n - j1 < 16) ? n - j1 : 16;
-                prof.add(FP_LA_CONVERT, t_cv);
-                const unsigned long long t_cols = prof.stamp();
-                const double tau = panel_core<NCH>(S, np1, nch - 1, Vn, rdiag + j1, lane, prof);
-                prof.add(FP_COLS, t_cols);
-                const unsigned long long t_st = prof.stamp();
-                strip_store<NCH>(S, A, ld, n, j1, nch - 1, j1, n + 1, lane & 3, lane >> 2);
-                r_rows_out(S[0], w.r, w.qtf, n, j1, j1, lane & 3, lane >> 2, true);
-                if (lane < np1) w.r[row_off(n, j1 + lane)] = rdiag[j1 + lane];
-                prof.add(FP_LA_STORE, t_st);
-                const unsigned long long t_T = prof.stamp();
-                panel_T<NCH>(nch - 1, tau, Vn, Tn, Gl, Tsave + 256 * (pi + 1), lane);
-                prof.add(FP_T, t_T);
-                prof.mark(FP_PANEL);
-            } else {
-                // the trailing strips: three wavefronts while one runs ahead, all four for the last panel
-                const int first = j0 + (has_next ? 32 : 16);
-                const int slot = has_next ? ((wave - ahead - 1) & 3) : wave, stride = has_next ? 48 : 64;
-                for (int c0 = first + 16 * slot; c0 <= n; c0 += stride) {
-                    f64x4 S[NCH];
-                    strip_load<NCH>(S, A, ld, n, j0, nch, c0, n + 1, g, m);
-                    if (pi == 0) {
-                        const double nrm = strip_column_norm<NCH, false>(S);
-                        if (g == 0 && c0 + m < n) acnorm[c0 + m] = nrm;
-                    }
-                    strip_apply<NCH>(S, nch, Vc, Tc, lane);
-                    r_rows_out(S[0], w.r, w.qtf, n, j0, c0, g, m, false);
-                    strip_store<NCH>(S, A, ld, n, j0, nch, c0, n + 1, g, m);
-                }
-                prof.mark(FP_TRAIL);
+                double P[Rows<NCH>::NQ][16];
+                strip_to_tile<NCH, 0>(S, V0, lane);
+                wave_lds_fence();
+                tile_to_rows<NCH, 0>(P, V0, lane);
+                wave_lds_fence();
+                unsigned alive;
+                const double tau = panel_rows<NCH>(P, np0, V0, rdiag + j0, lane, alive);
+                r_rows_from_rows(P[0], w.r, w.qtf, n, j0, lane);
+                rows_to_tile_V<NCH, 0>(P, alive, V0, lane);
+                wave_lds_fence();
+                tile_to_strip<NCH>(S, V0, lane);
+                strip_store<NCH>(S, A, ld, n, j0, nch, j0, n + 1, g, m, 0);  // (A keeps the vectors: qform reads them back)
+                if (lane < np0) w.r[row_off(n, j0 + lane)] = rdiag[j0 + lane];
+                panel_T<NCH>(nch, tau, V0, T0, Gl, Tsave + 256 * pp, lane);
             }
+            prof.mark(FP_PANEL);
+            __syncthreads();
+            prof.mark(FP_PANEL_WAIT);
+            if (two) {
+                if (wave == wb) {
+                    f64x4 S[NCH];
+                    const unsigned long long t_la = prof.stamp();
+                    strip_load<NCH>(S, A, ld, n, j0, nch, j1, n + 1, g, m);
+                    if (pp == 0) {
+                        const double nrm = strip_column_norm<NCH, false>(S);
+                        if (g == 0 && 16 + m < n) acnorm[16 + m] = nrm;
+                    }
+                    strip_apply<NCH>(S, nch, V0, T0, lane);
+                    prof.add(FP_LA_APPLY, t_la);
+                    const unsigned long long t_cv = prof.stamp();
+                    // its first 16 rows are rows of R now (packed R / Q^T fvec); the rest is panel pp + 1: through LDS (the buffer its V
+                    // will fill) into the row layout.  (A keeps nothing of those rows: qform zeroes them.)
+                    r_rows_out(S[0], w.r, w.qtf, n, j0, j1, g, m, false);
+                    SOCP_SCHED_FENCE();
+                    double P[Rows<NCH>::NQ][16];
+                    strip_to_tile<NCH, 1>(S, V1, lane);
+                    wave_lds_fence();
+                    tile_to_rows<NCH, 1>(P, V1, lane);
+                    wave_lds_fence();
+                    const int np1 = (n - j1 < 16) ? n - j1 : 16;
+                    prof.add(FP_LA_CONVERT, t_cv);
+                    const unsigned long long t_cols = prof.stamp();
+                    unsigned alive;
+                    const double tau = panel_rows<NCH>(P, np1, V1, rdiag + j1, lane, alive);
+                    prof.add(FP_COLS, t_cols);
+                    const unsigned long long t_st = prof.stamp();
+                    r_rows_from_rows(P[0], w.r, w.qtf, n, j1, lane);
+                    rows_to_tile_V<NCH, 1>(P, alive, V1, lane);
+                    wave_lds_fence();
+                    tile_to_strip<NCH>(S, V1, lane);
+                    strip_store<NCH>(S, A, ld, n, j0, nch, j1, n + 1, g, m, 1);
+                    if (lane < np1) w.r[row_off(n, j1 + lane)] = rdiag[j1 + lane];
+                    prof.add(FP_LA_STORE, t_st);
+                    const unsigned long long t_T = prof.stamp();
+                    panel_T<NCH>(nch, tau, V1, T1, Gl, Tsave + 256 * (pp + 1), lane);
+                    prof.add(FP_T, t_T);
+                }
+                prof.mark(FP_PANEL);
+                __syncthreads();
+                prof.mark(FP_PANEL_WAIT);
+            }
+            // [E] the strips right of the panel(s); their first 16 (32) rows leave as rows of R and are not written back
+            for (int c0 = j0 + (two ? 32 : 16) + 16 * wave; c0 <= n; c0 += 64) {
+                f64x4 S[NCH];
+                strip_load<NCH>(S, A, ld, n, j0, nch, c0, n + 1, g, m);
+                if (pp == 0) {
+                    const double nrm = strip_column_norm<NCH, false>(S);
+                    if (g == 0 && c0 + m < n) acnorm[c0 + m] = nrm;
+                }
+                strip_apply<NCH>(S, nch, V0, T0, lane);
+                r_rows_out(S[0], w.r, w.qtf, n, j0, c0, g, m, false);
+                if (two) {
+                    strip_apply<NCH>(S, nch, V1, T1, lane);
+                    if (NCH > 1) r_rows_out(S[NCH > 1 ? 1 : 0], w.r, w.qtf, n, j1, c0, g, m, false);
+                }
+                strip_store<NCH>(S, A, ld, n, j0, nch, c0, n + 1, g, m, two ? 2 : 1);
+            }
+            prof.mark(FP_TRAIL);
             __syncthreads();
             prof.mark(FP_TRAIL_WAIT);
         }

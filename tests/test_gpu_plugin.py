@@ -287,10 +287,22 @@ def test_switching_state_jacobian_hook_on_the_hybrj_path():
         z = rng.uniform(-1, 1, n)
         z[8:] = [0.45, 1.1][:n - 8]                                          # free node times, in order
         J = ctx.var_jacobian(z)
-        Jfd = ctx.fd_jacobian(z, ctx.residual(z), epsfcn=1e-12)
-        assert np.max(np.abs(J - Jfd)) <= 1e-5 * max(1.0, np.max(np.abs(J))), (mode_t, np.max(np.abs(J - Jfd)))
-        # closed form of the hook's rows: state row 4 = X_0(t2-) - Xp_0, costate row 6 = (X_2 - Xp_2) - g (X_0 - Xd_0)
         T = (z[8] if n > 8 else 0.5)
+        if n == 8:
+            # fixed node times: the analytic Jacobian IS the Jacobian -- forward differences of the value form
+            Jfd = ctx.fd_jacobian(z, ctx.residual(z), epsfcn=1e-12)
+            assert np.max(np.abs(J - Jfd)) <= 1e-5 * max(1.0, np.max(np.abs(J))), np.max(np.abs(J - Jfd))
+        else:
+            # a FREE node time: the reference's analytic Jacobian is not the derivative of its own residual there (only d/dt_end
+            # terms, the rows of node k get  d/dX . f(X) + d/dXp . f(Xp)  in the time column, shooting.cpp:1527-1551; the copy loop
+            # of :1070 drops the term one block further) -- the hook's rows follow the SAME convention, so they are checked against
+            # it, not against differences
+            Xe = ctx.integrate_batch(0.0, T, z[None, :4])[0]
+            fxt = ctx.eval_batch(capi.EVAL_RHS, T, Xe[None, :])[0]
+            fxp = ctx.eval_batch(capi.EVAL_RHS, T, z[None, 4:8])[0]
+            assert abs(J[4, 8] - (fxt[0] - fxp[0])) <= 1e-14 and abs(J[6, 8] - ((fxt[2] - fxp[2]) - g * fxt[0])) <= 1e-14
+            assert abs(J[5, 8] - (fxt[1] - fxp[1])) <= 1e-14 and abs(J[7, 8] - (fxt[3] - fxp[3])) <= 1e-14      # the CONTINUOUS rows beside them
+        # closed form of the hook's rows: state row 4 = X_0(t2-) - Xp_0, costate row 6 = (X_2 - Xp_2) - g (X_0 - Xd_0)
         Phi = np.array([[1, T, T ** 3 / 6, -T ** 2 / 2], [0, 1, T ** 2 / 2, -T], [0, 0, 1, 0], [0, 0, -T, 1]])
         assert np.allclose(J[4, :4], Phi[0], atol=1e-13) and np.allclose(J[4, 4:8], [-1, 0, 0, 0], atol=0)
         assert np.allclose(J[6, :4], Phi[2] - g * Phi[0], atol=1e-13) and np.allclose(J[6, 4:8], [0, 0, -1, 0], atol=0)
