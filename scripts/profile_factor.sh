@@ -42,7 +42,7 @@ PY
 unset SOCP_MEASURE_ONLY
 touch socp_amd/csrc/kernels_factor_fast.hip
 make -s -C socp_amd/csrc FACTOR_DEFS=-DSOCP_FACTOR_PROFILE > /dev/null 2>&1
-SOCP_MULTISTART_TRACE=1 SOCP_MEASURE_ONLY=fast $M 2>&1 | grep -E "clock ticks|look-ahead|kernel_ms" | cut -c1-600 > $OUT/${TAG}_factor_phases.txt; cat $OUT/${TAG}_factor_phases.txt
+SOCP_MULTISTART_TRACE=1 SOCP_MEASURE_ONLY=fast $M 2>&1 | grep -E "clock ticks|inside wave|kernel_ms" | cut -c1-600 > $OUT/${TAG}_factor_phases.txt; cat $OUT/${TAG}_factor_phases.txt
 rm -rf $OUT/pf_*
 # restore the product build (a profile build left behind would be what every later step of the same call measures)
 touch socp_amd/csrc/kernels_factor_fast.hip

@@ -702,8 +702,8 @@ extern "C" int socp_qr_factor_batch(int device, int n, int count, const double *
                                  "waiting for the panel %llu, trailing strips %llu, waiting after them %llu, R / qtf %llu, qform: panel load %llu, strips %llu, waiting %llu\n",
                          pf[0], pf[1], pf[2], pf[3], pf[4], pf[5], pf[6], pf[7], pf[8]);
         if (pf[11])
-            std::fprintf(stderr, "[socp_qr_factor_batch] inside wave 0's look-ahead panels: load + apply %llu, to the panel layout %llu, the 16 columns %llu (of which: norm %llu, "
-                                 "dot + axpy %llu), store %llu, Gram + T %llu\n", pf[9], pf[10], pf[11], pf[14], pf[15], pf[12], pf[13]);
+            std::fprintf(stderr, "[socp_qr_factor_batch] inside wave 0's panels: load (+ norms, to LDS) %llu, to the row layout %llu, the 16 columns %llu, "
+                                 "V to LDS + store %llu, Gram + T %llu\n", pf[9], pf[10], pf[11], pf[12], pf[13]);
     }
     if (rc == SOCP_OK && (Q || R || qtb || rdiag || acnorm || sing)) {
         // the workspaces come back whole, in slices of at most 256 MB, and are taken apart here

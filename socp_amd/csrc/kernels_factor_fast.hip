@@ -220,8 +220,9 @@ __device__ __forceinline__ int blocks_of(int nch) { return (nch + kBlk - 1) / kB
 // S <- (I - V X^T V^T) S for the panel in LDS: Vl[row][kLdV] (rows relative to the panel's first row, zero above the diagonal and
 // from the matrix's last row to the end of the block of chunks), Xl[16][16] row-major (X = T applies H_last .. H_first, i.e. the
 // panel's Q^T: qrfac; X = T^T applies the panel's Q: qform).  S in the MFMA layout (g = lane >> 4, m = lane & 15).
+// `lo`: chunks below it hold zeros of V (uniform): blocks wholly above chunk lo are skipped.
 template <int NCH>
-__device__ __forceinline__ void strip_apply(f64x4 (&S)[NCH], int nch, const double *Vl, const double *Xl, int lane)
+__device__ __forceinline__ void strip_apply(f64x4 (&S)[NCH], int nch, const double *Vl, const double *Xl, int lane, int lo = 0)
 {
     lane = here(lane);
     const int g = lane >> 4, m = lane & 15;
@@ -229,7 +230,7 @@ __device__ __forceinline__ void strip_apply(f64x4 (&S)[NCH], int nch, const doub
     f64x4 W = {0, 0, 0, 0};
 #pragma unroll
     for (int cb = 0; cb < NCH; cb += kBlk) {
-        if (cb < nch) {
+        if (cb < nch && cb + kBlk > lo) {
             // the block's operands first, ALL of them in flight, then the products: left to itself the compiler, short of registers,
             // reuses one register pair for every read and waits for each read before the next (an LDS round trip per operand)
             double a[4 * kBlk];
@@ -250,7 +251,7 @@ __device__ __forceinline__ void strip_apply(f64x4 (&S)[NCH], int nch, const doub
     const double *vu = Vl + m * kLdV + g;                                    // S -= V Y:  A operand V(16 cc + m, k = g + 4 r)
 #pragma unroll
     for (int cb = 0; cb < NCH; cb += kBlk) {
-        if (cb < nch) {
+        if (cb < nch && cb + kBlk > lo) {
             double a[4 * kBlk];
 #pragma unroll
             for (int q = 0; q < 4 * kBlk; q++) a[q] = vu[16 * (cb + q / 4) * kLdV + 4 * (q % 4)];
@@ -801,6 +802,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             if (wave == wa) {
                 f64x4 S[NCH];
                 const int np0 = (n - j0 < 16) ? n - j0 : 16;
+                const unsigned long long t_la = prof.stamp();
                 strip_load<NCH>(S, A, ld, n, j0, nch, j0, n + 1, g, m);      // (column n = fvec rides along when it falls into this strip)
                 if (pp == 0) {
                     const double nrm = strip_column_norm<NCH, false>(S);
@@ -808,18 +810,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
                 }
                 double P[Rows<NCH>::NQ][16];
                 strip_to_tile<NCH, 0>(S, V0, lane);
+                prof.add(FP_LA_APPLY, t_la);
+                const unsigned long long t_cv = prof.stamp();
                 wave_lds_fence();
                 tile_to_rows<NCH, 0>(P, V0, lane);
                 wave_lds_fence();
+                prof.add(FP_LA_CONVERT, t_cv);
+                const unsigned long long t_cols = prof.stamp();
                 unsigned alive;
                 const double tau = panel_rows<NCH>(P, np0, V0, rdiag + j0, lane, alive);
+                prof.add(FP_COLS, t_cols);
+                const unsigned long long t_st = prof.stamp();
                 r_rows_from_rows(P[0], w.r, w.qtf, n, j0, lane);
                 rows_to_tile_V<NCH, 0>(P, alive, V0, lane);
                 wave_lds_fence();
                 tile_to_strip<NCH>(S, V0, lane);
                 strip_store<NCH>(S, A, ld, n, j0, nch, j0, n + 1, g, m, 0);  // (A keeps the vectors: qform reads them back)
                 if (lane < np0) w.r[row_off(n, j0 + lane)] = rdiag[j0 + lane];
+                prof.add(FP_LA_STORE, t_st);
+                const unsigned long long t_T = prof.stamp();
                 panel_T<NCH>(nch, tau, V0, T0, Gl, Tsave + 256 * pp, lane);
+                prof.add(FP_T, t_T);
             }
             prof.mark(FP_PANEL);
             __syncthreads();
@@ -892,67 +903,63 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         for (int j = tid; j < n; j += 256) zero |= (rdiag[j] == 0) ? 1 : 0;
         const int sing = __syncthreads_or(zero);
         prof.mark(FP_RPACK);
-        // ---- qform: the panels backward, TWO per pass over the rows and columns they reach (a strip is read and written once per
-        // pair: half the traffic of the pass); an odd panel count leaves the last panel a pass of its own
-        int pi = npanels - 1;
-        while (pi >= 0) {
-            const bool pair = pi >= 1 && (((pi + 1) & 1) == 0 || pi != npanels - 1);      // (an odd count: the first pass is the last panel alone)
-            const int lo = pair ? pi - 1 : pi, j0 = 16 * lo, nch = (n - j0 + 15) >> 4;
-            const int np_lo = (n - j0 < 16) ? n - j0 : 16, np_hi = pair ? ((n - j0 - 16 < 16) ? n - j0 - 16 : 16) : 0;
-            double *V0 = lds, *T0 = V0 + 16 * NCH * kLdV, *V1 = lds + kPanelDoubles, *T1 = V1 + 16 * NCH * kLdV;
-            // the vectors of both panels with rows relative to the LOWER panel's first row (the upper panel's first 16 rows are zero)
-            const int nchb = blocks_of(nch) < NCH ? blocks_of(nch) : NCH;                // (rows from the matrix's end to the block's end: zeros)
-            {
-                // (all of a thread's loads first, then the LDS stores: with load and store in one loop body the loads go out one
-                // at a time, each waiting for the previous store's address arithmetic)
-                const int t = tid & 15, r0 = tid >> 4;
-                double x0[NCH], x1[NCH];
-#pragma unroll
-                for (int it = 0; it < NCH; it++) {
-                    const int rr = r0 + 16 * it, row = j0 + rr;
-                    const bool in = it < nchb && row < n;
-                    x0[it] = (in && rr >= t && t < np_lo) ? A[(long)row * ld + j0 + t] : 0.0;
-                    x1[it] = (pair && in && rr - 16 >= t && t < np_hi) ? A[(long)row * ld + j0 + 16 + t] : 0.0;
-                }
-#pragma unroll
-                for (int it = 0; it < NCH; it++) {
-                    if (it < nchb) {
-                        const int rr = r0 + 16 * it;
-                        V0[rr * kLdV + t] = x0[it];
-                        if (pair) V1[rr * kLdV + t] = x1[it];
-                    }
-                }
-            }
-            T0[(tid & 15) * 16 + (tid >> 4)] = Tsave[256 * lo + tid];                     // X = T^T
-            if (pair) T1[(tid & 15) * 16 + (tid >> 4)] = Tsave[256 * (lo + 1) + tid];
-            __syncthreads();
-            prof.mark(FP_QLOAD);
-            // the panels' own columns above the pass's first row held R: zeros of Q now
-            {
-                const int width = np_lo + np_hi;
-                for (int e = tid; e < j0 * 32; e += 256) { const int row = e >> 5, t = e & 31; if (t < width) A[(long)row * ld + j0 + t] = 0.0; }
-            }
-            for (int c0 = j0 + 16 * wave; c0 < n; c0 += 64) {
+        // ---- qform (round 5): a strip of Q STAYS in a wavefront's registers while every panel that reaches it streams through LDS.
+        // Q = H_0 ... H_last applied to the identity: the 16 columns c0 .. c0 + 15 start as identity columns and are touched by the
+        // panels p <= c0 / 16 only (a later panel acts on rows below the columns' ones), last panel first.  So a strip is never READ
+        // and is written ONCE (round 4: read and written once per pair of panels, 5 GB of the launch's 22); what is re-read instead are
+        // the panels' vectors -- from A's lower triangle, where qrfac left them -- once per ROUND of four strips (one per wavefront),
+        // double-buffered: the next panel's loads are in flight while the current one is applied.  Rounds go from the last strips to
+        // the first: a strip's store overwrites the vectors of its own panel, which only the strips from it on need.
+        {
+            const int nstrips = npanels, nch_all = (n + 15) >> 4;
+            const int t = tid & 15, r0 = tid >> 4;
+            // (rounds are counted from the LAST strip: the short round, if any, is the one of the first strips, which few panels reach)
+            for (int hi = nstrips; hi > 0; hi -= 4) {
+                const int s0 = hi >= 4 ? hi - 4 : 0;
+                const int sw = s0 + wave;                                    // this wavefront's strip
+                const bool have = sw < hi;
                 f64x4 S[NCH];
-                if (c0 == j0 || (pair && c0 == j0 + 16)) {
-                    // a panel's own columns start as columns of the identity
-                    const int gi = here(g), mi = here(m), own = (c0 == j0) ? 0 : 1, npo = own ? np_hi : np_lo;
+                {
+                    const int gi = here(g), mi = here(m);
 #pragma unroll
                     for (int cc = 0; cc < NCH; cc++) {
 #pragma unroll
-                        for (int r = 0; r < 4; r++) S[cc][r] = (cc == own && gi + 4 * r == mi && mi < npo) ? 1.0 : 0.0;
+                        for (int r = 0; r < 4; r++) S[cc][r] = (cc == sw && gi + 4 * r == mi && 16 * sw + mi < n) ? 1.0 : 0.0;
                     }
-                } else {
-                    strip_load<NCH>(S, A, ld, n, j0, nch, c0, n, g, m);
                 }
-                if (pair && c0 != j0) strip_apply<NCH>(S, nch, V1, T1, lane);           // (the lower panel's own columns are zero where the upper one acts)
-                strip_apply<NCH>(S, nch, V0, T0, lane);
-                strip_store<NCH>(S, A, ld, n, j0, nch, c0, n, g, m);
+                const int ptop = hi - 1;
+                // panel q's vectors at ABSOLUTE rows (zero above its diagonal: the strips meet every panel at one offset) and T^T
+                double xv[NCH], xt;
+                auto fetch = [&](int q) {
+                    const int jq = 16 * q, npq = (n - jq < 16) ? n - jq : 16;
+#pragma unroll
+                    for (int it = 0; it < NCH; it++) {
+                        const int row = r0 + 16 * it;
+                        xv[it] = (it < nch_all && row < n && row - jq >= t && t < npq) ? A[(long)row * ld + jq + t] : 0.0;
+                    }
+                    xt = Tsave[256 * q + tid];
+                };
+                auto deposit = [&](double *Vb, double *Tb) {
+#pragma unroll
+                    for (int it = 0; it < NCH; it++) Vb[(r0 + 16 * it) * kLdV + t] = xv[it];
+                    Tb[(tid & 15) * 16 + (tid >> 4)] = xt;                   // X = T^T
+                };
+                fetch(ptop);
+                deposit(lds, lds + 16 * NCH * kLdV);
+                __syncthreads();
+                prof.mark(FP_QLOAD);
+                for (int q = ptop; q >= 0; q--) {
+                    double *Vc = lds + ((ptop - q) & 1) * kPanelDoubles, *Tc = Vc + 16 * NCH * kLdV;
+                    double *Vn = lds + ((ptop - q + 1) & 1) * kPanelDoubles, *Tn = Vn + 16 * NCH * kLdV;
+                    if (q > 0) fetch(q - 1);
+                    if (have && q <= sw) strip_apply<NCH>(S, nch_all, Vc, Tc, lane, q);
+                    if (q > 0) deposit(Vn, Tn);
+                    prof.mark(FP_QSTRIPS);
+                    __syncthreads();
+                    prof.mark(FP_QWAIT);
+                }
+                if (have) strip_store<NCH>(S, A, ld, n, 0, nch_all, 16 * sw, n, g, m);
             }
-            prof.mark(FP_QSTRIPS);
-            __syncthreads();
-            prof.mark(FP_QWAIT);
-            pi = lo - 1;
         }
         if (tid == 0) { states[p].sing = sing ? 1 : 0; states[p].pad = 1; }
         __syncthreads();
