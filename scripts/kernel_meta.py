@@ -48,11 +48,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--all", action="store_true")
     ap.add_argument("--json")
+    ap.add_argument("--build", default=os.path.join(ROOT, "socp_amd", "_build"), help="directory with the kernels_*.o to read")
     args = ap.parse_args()
     tmp = tempfile.mkdtemp()
     rows = []
     try:
-        for obj in sorted(glob.glob(os.path.join(ROOT, "socp_amd", "_build", "kernels_*.o"))):
+        for obj in sorted(glob.glob(os.path.join(args.build, "kernels_*.o"))):
             recs = kernels_of(obj, tmp)
             names = demangle([r["name"] for r in recs])
             for r, nm in zip(recs, names):

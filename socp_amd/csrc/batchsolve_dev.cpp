@@ -300,6 +300,9 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
     if (fast_factor) {
         const char *e = std::getenv("SOCP_SOLVER_LAZY_Q");
         pool.cfg.lazy_q = e ? (e[0] == '0' ? 0 : 1) : (n >= 192 ? 1 : 0);
+        // ... and forms the back substitution's row sums in parallel (solver_dev.hpp: dogleg).  SOCP_SOLVER_FAST_SUMS=0: the serial chains.
+        const char *f = std::getenv("SOCP_SOLVER_FAST_SUMS");
+        pool.cfg.fast_sums = (f && f[0] == '0') ? 0 : 1;
     }
     const EnginePlan plan_sizes(n, P, nodes, S, stride);
     pool.ws_stride = (long)plan_sizes.ws_stride;
@@ -630,6 +633,9 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
             std::fprintf(stderr, "[socp_chains/device] solver phases, clock ticks of thread 0 summed over problems (a -DSOCP_SOLVER_PROFILE build): trial head %llu, "
                                  "Q^T w %llu, r1updt %llu, r1mpyq %llu, dogleg %llu, step tail %llu, factor %llu, Jacobian tail %llu\n",
                          pf[0], pf[1], pf[2], pf[3], pf[4], pf[5], pf[6], pf[7]);
+        if (pf[8] && !pf[11])
+            std::fprintf(stderr, "[socp_chains/device] inside the trial step: dogleg = back substitution %llu + gradient %llu + the rest (above); r1updt = first sweep %llu + second sweep (above)\n",
+                         pf[8], pf[9], pf[10]);
         if (pf[9] | pf[11])
             std::fprintf(stderr, "[socp_chains/device] inside the factor work: set-up %llu; qrfac: column ahead %llu, its norm and scaling %llu, sweep %llu; "
                                  "R, clearing %llu; qform %llu\n", pf[8], pf[9], pf[10], pf[11], pf[12], pf[13]);

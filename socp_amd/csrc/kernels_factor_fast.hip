@@ -1022,14 +1022,16 @@ hipError_t launch_factor_fast(hipStream_t st, const PoolDev &pool, const int *d_
     const int n = pool.cfg.n;
     if (!fast_factor_applies(n) || pool.cfg.ld < n + 1) return hipErrorInvalidValue;
     // the strip's register count follows the problem size: 16 rows per chunk
+    // (wavefronts per SIMD the registers are budgeted for: profiles/r05_factor_fast_wpe_ab.txt -- the 4-chunk strip is 13 % faster with
+    // four whatever it spills; 6 and 8 chunks run no slower with two, and spill 46 / 52 registers instead of 314 / 231)
 #ifndef SOCP_FACTOR_WPE_SMALL
 #define SOCP_FACTOR_WPE_SMALL 4
 #endif
 #ifndef SOCP_FACTOR_WPE_MID
-#define SOCP_FACTOR_WPE_MID 3
+#define SOCP_FACTOR_WPE_MID 2
 #endif
     if (n <= 64) return launch_nch<4, SOCP_FACTOR_WPE_SMALL>(st, pool, d_list, count);
-    if (n <= 96) return launch_nch<6, SOCP_FACTOR_WPE_SMALL>(st, pool, d_list, count);
+    if (n <= 96) return launch_nch<6, SOCP_FACTOR_WPE_MID>(st, pool, d_list, count);
     if (n <= 128) return launch_nch<8, SOCP_FACTOR_WPE_MID>(st, pool, d_list, count);
     if (n <= 192) return launch_nch<12, 2>(st, pool, d_list, count);
     return launch_nch<16, 2>(st, pool, d_list, count);

@@ -41,10 +41,16 @@ __global__ __launch_bounds__(MAXT) SOCP_SOLVER_OCCUPANCY void advance_kernel(Con
                                                        const int *__restrict__ flags, int count, int lds_matrix_doubles)
 {
     extern __shared__ double lds[];
-    BlockExec ex;
+    // rows of R fetched ahead of the serial chains (solver_dev.hpp: ring_fetch), 16 doubles per thread: its one entry of the next 16 rows
+    // where a workgroup has a thread per column, two entries of 8 rows / four of 4 where the launch shrank it (launch_advance)
+#ifndef SOCP_SOLVER_RING_ROWS
+#define SOCP_SOLVER_RING_ROWS 16
+#endif
+    using Exec = BlockExecRing<(MAXT <= 64 ? 4 : (MAXT <= 128 ? 2 : 1)), (MAXT <= 64 ? SOCP_SOLVER_RING_ROWS / 4 : (MAXT <= 128 ? SOCP_SOLVER_RING_ROWS / 2 : SOCP_SOLVER_RING_ROWS))>;
+    Exec ex;
     for (int b = blockIdx.x; b < count; b += gridDim.x) {
         const int p = list[b];
-        Machine<BlockExec> m(ex, c, states[p], ws + (long)p * ws_stride, lds);
+        Machine<Exec> m(ex, c, states[p], ws + (long)p * ws_stride, lds);
         if (lds_matrix_doubles > 0) m.fast_matrix = lds + 8 * (long)c.n;
         m.advance(flags ? flags[b] : 0);
         __syncthreads();
@@ -213,11 +219,12 @@ hipError_t launch_advance(hipStream_t st, const PoolDev &pool, const int *d_list
         // once instead of queueing behind a workgroup that mostly waits at barriers: measured 5-9 % of the solver time of
         // 4096 x (n = 85 / 127) and 2048 x (n = 253); a launch that fits keeps the full size (256 x (n = 253) is 5 % slower at 64).
         // SOCP_SOLVER_THREADS_FACTOR / SOCP_SOLVER_THREADS_TRIAL (multiples of 64) override both (A/B, tests).
+        static const bool fit_rule = [] { const char *f = std::getenv("SOCP_SOLVER_FIT"); return !(f && f[0] == '0'); }();     // (A/B: 0 = a thread per column)
         const char *e = std::getenv(factor_phase ? "SOCP_SOLVER_THREADS_FACTOR" : "SOCP_SOLVER_THREADS_TRIAL");
         const long want = e ? std::atol(e) : 0L;
         if (want >= 64 && want % 64 == 0) {
             if (want < threads) threads = (int)want;
-        } else if (!factor_phase && threads > 64) {
+        } else if (!factor_phase && threads > 64 && fit_rule) {
             int dev = 0, cus = 0;
             if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) {
                 const long slots = (long)cus * 4 * 3;                        // (three per SIMD: the rule was measured with that; with the four the
@@ -237,10 +244,17 @@ hipError_t launch_advance(hipStream_t st, const PoolDev &pool, const int *d_list
         hipLaunchKernelGGL((advance_kernel<MAXT, WPE>), dim3(grid), dim3(threads), lds_bytes, st, pool.cfg, pool.states, pool.ws,          \
                            pool.ws_stride, d_list, d_flags, count, lds_matrix);                                                            \
     } while (0)
+    // Wavefronts per SIMD the TRIAL launches are built for (profiles/r05_trial_wpe_ab.txt).  One-wavefront workgroups -- large problems
+    // whose launch was shrunk until every problem is resident: four entries of a row per thread, 16 doubles of row ring -- get 256
+    // registers (two per SIMD: a 2048-problem launch has no more wavefronts than that anyway): config 5, 2048 starts 0.0203 -> 0.0185 s
+    // against four.  The others keep round 4's four (KD chains and M = 6 sweeps 5 % faster than with two, M = 9 2 % slower).
+#ifndef SOCP_SOLVER_TRIAL_WPE
+#define SOCP_SOLVER_TRIAL_WPE(MAXT) ((MAXT) <= 64 ? 2 : 4)
+#endif
 #define SOCP_LAUNCH_ADVANCE(MAXT)                                                                                                          \
     do {                                                                                                                                   \
         if (factor_phase) SOCP_LAUNCH_ADVANCE_W(MAXT, 3);                                                                                  \
-        else SOCP_LAUNCH_ADVANCE_W(MAXT, 4);                                                                                               \
+        else SOCP_LAUNCH_ADVANCE_W(MAXT, SOCP_SOLVER_TRIAL_WPE(MAXT));                                                                     \
     } while (0)
     if (threads <= 64) SOCP_LAUNCH_ADVANCE(64);
     else if (threads <= 128) SOCP_LAUNCH_ADVANCE(128);

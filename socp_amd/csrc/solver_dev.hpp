@@ -31,6 +31,9 @@
 #else
 #define SOCP_HD inline
 #endif
+#if defined(__HIPCC__)
+#include "wave_reduce.hpp"            // wave_sum: the throughput flavour's parallel sums (Config::fast_sums)
+#endif
 
 namespace socp {
 namespace devsolver {
@@ -43,6 +46,7 @@ struct Config {
     int n, ld, maxfev, mode, analytic;
     double xtol, epsfcn, factor;
     int lazy_q = 0;    // throughput flavour: Broyden's rotations are kept as a list and Q stays as factorised (see lazy_capacity)
+    int fast_sums = 0; // throughput flavour: the back substitution's row sums are formed in parallel (dogleg), summation order free
 };
 
 // per-problem iteration state (Core of minpack.cpp)
@@ -86,6 +90,10 @@ struct Work {
 #endif
         for (int k = 0; k < 8; k++) f[k] = fb + (long)k * n;
     }
+    // Device only: the 8 n doubles behind wa4 are the fast vectors' home on the HOST (LDS holds them on the device) and free here:
+    // where the ringed loops of r1updt send the stores of lanes that own no entry of the row in hand (kRingE doubles per thread; the
+    // rings take a problem only if that fits)
+    SOCP_HD double *dump_area(int n) const { return x + 8 * (long)n; }
 };
 
 // executors: one thread of a workgroup (device) or the whole problem on one host thread (simulation)
@@ -99,12 +107,30 @@ struct BlockExec {
     // while each wavefront has a SIMD to itself -- with 14 wavefronts per problem (n = 832), or three workgroups sharing a CU,
     // the copies take each other's issue slots and the chain runs 3-4 x slower.
     __device__ bool leader() const { return tid < 64; }
+    // A hand-over through LDS alone (the values a step of a serial chain needs from their owner threads): the wavefronts meet, LDS
+    // operations are complete -- but the wave's outstanding GLOBAL loads stay in flight.  __syncthreads() also waits for those
+    // (s_waitcnt vmcnt(0)), i.e. it drains the rows of R fetched ahead of the chain (row rings, below) at every step.  A workgroup of
+    // one wavefront needs no barrier at all: its LDS operations execute in order.
+    __device__ void sync_lds() const
+    {
+        if (nt <= 64) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    // row rings (r1updt, the dogleg's back substitution): kRingE entries of a row per thread, kRingB rows in flight; 0 = none
+    static constexpr int kRingE = 0, kRingB = 0;
+};
+// the advance kernels' executor: a thread owns at most E entries of a row of R (n <= E * threads; larger problems take the plain loops)
+template <int E, int B>
+struct BlockExecRing : BlockExec {
+    static constexpr int kRingE = E, kRingB = B;
 };
 #endif
 struct SerialExec {
     int tid = 0, nt = 1;
     SOCP_HD void sync() const {}
+    SOCP_HD void sync_lds() const {}
     SOCP_HD bool leader() const { return true; }
+    static constexpr int kRingE = 0, kRingB = 0;
 };
 
 // Development aid (-DSOCP_SOLVER_PROFILE, device only): thread 0 of every workgroup adds the clock ticks between marks to
@@ -243,15 +269,29 @@ SOCP_HD double dot_run(const double *v, const double *a, long stride, int lo, in
 }
 
 // sum + a[lo] + a[lo + 1] + ... + a[hi - 1], added in that order
+// (the back substitution's chain: n - j DEPENDENT additions per step, 32 000 per trial step at n = 253, every one of them on the
+// critical path of the problem.  The entries come from LDS, and with load-then-add batches every batch paid an LDS round trip before
+// its eight additions could start -- 40 cycles per addition, 57 % of a config-5 trial round (profiles/r05n_solver_phases.txt).  The
+// next batch is therefore fetched BEFORE the current one is added: the chain then runs at the adder's own latency.)
 SOCP_HD double sum_run(const double *a, int lo, int hi, double sum)
 {
     int i = lo;
-    for (; i + kBatch <= hi; i += kBatch) {
-        double av[kBatch];
+    if (i + kBatch <= hi) {
+        double cur[kBatch];
 #pragma unroll
-        for (int u = 0; u < kBatch; u++) av[u] = a[i + u];
+        for (int u = 0; u < kBatch; u++) cur[u] = a[i + u];
+        i += kBatch;
+        for (; i + kBatch <= hi; i += kBatch) {
+            double nxt[kBatch];
 #pragma unroll
-        for (int u = 0; u < kBatch; u++) sum += av[u];
+            for (int u = 0; u < kBatch; u++) nxt[u] = a[i + u];
+#pragma unroll
+            for (int u = 0; u < kBatch; u++) sum += cur[u];
+#pragma unroll
+            for (int u = 0; u < kBatch; u++) cur[u] = nxt[u];
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; u++) sum += cur[u];
     }
     for (; i < hi; i++) sum += a[i];
     return sum;
@@ -682,11 +722,33 @@ SOCP_HD bool factor_blocked(const E &ex, int n, int ld, Work &w, double *Pn, dou
     return sing;
 }
 
+// The rows of the packed R a serial chain walks (r1updt's two sweeps, the dogleg's back substitution), fetched AHEAD of the chain.
+// Every step of those chains begins with its row of R, and left to itself each load waits for the step before it: the compiler
+// must assume that the row just stored aliases the next one, and the per-step barrier of the second sweep / the back substitution
+// drained the wave's loads (vmcnt(0)).  ~760 dependent trips to memory per trial step at n = 253, 80 % of a trial round
+// (profiles/r05j_solver_phases.txt).  A thread owns the entries i = tid, tid + nt, ... of every row (absolute ownership, above), so
+// it can hold its kRingE entries of the next kRingB rows in registers: slot b is refilled with row j -+ kRingB as soon as row j
+// has been consumed.  The ARITHMETIC is untouched -- same operations, same order -- so every flavour keeps its bits.
+// Every load and store of the ringed loops is UNCONDITIONAL -- a lane without an entry in row j loads the diagonal entry instead
+// (and ignores it), and stores to a dump slot of its own: the compiler counts outstanding memory operations per path and, where
+// paths differ, waits for the shortest count it can prove -- behind per-lane branches (first version) it drained all but the last
+// few operations at every step and the ring bought nothing.
+template <int E>
+SOCP_HD void ring_fetch(double (&slot)[E], const double *s, int n, int j, int tid, int nt)
+{
+    const double *row = s + row_off(n, j) - j;               // row[i] = s(j, i), i = j .. n - 1
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const int i = tid + e * nt;
+        slot[e] = row[(i >= j && i < n) ? i : j];
+    }
+}
+
 // minpack.cpp: dogleg; the step comes out in w.wa1.  Fast vectors: f0 = the Gauss-Newton step, f1 / f2 = the row of R in hand
 // (alternating), f3 = qtb, f4 = scaled vectors whose norm is taken, f5 = the gradient direction.  Every thread returns with
 // the step complete (synchronised).
 template <class E>
-SOCP_HD void dogleg(const E &ex, int n, Work &w, double delta)
+SOCP_HD void dogleg(const E &ex, int n, Work &w, double delta, Prof *pf = nullptr, bool fast_sums = false)
 {
     const double *r = w.r, *diag = w.diag;
     double *x = w.wa1, *xl = w.f[0], *qtb = w.f[3], *sc = w.f[4], *g = w.f[5];
@@ -694,7 +756,64 @@ SOCP_HD void dogleg(const E &ex, int n, Work &w, double delta)
     // Gauss-Newton direction by back substitution: x[j] needs every later x[i], the last computed first -- one serial chain.
     // Row j of R is brought to a fast vector by all threads at once; every thread then runs the same sum.
     long jj = (long)n * (n + 1) / 2;
-    for (int k = 1; k <= n; k++) {
+    bool ringed = false;
+    if constexpr (E::kRingE > 0) {
+        if (n <= E::kRingE * ex.nt) {
+            // the rows fetched ahead of the chain (ring_fetch, above r1updt): the sum a step runs is a chain of n - j dependent
+            // additions -- long enough to cover the next rows' trip to memory, if that trip has been started
+            ringed = true;
+            constexpr int RE = E::kRingE, RB = E::kRingB;
+            const int tid = ex.tid, nt = ex.nt;
+            double ring[RB][RE];
+#pragma unroll
+            for (int b = 0; b < RB; b++) ring_fetch<RE>(ring[b], r, n, (n - 1 - b > 0) ? n - 1 - b : 0, tid, nt);
+            for (int jb = n - 1; jb >= 0; jb -= RB) {
+#pragma unroll
+                for (int b = 0; b < RB; b++) {               // (straight-line groups: see r1updt)
+                    const bool live = jb - b >= 0;
+                    const int j = live ? jb - b : 0;
+                    const int k = n - j;
+                    if (live) jj -= k;
+                    double *row = (k & 1) ? w.f[2] : w.f[1];
+#pragma unroll
+                    for (int e = 0; e < RE; e++) {
+                        const int i = tid + e * nt;
+                        if (live && i >= j && i < n) row[i] = (i >= j + 2) ? ring[b][e] * xl[i] : ring[b][e];
+                    }
+                    ring_fetch<RE>(ring[b], r, n, (j - RB > 0) ? j - RB : 0, tid, nt);
+                    ex.sync_lds();                           // the row, qtb, and the x[j + 1] thread 0 stored before arriving here
+                    if (live && ex.leader()) {
+                        double sum = 0.0;
+#if defined(__HIP_DEVICE_COMPILE__)
+                        if (fast_sums) {
+                            // throughput flavour: the n - j - 2 products are summed by the wavefront's lanes side by side and the
+                            // partial sums by a wave-wide reduction -- ~40 instructions a step instead of a chain of n - j dependent
+                            // additions fed from LDS (32 000 of them per trial step at n = 253).  The order of the additions changes:
+                            // rounding level, this flavour only.
+                            double part = 0.0;
+                            for (int i = j + 2 + (tid & 63); i < n; i += 64) part += row[i];
+                            sum = wave_sum(part);
+                            if (j + 1 < n) sum += row[j + 1] * xl[j + 1];
+                        } else
+#endif
+                        {
+                            if (j + 1 < n) sum += row[j + 1] * xl[j + 1];
+                            sum = sum_run(row, j + 2, n, sum);
+                        }
+                        double temp = row[j];
+                        if (temp == 0) {
+                            long l = j;
+                            for (int i = 0; i <= j; i++) { temp = max_of(temp, fabs(r[l])); l += n - i - 1; }
+                            temp = kEpsMch * temp;
+                            if (temp == 0) temp = kEpsMch;
+                        }
+                        if (ex.tid == 0) xl[j] = (qtb[j] - sum) / temp;
+                    }
+                }
+            }
+        }
+    }
+    for (int k = 1; k <= n && !ringed; k++) {
         const int j = n - k;
         jj -= k;
         double *row = (k & 1) ? w.f[2] : w.f[1];            // (no run-time index into the pointer table: it would go to scratch)
@@ -721,6 +840,7 @@ SOCP_HD void dogleg(const E &ex, int n, Work &w, double delta)
         }
     }
     ex.sync();
+    if (pf) pf->mark(8, ex.tid);                             // (profile builds: the back substitution)
     SOCP_PAR_FOR(j, 0, n) sc[j] = diag[j] * xl[j];
     ex.sync();
     const double qnorm = enorm(n, sc);
@@ -736,6 +856,7 @@ SOCP_HD void dogleg(const E &ex, int n, Work &w, double delta)
         g[i] = acc / diag[i];
     }
     ex.sync();
+    if (pf) pf->mark(9, ex.tid);                             // (the gradient)
     const double gnorm = enorm(n, g);
     double sgnorm = 0;
     double alpha = delta / qnorm;
@@ -791,13 +912,105 @@ SOCP_HD void decode_rotation(double t, double &cs, double &sn)
 // MINPACK leaves the encodings in v and w themselves; here nobody may see a half-updated vector, so they go elsewhere.
 // A thread owns element i of w and column-position i of every row of s for the whole routine.
 template <class E>
-SOCP_HD bool r1updt(const E &ex, int n, Work &wk)
+SOCP_HD bool r1updt(const E &ex, int n, Work &wk, Prof *pf = nullptr)
 {
     double *s = wk.r, *w = wk.f[6], *rot = wk.f[7], *sd = wk.f[1], *rot2 = wk.f[4];
     const double *u = wk.f[5], *v = wk.f[4];
     long jj = (long)n * (n + 1) / 2 - 1;                     // the last diagonal entry
     if (ex.tid == (n - 1) % ex.nt) w[n - 1] = s[jj];
     double vn = v[n - 1];
+    if constexpr (E::kRingE > 0) {
+        if (n <= E::kRingE * ex.nt && (long)E::kRingE * ex.nt <= 8L * n) {     // (the second condition: the dump slots fit, Work::dump_area)
+            constexpr int RE = E::kRingE, RB = E::kRingB;
+            const int tid = ex.tid, nt = ex.nt;
+            double *dump = wk.dump_area(n) + (long)tid * RE;       // a lane's own dump slots (ring_fetch, above)
+            double ring[RB][RE];
+            // (a group of RB steps is straight-line code: steps beyond the last row run as no-ops -- `live` false: they load row 0 and
+            // store to the dump slots -- rather than leave the group through a branch, and every prefetch is issued, clamped to a row
+            // that exists: the compiler's count of outstanding loads is then exact on the one path there is)
+#pragma unroll
+            for (int b = 0; b < RB; b++) ring_fetch<RE>(ring[b], s, n, (n - 2 - b > 0) ? n - 2 - b : 0, tid, nt);
+            for (int jb = n - 2; jb >= 0; jb -= RB) {
+#pragma unroll
+                for (int b = 0; b < RB; b++) {
+                    const bool live = jb - b >= 0;
+                    const int j = live ? jb - b : 0;
+                    if (live) jj -= (n - j);
+                    const double vj = v[j];
+                    const bool upd = live && vj != 0;
+                    double cs = 0, sn = 0, tau = vj;
+                    if (upd) {
+                        givens(vn, vj, cs, sn, tau);
+                        vn = sn * vj + cs * vn;
+                    }
+                    if (live && tid == 0) rot[j] = tau;
+                    {
+                        // (vj == 0: no rotation -- the row stays, w[j] = 0, sd[j] = s(j, j): the same stores with the values selected)
+                        double *row = s + jj - j;
+#pragma unroll
+                        for (int e = 0; e < RE; e++) {
+                            const int i = tid + e * nt;
+                            const bool mine = live && i >= j && i < n;
+                            const double sv = ring[b][e];
+                            const double wi = (i == j) ? 0.0 : w[mine ? i : j];
+                            const double temp = upd ? cs * sv - sn * wi : sv;
+                            const double wn = upd ? sn * sv + cs * wi : wi;
+                            double *dst = mine ? row + i : dump + e;
+                            *dst = temp;
+                            if (mine) { w[i] = wn; if (i == j) sd[j] = temp; }
+                        }
+                    }
+                    ring_fetch<RE>(ring[b], s, n, (j - RB > 0) ? j - RB : 0, tid, nt);
+                }
+            }
+            SOCP_PAR_FOR(i, 0, n) w[i] += vn * u[i];
+            if (pf) pf->mark(10, ex.tid);                    // (profile builds: the first sweep)
+            bool sing = false;
+            // (the rows the first sweep has just stored: a thread reads back its own entries)
+            const int jlast = (n - 2 > 0) ? n - 2 : 0;
+#pragma unroll
+            for (int b = 0; b < RB; b++) ring_fetch<RE>(ring[b], s, n, (b < jlast) ? b : jlast, tid, nt);
+            for (int jb = 0; jb < n - 1; jb += RB) {
+#pragma unroll
+                for (int b = 0; b < RB; b++) {
+                    const bool live = jb + b < n - 1;
+                    const int j = live ? jb + b : jlast;
+                    ex.sync_lds();                           // s(j, j) and w[j] come from the thread that owns element j
+                    const double wj = w[j], sjj = sd[j];
+                    double cs = 0, sn = 0, tau = 0;
+                    const bool upd = live && wj != 0;
+                    if (upd) {
+                        givens(sjj, wj, cs, sn, tau);
+                        if (cs * sjj + sn * wj == 0) sing = true;
+                    } else if (live && sjj == 0) {
+                        sing = true;
+                    }
+                    {
+                        double *row = s + jj - j;
+#pragma unroll
+                        for (int e = 0; e < RE; e++) {
+                            const int i = tid + e * nt;
+                            const bool mine = live && i >= j && i < n;
+                            const double sv = ring[b][e], wi = w[mine ? i : j];
+                            const double temp = upd ? cs * sv + sn * wi : sv;
+                            const double wn = -sn * sv + cs * wi;
+                            double *dst = mine ? row + i : dump + e;
+                            *dst = temp;
+                            if (mine && upd && i != j) w[i] = wn;
+                        }
+                    }
+                    if (live && tid == 0) rot2[j] = (wj != 0) ? tau : wj;
+                    if (live) jj += (n - j);
+                    ring_fetch<RE>(ring[b], s, n, (j + RB < jlast) ? j + RB : jlast, tid, nt);
+                }
+            }
+            ex.sync();
+            const double last = w[n - 1];
+            if (ex.tid == 0) s[jj] = last;
+            if (last == 0) sing = true;
+            return sing;
+        }
+    }
     for (int nmj = 1; nmj <= n - 1; nmj++) {
         const int j = n - 1 - nmj;
         jj -= (n - j);
@@ -823,6 +1036,7 @@ SOCP_HD bool r1updt(const E &ex, int n, Work &wk)
         }
     }
     SOCP_PAR_FOR(i, 0, n) w[i] += vn * u[i];
+    if (pf) pf->mark(10, ex.tid);
     bool sing = false;
     for (int j = 0; j < n - 1; j++) {
         ex.sync();                                           // s(j, j) and w[j] come from the thread that owns element j
@@ -1128,7 +1342,7 @@ struct Machine {
     {
         const int n = c.n;
         prof.mark(15, ex.tid);
-        dogleg(ex, n, w, s.delta);
+        dogleg(ex, n, w, s.delta, &prof, c.fast_sums != 0);
         prof.mark(PF_DOGLEG, ex.tid);
         double *sc = w.f[0];
         SOCP_PAR_FOR(j, 0, n) {
@@ -1262,7 +1476,7 @@ struct Machine {
         }
         ex.sync();
         prof.mark(PF_QTW, ex.tid);
-        s.sing = r1updt(ex, n, w) ? 1 : 0;
+        s.sing = r1updt(ex, n, w, &prof) ? 1 : 0;
         prof.mark(PF_R1UPDT, ex.tid);
         if (lazy) {
             if (s.lazy == lazy_capacity(n)) { lazy_flush(ex, n, c.ld, w, s.lazy); s.lazy = 0; }

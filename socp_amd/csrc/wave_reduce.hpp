@@ -41,6 +41,22 @@ __device__ __forceinline__ void swap_rows(double &a, double &b)
     b = __hiloint2double(hi[1], lo[1]);
 }
 
+// one wave-wide sum, the result in every lane: four DPP stages inside the rows of 16 lanes, then the four row sums by v_readlane
+__device__ __forceinline__ double wave_sum(double x)
+{
+    x += dpp_move<0xB1>(x);                                                  // quad_perm [1, 0, 3, 2]
+    x += dpp_move<0x4E>(x);                                                  // quad_perm [2, 3, 0, 1]
+    x += dpp_move<0x141>(x);                                                 // row_half_mirror: l ^ 7
+    x += dpp_move<0x140>(x);                                                 // row_mirror: l ^ 15
+    double r[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int lo = __builtin_amdgcn_readlane(__double2loint(x), 16 * k), hi = __builtin_amdgcn_readlane(__double2hiint(x), 16 * k);
+        r[k] = __hiloint2double(hi, lo);
+    }
+    return (r[0] + r[1]) + (r[2] + r[3]);
+}
+
 __device__ __forceinline__ double reduce16(double (&x)[16], int lane)
 {
     double y[8], z[4], u[2];
