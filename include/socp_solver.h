@@ -173,7 +173,9 @@ int socp_chains_solve_ex(struct socp_ctx *ctx, int P, const socp_chain_options *
 
 /* ---- the device engine's workspace.  socp_chains_solve with the solvers on the device takes ONE device allocation and ONE pinned host
  * allocation per call (32 GB + 1.8 GB for 4 M chains of n = 14; 26 GB for 16 384 of n = 253).  They are KEPT for the next call on that
- * device instead of being returned (one pair per device, grown when a call needs more, never shrunk): returning and taking tens of GB
+ * device instead of being returned (up to FOUR pairs per device -- one per workspace slot: chain groups of one call run side by side,
+ * each on its own pair --, grown when a call needs more, never shrunk; a call can only take the pair of its own slot, so when an
+ * allocation fails the idle pairs of the device's other slots are released and it is tried once more): returning and taking tens of GB
  * costs 0.7-1 s per call on this platform -- freed device memory is cleared before it is handed out again, and an allocation that
  * follows a large free waits for that (measured: a 4.3 GB arena 756 ms after a 32 GB one was freed, 0.4 ms otherwise).  A second
  * engine call on the same device while the first is running takes private allocations.  SOCP_WORKSPACE_CACHE=0 turns the keeping

@@ -42,7 +42,7 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
 // throughput factorisation exists for size n, and the code with which it reports "could not allocate, nothing has run yet"
 double socp_chains_device_bytes(const socp_ctx *ctx, int P, const socp_chain_options *opt, bool per_chain_params, bool per_chain_bounds);
 bool socp_chains_fast_factor_applies(int n);
-double socp_workspace_reusable_device_bytes(int device);
+double socp_workspace_reusable_device_bytes(int device, int slot);
 constexpr int kDeviceEngineAllocFailed = -1000;
 using clk_t = std::chrono::steady_clock;
 
@@ -120,6 +120,15 @@ extern "C" int socp_chains_solve(socp_ctx *ctx, int P, const socp_chain_options 
                                 nullptr, solves, b_reached, param_final, fnorm, stats);
 }
 
+// how many groups of chains a device-solver call runs side by side (see the call site below)
+static int device_groups(int P, const socp_chain_options *opt)
+{
+    int G = (P >= 262144 && !opt->analytic_jac) ? 2 : 1;
+    if (const char *e = std::getenv("SOCP_CHAINS_DEVICE_GROUPS")) G = std::max(1, std::min(4, std::atoi(e)));
+    if (opt->analytic_jac || G > P) G = 1;
+    return G;
+}
+
 extern "C" int socp_chains_solve_ex(socp_ctx *ctx, int P, const socp_chain_options *opt, const double *Z0, const double *params,
                                     const double *goal, const double *time_prev, const double *x_prev, const double *time_goal,
                                     const double *x_goal, double *Zout, int *info, int *nfev_last, int *nfev_total, int *njev_last,
@@ -167,11 +176,18 @@ extern "C" int socp_chains_solve_ex(socp_ctx *ctx, int P, const socp_chain_optio
                 // own had drifted below what the arena really takes)
                 size_t free_b = 0, total_b = 0;
                 int prev = -1;
-                const double need = socp_chains_device_bytes(ctx, P, opt, params != nullptr || kind == SOCP_CHAIN_PARAM,
-                                                             kind == SOCP_CHAIN_DATA || time_goal != nullptr || x_goal != nullptr);
+                // (chain groups -- below -- each allocate their own plan, Jacobian buffer of up to 8 GiB included: the estimate is the
+                // SUM of the groups' plans, not the plan of one engine of P chains)
+                const int Gest = device_groups(P, opt);
+                double need = 0;
+                for (int g = 0; g < Gest; g++) {
+                    const int Pg = (int)((long long)P * (g + 1) / Gest) - (int)((long long)P * g / Gest);
+                    need += socp_chains_device_bytes(ctx, Pg, opt, params != nullptr || kind == SOCP_CHAIN_PARAM,
+                                                     kind == SOCP_CHAIN_DATA || time_goal != nullptr || x_goal != nullptr);
+                }
                 if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(socp_ctx_device(ctx)) != hipSuccess ||
                     hipMemGetInfo(&free_b, &total_b) != hipSuccess ||
-                    need > 0.9 * ((double)free_b + socp_workspace_reusable_device_bytes(socp_ctx_device(ctx))))
+                    need > 0.9 * ((double)free_b + socp_workspace_reusable_device_bytes(socp_ctx_device(ctx), 0)))
                     solver = SOCP_SOLVER_HOST;
                 if (prev >= 0) (void)hipSetDevice(prev);
             }
@@ -188,9 +204,7 @@ extern "C" int socp_chains_solve_ex(socp_ctx *ctx, int P, const socp_chain_optio
             // (scripts/probes/two_groups_probe.py): 5.36 -> 5.03 s; four groups no better.  A chain only ever meets its own group, so
             // its iterates are those of one call (with a round budget the ROUND in which a chain is served can differ, as it does
             // between any two batch sizes).  SOCP_CHAINS_DEVICE_GROUPS=1|2 overrides.
-            int G = (P >= 262144 && !opt->analytic_jac) ? 2 : 1;
-            if (const char *e = std::getenv("SOCP_CHAINS_DEVICE_GROUPS")) G = std::max(1, std::min(4, std::atoi(e)));
-            if (opt->analytic_jac || G > P) G = 1;
+            const int G = device_groups(P, opt);
             int rc = SOCP_OK;
             if (G == 1) {
                 rc = socp_chains_solve_device(ctx, P, opt, Z0, params, goal, time_prev, x_prev, time_goal, x_goal, Zout, info, nfev_last, nfev_total,
@@ -225,9 +239,13 @@ extern "C" int socp_chains_solve_ex(socp_ctx *ctx, int P, const socp_chain_optio
                 }
                 for (int g = 1; g < G; g++) {
                     if (!gctx[g]) continue;
-                    long long traj = 0, launches = 0;
-                    socp_ctx_counters(gctx[g], &traj, &launches);
-                    socp_ctx_add_counters(ctx, traj, launches);
+                    // (a group that ran while another could not allocate: AUTO repeats ALL chains on the host engine -- below -- and the
+                    // finished group's trajectories are then not part of the result: not counted)
+                    if (rc != kDeviceEngineAllocFailed) {
+                        long long traj = 0, launches = 0;
+                        socp_ctx_counters(gctx[g], &traj, &launches);
+                        socp_ctx_add_counters(ctx, traj, launches);
+                    }
                     socp_ctx_destroy(gctx[g]);
                 }
                 if (stats && rc == SOCP_OK) {
@@ -243,8 +261,10 @@ extern "C" int socp_chains_solve_ex(socp_ctx *ctx, int P, const socp_chain_optio
                 }
             }
             if (rc != kDeviceEngineAllocFailed) return rc;
-            // the arena did not fit after all (another process took the memory since the estimate): nothing has run.  AUTO made the
-            // choice, so AUTO takes the other engine; a caller who asked for the device solvers gets the error.
+            // the arena did not fit after all (another process took the memory since the estimate).  With one group nothing has run;
+            // with two, one group may have run to completion while the other could not allocate -- its results are overwritten by the
+            // host engine below, which repeats every chain.  AUTO made the choice, so AUTO takes the other engine; a caller who asked
+            // for the device solvers gets the error.
             (void)hipGetLastError();
             if (!automatic) return SOCP_ERR_HIP;
         }

@@ -33,6 +33,7 @@
 
 #include "chains_common.hpp"
 #include "solver_launch.hpp"
+#include "staging.hpp"
 
 namespace {
 
@@ -62,8 +63,37 @@ bool keep_workspaces()
     static const bool on = [] { const char *e = std::getenv("SOCP_WORKSPACE_CACHE"); return !(e && e[0] == '0'); }();
     return on;
 }
-hipError_t raw_alloc(void **p, size_t bytes, bool host) { return host ? hipHostMalloc(p, bytes, hipHostMallocDefault) : hipMalloc(p, bytes); }
+hipError_t raw_alloc_once(void **p, size_t bytes, bool host) { return host ? hipHostMalloc(p, bytes, hipHostMallocDefault) : hipMalloc(p, bytes); }
 void raw_free(void *p, bool host) { if (p) (void)(host ? hipHostFree(p) : hipFree(p)); }
+// the idle kept blocks of `device` (every slot nobody is using), device and pinned: freed.  Returns the bytes given back.
+double release_idle_blocks(int device)
+{
+    Workspaces &w = workspaces();
+    std::lock_guard<std::mutex> lock(w.m);
+    double freed = 0;
+    for (int host = 0; host < 2; host++)
+        for (auto &kv : host ? w.host : w.dev) {
+            KeptBlock &b = kv.second;
+            if (kv.first / kSlotsPerDevice != device || b.busy || !b.p) continue;
+            raw_free(b.p, host != 0);
+            freed += (double)b.cap;
+            b.p = nullptr; b.cap = 0;
+        }
+    return freed;
+}
+// An allocation for the engine on the CURRENT device.  A call can only take the kept block of its own slot (Arena::alloc), so the
+// idle blocks of the device's OTHER slots -- tens of GB after a two-group sweep of millions of starts -- are memory it cannot use but
+// that stands in its way: when the allocation fails they are released and it is tried once more.
+hipError_t raw_alloc(void **p, size_t bytes, bool host, int device)
+{
+    hipError_t e = raw_alloc_once(p, bytes, host);
+    if (e == hipSuccess) return e;
+    (void)hipGetLastError();
+    if (release_idle_blocks(device) <= 0) return e;
+    e = raw_alloc_once(p, bytes, host);
+    if (e != hipSuccess) (void)hipGetLastError();
+    return e;
+}
 
 // The engine's buffers: ONE device allocation and ONE pinned host allocation, carved into aligned pieces (thirty-odd separate
 // hipMalloc / hipHostMalloc calls were 5 of the 6-8 ms a call spent before its first launch).  The allocation comes from -- and goes
@@ -98,10 +128,10 @@ struct Arena {
                     // free waits for that), the other order only when both do not fit
                     void *const old = b->p;                  // (nobody else touches a busy slot; its fields change under the lock only,
                                                              // socp_workspace_cached_bytes reads them)
-                    bool ok = raw_alloc(&p, cap, host) == hipSuccess;
+                    bool ok = raw_alloc_once(&p, cap, host) == hipSuccess;
                     if (!ok) (void)hipGetLastError();
                     raw_free(old, host);
-                    if (!ok) { p = nullptr; ok = raw_alloc(&p, cap, host) == hipSuccess; }
+                    if (!ok) { p = nullptr; ok = raw_alloc(&p, cap, host, dev) == hipSuccess; }        // (with the other slots' idle blocks released if need be)
                     std::lock_guard<std::mutex> lock(w.m);
                     b->p = ok ? p : nullptr;
                     b->cap = ok ? cap : 0;
@@ -111,7 +141,7 @@ struct Arena {
                 return true;
             }
         }
-        const hipError_t e = raw_alloc(&p, cap, host);
+        const hipError_t e = raw_alloc(&p, cap, host, dev);
         base = static_cast<char *>(p);
         return e == hipSuccess;
     }
@@ -134,8 +164,26 @@ struct Piece {
     double *d() const { return static_cast<double *>(p); }
     int *i() const { return static_cast<int *>(p); }
 };
-using Pinned = Piece;
 using Dev = Piece;
+// A pinned staging buffer: its memory is reached through socp::staging::Staged only (staging.hpp) -- host() when the host is about
+// to read or write it, async_source() / async_target() when an asynchronous operation is about to be enqueued with it -- so that "the
+// host rewrote a list before the copy of its last contents had run" (round 4, commit e52cc58) cannot be written down again.
+struct HipBackend {
+    using stream_type = hipStream_t;
+    static bool synchronize(hipStream_t s) { return hipStreamSynchronize(s) == hipSuccess; }
+};
+using StreamClock = socp::staging::StreamClock<HipBackend>;
+struct Pinned {
+    Piece piece;
+    socp::staging::Staged<HipBackend> st;
+    explicit Pinned(const char *name) : st(name) {}
+    void bind(const Arena &a) { piece.bind(a); st.set_memory(piece.p); }
+    void *host() { return st.host(); }
+    double *hd() { return st.host_as<double>(); }
+    int *hi() { return st.host_as<int>(); }
+    const void *source(StreamClock &c) { return st.async_source(c); }    // an asynchronous READ of the buffer is being enqueued on c
+    void *target(StreamClock &c) { return st.async_target(c); }          // ... an asynchronous WRITE
+};
 
 // Chain lists into ascending order.  A round's request lists are read off lists that were ascending themselves, so they are a few
 // ascending runs (one per inner pass): merged in O(n) instead of sorted (4 M starts: two sorts per round were 1 s of a 22 s sweep).
@@ -221,11 +269,14 @@ extern "C" double socp_workspace_release(int device)
     return freed;
 }
 
-// device memory the engine could take on `device` beyond what hipMemGetInfo calls free: its own kept block, when not in use
-double socp_workspace_reusable_device_bytes(int device)
+// Device memory a call with workspace slot `slot` could take on `device` beyond what hipMemGetInfo calls free: the kept block of
+// ITS slot when not in use (Arena::alloc takes no other), plus -- because a failed allocation releases them (raw_alloc) -- the idle
+// blocks of the device's other slots.  Both are memory the call can really get; blocks in use by a running call are not.
+double socp_workspace_reusable_device_bytes(int device, int slot)
 {
     Workspaces &w = workspaces();
     std::lock_guard<std::mutex> lock(w.m);
+    (void)slot;                                      // (every idle block counts, whichever slot: the retry after a release reaches them all)
     double total = 0;
     for (auto &kv : w.dev)
         if (kv.first / kSlotsPerDevice == device && !kv.second.busy) total += (double)kv.second.cap;
@@ -331,8 +382,9 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
     // the most residual requests a round evaluates as FD batches: all P when forced, else what one wavefront per SIMD holds
     const int capS = !spec_on ? 0 : (speculate > 0 ? P : (int)std::min<long>(P, std::max<long>(1, (long)num_simd * 64 / ((long)(n + 1) * segs))));
     Dev dWs, dStates, dStatus, dList, dListS, dFlags, dListF, dListJ, dX, dF, dJx, dJf, dJ, dRes, dPF, dTF, dXF, dPJ, dTJ, dXJ, dSlots, dStage, dIdxA, dIdxB;
-    Pinned hIdxA, hIdxB;
-    Pinned hStatus, hList, hListS, hFlags, hListF, hListJ, hX, hRes, hPF, hTF, hXF, hPJ, hTJ, hXJ;
+    Pinned hIdxA{"hIdxA"}, hIdxB{"hIdxB"};
+    Pinned hStatus{"hStatus"}, hList{"hList"}, hListS{"hListS"}, hFlags{"hFlags"}, hListF{"hListF"}, hListJ{"hListJ"}, hX{"hX"}, hRes{"hRes"}, hPF{"hPF"},
+        hTF{"hTF"}, hXF{"hXF"}, hPJ{"hPJ"}, hTJ{"hTJ"}, hXJ{"hXJ"};
     Arena dev_arena, host_arena;
     {
         const size_t intsB = plan_sizes.intsB, parB = plan_sizes.parB, timeB = plan_sizes.timeB, nodeB = plan_sizes.nodeB;
@@ -342,12 +394,12 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
             {&dJx, rowB * P, false}, {&dJf, rowB * P, false}, {&dJ, jacB * jlaunch, false}, {&dRes, 2 * rowB * P, false},
             {&dPF, pp_params ? parB : 0, false}, {&dPJ, pp_params ? parB : 0, false}, {&dTF, pp_bound ? timeB : 0, false},
             {&dTJ, pp_bound ? timeB : 0, false}, {&dXF, pp_bound ? nodeB : 0, false}, {&dXJ, pp_bound ? nodeB : 0, false},
-            {&hStatus, sizeof(Status) * P, true}, {&hList, intsB, true}, {&hListS, intsB, true}, {&hFlags, intsB, true}, {&hListF, intsB, true},
-            {&hListJ, intsB, true}, {&hX, rowB * P, true}, {&hRes, 2 * rowB * P, true}, {&hPF, pp_params ? parB : 0, true},
-            {&hPJ, pp_params ? parB : 0, true}, {&hTF, pp_bound ? timeB : 0, true}, {&hTJ, pp_bound ? timeB : 0, true},
-            {&hXF, pp_bound ? nodeB : 0, true}, {&hXJ, pp_bound ? nodeB : 0, true},
+            {&hStatus.piece, sizeof(Status) * P, true}, {&hList.piece, intsB, true}, {&hListS.piece, intsB, true}, {&hFlags.piece, intsB, true}, {&hListF.piece, intsB, true},
+            {&hListJ.piece, intsB, true}, {&hX.piece, rowB * P, true}, {&hRes.piece, 2 * rowB * P, true}, {&hPF.piece, pp_params ? parB : 0, true},
+            {&hPJ.piece, pp_params ? parB : 0, true}, {&hTF.piece, pp_bound ? timeB : 0, true}, {&hTJ.piece, pp_bound ? timeB : 0, true},
+            {&hXF.piece, pp_bound ? nodeB : 0, true}, {&hXJ.piece, pp_bound ? nodeB : 0, true},
             {&dSlots, spec_on ? rowsB * P : 0, false}, {&dStage, spec_on ? rowsB * capS : 0, false}, {&dIdxA, spec_on ? intsB : 0, false},
-            {&dIdxB, spec_on ? intsB : 0, false}, {&hIdxA, spec_on ? intsB : 0, true}, {&hIdxB, spec_on ? intsB : 0, true}};
+            {&dIdxB, spec_on ? intsB : 0, false}, {&hIdxA.piece, spec_on ? intsB : 0, true}, {&hIdxB.piece, spec_on ? intsB : 0, true}};
         for (auto &e : plan) e.piece->plan(e.host ? host_arena : dev_arena, e.bytes);
         const double t0 = ms_since(t_begin);
         bool ok = dev_arena.alloc(false, socp_ctx_device(ctx), workspace_slot);
@@ -361,13 +413,17 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
                                 t0, 1e-6 * dev_arena.cap, t1 - t0, 1e-6 * host_arena.cap, t2 - t1, ms_since(t_begin) - t2);
         if (!ok) { (void)hipGetLastError(); return (dev_arena.base && host_arena.base) ? SOCP_ERR_HIP : kDeviceEngineAllocFailed; }
         for (auto &e : plan) e.piece->bind(e.host ? host_arena : dev_arena);
+        for (Pinned *h : {&hStatus, &hList, &hListS, &hFlags, &hListF, &hListJ, &hX, &hRes, &hPF, &hPJ, &hTF, &hTJ, &hXF, &hXJ, &hIdxA, &hIdxB}) h->bind(host_arena);
     }
+    // what the host knows about the two streams' progress (staging.hpp): every synchronise below goes through these
+    StreamClock clk_main(main_stream), clk_fs(fs);
+    auto sync_main = [&] { return clk_main.synchronize() ? hipSuccess : hipErrorUnknown; };
+    auto sync_fs = [&] { return clk_fs.synchronize() ? hipSuccess : hipErrorUnknown; };
     pool.states = static_cast<State *>(dStates.p);
     pool.ws = dWs.d();
     // what the host knows of every chain's state machine: refreshed after each advance for the chains that were advanced (the others
     // have not changed), from a compact record gathered on the device
     std::vector<Status> hS(P, Status{0, 0, 0, 0, 0, 0});
-    const Status *const hNew = static_cast<const Status *>(hStatus.p);
 
     // per chain: where its request's FD rows sit in the staging area (-1: none), what the solver's iteration counter and the kind of
     // the request were when they were staged, and for which iteration counter the rows in its slot are the rows at x (-1: none).
@@ -390,17 +446,18 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
         // its OWN list buffers: the copy below is asynchronous and the advance loop refills hList right after this returns -- with
         // the same chains when nothing else is waiting for an advance, but with cached-Jacobian chains in front of them when the
         // speculative rows are on (found in round 4: continuation chains restarted from the wrong list, iterates changed)
-        std::memcpy(hListS.p, list.data(), sizeof(int) * list.size());
-        hip_ok(hipMemcpyAsync(dListS.p, hListS.p, sizeof(int) * list.size(), hipMemcpyHostToDevice, main_stream));
+        std::memcpy(hListS.host(), list.data(), sizeof(int) * list.size());
+        hip_ok(hipMemcpyAsync(dListS.p, hListS.source(clk_main), sizeof(int) * list.size(), hipMemcpyHostToDevice, main_stream));
         // the start kernel reads the rows straight from the pinned buffer (it is mapped into the device's address space): a
         // hipMemcpyAsync of these 4 MB held the calling thread for 7 ms at the first start of 4096 chains.  hX is not written
-        // again before the next stream synchronise.
-        hip_ok(socp::devsolver::launch_start(main_stream, pool, dListS.i(), (int)list.size(), hX.d()));
+        // again before the next stream synchronise (Staged: a host access before that would be caught).
+        hip_ok(socp::devsolver::launch_start(main_stream, pool, dListS.i(), (int)list.size(), static_cast<const double *>(hX.source(clk_main))));
     };
 
     {
         std::vector<int> all(P);
-        for (int p = 0; p < P; p++) { all[p] = p; std::memcpy(hX.d() + (size_t)p * n, ch[p].committed.data(), rowB); }
+        double *const x0 = hX.hd();
+        for (int p = 0; p < P; p++) { all[p] = p; std::memcpy(x0 + (size_t)p * n, ch[p].committed.data(), rowB); }
         hip_ok(hipMemsetAsync(dStates.p, 0, sizeof(State) * P, main_stream));
         start_chains(all);
         adv = all;
@@ -415,10 +472,10 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
         while (!adv.empty() && rc == SOCP_OK) {
             const clk::time_point ta = clk::now();
             const int count = (int)adv.size();
-            std::memcpy(hList.p, adv.data(), sizeof(int) * count);
-            std::memcpy(hFlags.p, advflag.data(), sizeof(int) * count);
-            hip_ok(hipMemcpyAsync(dList.p, hList.p, sizeof(int) * count, hipMemcpyHostToDevice, main_stream));
-            hip_ok(hipMemcpyAsync(dFlags.p, hFlags.p, sizeof(int) * count, hipMemcpyHostToDevice, main_stream));
+            std::memcpy(hList.host(), adv.data(), sizeof(int) * count);
+            std::memcpy(hFlags.host(), advflag.data(), sizeof(int) * count);
+            hip_ok(hipMemcpyAsync(dList.p, hList.source(clk_main), sizeof(int) * count, hipMemcpyHostToDevice, main_stream));
+            hip_ok(hipMemcpyAsync(dFlags.p, hFlags.source(clk_main), sizeof(int) * count, hipMemcpyHostToDevice, main_stream));
             // the chains that have just received a Jacobian come first in the list (adv_jac of them) and go in their own launch
             if (adv_jac > 0 && fast_factor) hip_ok(socp::devsolver::launch_factor_fast(main_stream, pool, dList.i(), adv_jac));
             else if (adv_jac > 0 && blocked_factor) hip_ok(socp::devsolver::launch_factor(main_stream, pool, dList.i(), adv_jac));
@@ -426,10 +483,11 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
             hip_ok(socp::devsolver::launch_advance(main_stream, pool, dList.i() + adv_jac, count - adv_jac, dFlags.i() + adv_jac, false));
             adv_jac = 0;
             hip_ok(socp::devsolver::launch_gather_status(main_stream, pool, dList.i(), count, static_cast<Status *>(dStatus.p)));
-            hip_ok(hipMemcpyAsync(hStatus.p, dStatus.p, sizeof(Status) * count, hipMemcpyDeviceToHost, main_stream));
-            hip_ok(hipStreamSynchronize(main_stream));
+            hip_ok(hipMemcpyAsync(hStatus.target(clk_main), dStatus.p, sizeof(Status) * count, hipMemcpyDeviceToHost, main_stream));
+            hip_ok(sync_main());
             t_adv += ms_since(ta);
             if (rc != SOCP_OK) break;
+            const Status *const hNew = static_cast<const Status *>(hStatus.host());
             for (int k = 0; k < count; k++) hS[adv[k]] = hNew[k];
             const clk::time_point th = clk::now();
             done.clear();
@@ -444,11 +502,12 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
                     else if (!live) slot_iter[p] = -1;
                 }
                 if (!accepted.empty()) {
-                    for (size_t k = 0; k < accepted.size(); k++) { hIdxA.i()[k] = stage_idx[accepted[k]]; hIdxB.i()[k] = accepted[k]; }
-                    hip_ok(hipMemcpyAsync(dIdxA.p, hIdxA.p, sizeof(int) * accepted.size(), hipMemcpyHostToDevice, main_stream));
-                    hip_ok(hipMemcpyAsync(dIdxB.p, hIdxB.p, sizeof(int) * accepted.size(), hipMemcpyHostToDevice, main_stream));
+                    int *const ia = hIdxA.hi(), *const ib = hIdxB.hi();
+                    for (size_t k = 0; k < accepted.size(); k++) { ia[k] = stage_idx[accepted[k]]; ib[k] = accepted[k]; }
+                    hip_ok(hipMemcpyAsync(dIdxA.p, hIdxA.source(clk_main), sizeof(int) * accepted.size(), hipMemcpyHostToDevice, main_stream));
+                    hip_ok(hipMemcpyAsync(dIdxB.p, hIdxB.source(clk_main), sizeof(int) * accepted.size(), hipMemcpyHostToDevice, main_stream));
                     hip_ok(socp::devsolver::launch_copy_blocks(main_stream, dStage.d(), dIdxA.i(), dSlots.d(), dIdxB.i(), (int)accepted.size(), rowsLen));
-                    hip_ok(hipStreamSynchronize(main_stream));       // (the index buffers are reused below)
+                    hip_ok(sync_main());                             // (the index buffers are reused below)
                     for (int p : accepted) slot_iter[p] = hS[p].iter;
                 }
                 for (int p : adv) stage_idx[p] = -1;                 // the staging area is about to be reused
@@ -470,14 +529,14 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
                 const int chunk = std::max(1, std::min(capS, jlaunch));
                 for (size_t j0 = 0; j0 < reqJc.size() && rc == SOCP_OK; j0 += (size_t)chunk) {
                     const int kc = (int)std::min<size_t>((size_t)chunk, reqJc.size() - j0);
-                    std::memcpy(hIdxA.p, reqJc.data() + j0, sizeof(int) * kc);
-                    hip_ok(hipMemcpyAsync(dIdxA.p, hIdxA.p, sizeof(int) * kc, hipMemcpyHostToDevice, main_stream));
+                    std::memcpy(hIdxA.host(), reqJc.data() + j0, sizeof(int) * kc);
+                    hip_ok(hipMemcpyAsync(dIdxA.p, hIdxA.source(clk_main), sizeof(int) * kc, hipMemcpyHostToDevice, main_stream));
                     hip_ok(socp::devsolver::launch_copy_blocks(main_stream, dSlots.d(), dIdxA.i(), dStage.d(), nullptr, kc, rowsLen));
                     hip_ok(socp::devsolver::launch_gather_jac(main_stream, pool, dIdxA.i(), kc, dJx.d(), dJf.d()));
                     const int r = socp_fd_diff_dev(ctx, kc, dJx.d(), opt->epsfcn, dStage.d(), dJ.d());
                     if (r != SOCP_OK) { rc = r; break; }
                     hip_ok(socp::devsolver::launch_scatter_jac(main_stream, pool, dIdxA.i(), kc, dJ.d()));
-                    hip_ok(hipStreamSynchronize(main_stream));       // (dIdxA is rewritten by the next chunk / the next pass)
+                    hip_ok(sync_main());                             // (dIdxA is rewritten by the next chunk / the next pass)
                 }
                 jac_from_cache += (long long)reqJc.size();
                 adv = reqJc;
@@ -486,22 +545,24 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
             }
             if (!done.empty()) {
                 // results of the solves that ended: x and fvec of those chains, then the homotopy logic on the host
-                std::memcpy(hList.p, done.data(), sizeof(int) * done.size());
-                hip_ok(hipMemcpyAsync(dList.p, hList.p, sizeof(int) * done.size(), hipMemcpyHostToDevice, main_stream));
+                std::memcpy(hList.host(), done.data(), sizeof(int) * done.size());
+                hip_ok(hipMemcpyAsync(dList.p, hList.source(clk_main), sizeof(int) * done.size(), hipMemcpyHostToDevice, main_stream));
                 hip_ok(socp::devsolver::launch_gather_result(main_stream, pool, dList.i(), (int)done.size(), dRes.d()));
-                hip_ok(hipMemcpyAsync(hRes.p, dRes.p, 2 * rowB * done.size(), hipMemcpyDeviceToHost, main_stream));
-                hip_ok(hipStreamSynchronize(main_stream));
+                hip_ok(hipMemcpyAsync(hRes.target(clk_main), dRes.p, 2 * rowB * done.size(), hipMemcpyDeviceToHost, main_stream));
+                hip_ok(sync_main());
                 if (rc != SOCP_OK) break;
                 restart.clear();
                 std::vector<double> next;
+                const double *const res = hRes.hd();
+                double *const x0 = hX.hd();
                 for (size_t k = 0; k < done.size(); k++) {
                     const int p = done[k];
-                    const double *x = hRes.d() + 2 * (size_t)n * k, *f = x + n;
+                    const double *x = res + 2 * (size_t)n * k, *f = x + n;
                     double ss = 0;
                     for (int i = 0; i < n; i++) ss += f[i] * f[i];
                     ch[p].fnorm = std::sqrt(ss);
                     if (socp::chains::after_solve(*opt, blk, p, ch[p], x, n, hS[p].info, hS[p].nfev, hS[p].njev, next)) {
-                        std::memcpy(hX.d() + (size_t)restart.size() * n, next.data(), rowB);
+                        std::memcpy(x0 + (size_t)restart.size() * n, next.data(), rowB);
                         restart.push_back(p);
                     }
                 }
@@ -533,13 +594,16 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
         const clk::time_point te = clk::now();
         // ---- residual requests: stream fs ------------------------------------------------------------------------------------
         if (kF) {
-            std::memcpy(hListF.p, reqF.data(), sizeof(int) * kF);
-            for (int k = 0; k < kF; k++) blk.stage(reqF[k], k, hPF.d(), hTF.d(), hXF.d());
-            hip_ok(hipMemcpyAsync(dListF.p, hListF.p, sizeof(int) * kF, hipMemcpyHostToDevice, fs));
-            if (pp_params) hip_ok(hipMemcpyAsync(dPF.p, hPF.p, sizeof(double) * stride * kF, hipMemcpyHostToDevice, fs));
+            std::memcpy(hListF.host(), reqF.data(), sizeof(int) * kF);
+            {
+                double *const pf = hPF.hd(), *const tf = hTF.hd(), *const xf = hXF.hd();
+                for (int k = 0; k < kF; k++) blk.stage(reqF[k], k, pf, tf, xf);
+            }
+            hip_ok(hipMemcpyAsync(dListF.p, hListF.source(clk_fs), sizeof(int) * kF, hipMemcpyHostToDevice, fs));
+            if (pp_params) hip_ok(hipMemcpyAsync(dPF.p, hPF.source(clk_fs), sizeof(double) * stride * kF, hipMemcpyHostToDevice, fs));
             if (pp_bound) {
-                hip_ok(hipMemcpyAsync(dTF.p, hTF.p, sizeof(double) * nodes * kF, hipMemcpyHostToDevice, fs));
-                hip_ok(hipMemcpyAsync(dXF.p, hXF.p, sizeof(double) * nodes * S * kF, hipMemcpyHostToDevice, fs));
+                hip_ok(hipMemcpyAsync(dTF.p, hTF.source(clk_fs), sizeof(double) * nodes * kF, hipMemcpyHostToDevice, fs));
+                hip_ok(hipMemcpyAsync(dXF.p, hXF.source(clk_fs), sizeof(double) * nodes * S * kF, hipMemcpyHostToDevice, fs));
             }
             hip_ok(socp::devsolver::launch_gather_eval(fs, pool, dListF.i(), kF, dX.d()));
             // all of them as whole forward-difference batches when they fit the idle SIMDs (one wavefront per SIMD keeps the round at
@@ -567,13 +631,16 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
         }
         // ---- Jacobian requests: the context's stream, in passes of jlaunch -----------------------------------------------------
         if (kJ) {
-            std::memcpy(hListJ.p, reqJ.data(), sizeof(int) * kJ);
-            for (int k = 0; k < kJ; k++) blk.stage(reqJ[k], k, hPJ.d(), hTJ.d(), hXJ.d());
-            hip_ok(hipMemcpyAsync(dListJ.p, hListJ.p, sizeof(int) * kJ, hipMemcpyHostToDevice, main_stream));
-            if (pp_params) hip_ok(hipMemcpyAsync(dPJ.p, hPJ.p, sizeof(double) * stride * kJ, hipMemcpyHostToDevice, main_stream));
+            std::memcpy(hListJ.host(), reqJ.data(), sizeof(int) * kJ);
+            {
+                double *const pj = hPJ.hd(), *const tj = hTJ.hd(), *const xj = hXJ.hd();
+                for (int k = 0; k < kJ; k++) blk.stage(reqJ[k], k, pj, tj, xj);
+            }
+            hip_ok(hipMemcpyAsync(dListJ.p, hListJ.source(clk_main), sizeof(int) * kJ, hipMemcpyHostToDevice, main_stream));
+            if (pp_params) hip_ok(hipMemcpyAsync(dPJ.p, hPJ.source(clk_main), sizeof(double) * stride * kJ, hipMemcpyHostToDevice, main_stream));
             if (pp_bound) {
-                hip_ok(hipMemcpyAsync(dTJ.p, hTJ.p, sizeof(double) * nodes * kJ, hipMemcpyHostToDevice, main_stream));
-                hip_ok(hipMemcpyAsync(dXJ.p, hXJ.p, sizeof(double) * nodes * S * kJ, hipMemcpyHostToDevice, main_stream));
+                hip_ok(hipMemcpyAsync(dTJ.p, hTJ.source(clk_main), sizeof(double) * nodes * kJ, hipMemcpyHostToDevice, main_stream));
+                hip_ok(hipMemcpyAsync(dXJ.p, hXJ.source(clk_main), sizeof(double) * nodes * S * kJ, hipMemcpyHostToDevice, main_stream));
             }
             hip_ok(socp::devsolver::launch_gather_jac(main_stream, pool, dListJ.i(), kJ, dJx.d(), dJf.d()));
             for (int j0 = 0; j0 < kJ && rc == SOCP_OK; j0 += jlaunch) {
@@ -589,8 +656,8 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
             jac_launched += kJ;
         }
         if (rc != SOCP_OK) break;
-        hip_ok(hipStreamSynchronize(fs));
-        hip_ok(hipStreamSynchronize(main_stream));
+        hip_ok(sync_fs());
+        hip_ok(sync_main());
         t_eval += ms_since(te);
         adv = reqJ;
         adv.insert(adv.end(), reqF.begin(), reqF.end());
@@ -617,6 +684,9 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
             if (fnorm) fnorm[p] = c.fnorm;
         }
     }
+    if (clk_main.forced_syncs + clk_fs.forced_syncs)
+        std::fprintf(stderr, "[socp_chains/device] WARNING: %llu host accesses to pinned staging buffers had to synchronise a stream first (staging.hpp): an ordering the "
+                             "engine should have by construction is missing\n", clk_main.forced_syncs + clk_fs.forced_syncs);
     if (trace && round_limit_hit) std::fprintf(stderr, "[socp_chains/device] round limit %d reached: the chains still solving were stopped\n", opt->max_rounds);
     if (trace) std::fprintf(stderr, "[socp_chains/device] first start of the chains %.2f ms, rounds %.2f ms (of which outside the three timers %.2f ms), after the last round %.2f ms\n",
                             t_pre, std::chrono::duration<double, std::milli>(t_loop_end - t_loop_begin).count(),

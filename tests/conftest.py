@@ -11,6 +11,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the device engine's pinned staging buffers in STRICT mode for the whole suite (socp_amd/csrc/staging.hpp): a host access to a
+    # buffer whose asynchronous operation has not been synchronised aborts the process, naming the buffer -- instead of being
+    # repaired by a forced synchronise the way a production call would repair it
+    os.environ.setdefault("SOCP_STAGING_STRICT", "1")
 
 
 @pytest.fixture(scope="session", autouse=True)
