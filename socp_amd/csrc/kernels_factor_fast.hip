@@ -1014,7 +1014,9 @@ hipError_t read_factor_profile(unsigned long long out[16], bool reset)
 // n <= 256: a panel's strip (n rows x 16 columns) lives in the registers of one wavefront; the T factors of the panels
 // (256 doubles each) are kept in the workspace's spare n (n + 1) / 2 doubles until qform, which they fit from n = 39 on
 // (n = 33 .. 38 excepted) -- below that the order-preserving kernel is fast anyway.
-bool fast_factor_applies(int n) { return n >= 1 && n <= 256 && (long)n * (n + 1) / 2 >= 256L * ((n + 15) / 16); }
+// (n = 32 would pass the storage test as well; it is refused so that the rule is the documented range, every size of which is
+// under test -- tests/test_gpu_factor_fast.py)
+bool fast_factor_applies(int n) { return n >= 39 && n <= 256 && (long)n * (n + 1) / 2 >= 256L * ((n + 15) / 16); }
 
 hipError_t launch_factor_fast(hipStream_t st, const PoolDev &pool, const int *d_list, int count)
 {

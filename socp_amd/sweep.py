@@ -132,6 +132,16 @@ def goddard_north_star_128_problem(ctx, M=9):
     return n, z, mode_t, mode_x, tn, X
 
 
+def single_tensor_gather(dist):
+    """Whether the gather runs as all_gather_into_tensor: the function exists in this torch build and the backend implements it (nccl =
+    RCCL does; gloo does from torch 2.x on CPU tensors; SOCP_SWEEP_GATHER=list forces the list form).  The same answer on every rank."""
+    if os.environ.get("SOCP_SWEEP_GATHER") == "list":
+        return False
+    if not hasattr(dist, "all_gather_into_tensor"):
+        return False
+    return dist.get_backend() in ("nccl", "gloo")
+
+
 def run_sweep(Z0, solve_local, dist=None, device=None):
     """Shard the rows of Z0 over the ranks, solve, gather.  `solve_local(Zblock)` returns a dict with
     z [k][n], info [k], nfev [k], fnorm [k].  Returns (table [P][n+3] in start order, local dict)."""
@@ -151,10 +161,14 @@ def run_sweep(Z0, solve_local, dist=None, device=None):
     buf[:hi - lo] = torch.from_numpy(rec).to(buf.device)
     # ONE collective into ONE tensor and one copy back (a list of per-rank tensors costs a device-to-host copy and a concatenation
     # per rank: 0.2 s of a 3 s sweep at 4 M starts on 8 ranks)
+    # The FORM of the collective is chosen before anything is communicated, from facts every rank shares (the torch build and the
+    # process group's backend) -- never by catching an error of the collective itself: an error raised on one rank only (a timeout, an
+    # out-of-memory condition) would send that rank into a different collective than its peers, and the job would hang.
+    # Communication errors propagate.
     full = torch.empty((world * kmax, n + 3), dtype=torch.float64, device=buf.device)
-    try:
+    if single_tensor_gather(dist):
         dist.all_gather_into_tensor(full, buf)
-    except (RuntimeError, NotImplementedError, AttributeError):      # a backend without the single-tensor form
+    else:
         parts = [torch.empty_like(buf) for _ in range(world)]
         dist.all_gather(parts, buf)
         full = torch.cat(parts)

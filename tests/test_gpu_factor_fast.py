@@ -71,7 +71,7 @@ def test_fast_factor_special_columns():
 
 def test_fast_factor_refuses_sizes_it_is_not_built_for():
     from socp_amd import capi
-    for n in (14, 33, 257):
+    for n in (14, 32, 33, 38, 257):
         J, b = _problems(n, 1, n)
         with pytest.raises(RuntimeError):
             capi.qr_factor_batch(J, b, flavour=capi.FACTOR_FAST)

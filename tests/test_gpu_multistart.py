@@ -70,10 +70,11 @@ def test_multiple_shooting_sweep_lands_on_the_cpu_solution(variant):
     ctx.close()
 
 
-@pytest.mark.parametrize("mode,count", [("devices", 1), ("ranks", 2), ("ranks", 3), ("ranksdev", 2)])
+@pytest.mark.parametrize("mode,count", [("devices", 1), ("ranks", 2), ("ranks", 3), ("ranksdev", 2), ("ranks", 8)])
 def test_cpp_sweep_entry_points(tmp_path, mode, count):
     """The C++ multi-GPU entry points (include/socp_solver.h) driven by a C++ program with no Python in it
-    (tests/cpp/sweep_flow.cpp): socp_sweep_solve with one device, and socp_sweep_solve_rank with 2 / 3 ranks emulated by threads
+    (tests/cpp/sweep_flow.cpp): socp_sweep_solve with one device, and socp_sweep_solve_rank with 2 / 3 / 8 ranks (8 = the driver's job:
+    an odd total of 37 starts in blocks of 5 and 4) emulated by threads
     that gather through a user collective.  Every start's record equals the one the single-context engine returns, bit for bit,
     in start order, whatever the sharding."""
     import json

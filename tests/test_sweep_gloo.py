@@ -34,10 +34,12 @@ def _oracle_solver(step_nbr):
     return solve
 
 
-def _worker(rank, world, port, P, out_dir):
+def _worker(rank, world, port, P, out_dir, gather="tensor"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    if gather == "list":
+        os.environ["SOCP_SWEEP_GATHER"] = "list"
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     from socp_amd import sweep
     Z0 = sweep.goddard_starts(P, 1e-3)
@@ -86,3 +88,40 @@ def test_two_rank_sweep_matches_single_process(tmp_path, built):
     single, _ = sweep.run_sweep(sweep.goddard_starts(P, 1e-3), _oracle_solver(20), None)
     assert np.array_equal(single, t0)                                 # same records, in start order
     assert np.all(t0[:, -2] == 1)                                     # eps = 1e-3 is inside the basin
+
+
+@pytest.mark.parametrize("gather", ["tensor", "list"])
+def test_eight_rank_sweep_with_an_odd_start_count(tmp_path, built, gather):
+    """the shape of the driver's 8-GPU job, rehearsed where eight ranks can run -- on the CPU (a one-GPU box admits six
+    processes on its card): world_size 8, an odd total of 11 starts (blocks of 2, 2, 2, 1, 1, 1, 1, 1: shorter than the padded
+    gather record), one collective, every rank ends with the same table in start order, equal to a single process's.  Both forms of
+    the gather (the form is chosen BEFORE communicating, from facts every rank shares -- here forced through the
+    environment to cover the list form too)."""
+    P, world = 11, 8
+    mp.spawn(_worker, args=(world, 29641 if gather == "tensor" else 29643, P, str(tmp_path), gather), nprocs=world, join=True)
+    tables = [np.load(tmp_path / ("table_%d.npy" % r)) for r in range(world)]
+    assert all(np.array_equal(t, tables[0]) for t in tables) and tables[0].shape == (P, 17)
+    assert [int(np.load(tmp_path / ("count_%d.npy" % r))[0]) for r in range(world)] == [2, 2, 2, 1, 1, 1, 1, 1]
+    from socp_amd import sweep
+    single, _ = sweep.run_sweep(sweep.goddard_starts(P, 1e-3), _oracle_solver(20), None)
+    assert np.array_equal(single, tables[0])
+
+
+def test_the_gather_form_is_decided_without_communicating():
+    """The single-tensor / list decision of run_sweep reads the torch build, the backend name and the environment only."""
+    from socp_amd import sweep
+
+    class FakeDist:
+        def __init__(self, backend, has):
+            self._b = backend
+            if has:
+                self.all_gather_into_tensor = lambda *a: None
+        def get_backend(self):
+            return self._b
+    assert sweep.single_tensor_gather(FakeDist("nccl", True)) and sweep.single_tensor_gather(FakeDist("gloo", True))
+    assert not sweep.single_tensor_gather(FakeDist("nccl", False)) and not sweep.single_tensor_gather(FakeDist("mpi", True))
+    os.environ["SOCP_SWEEP_GATHER"] = "list"
+    try:
+        assert not sweep.single_tensor_gather(FakeDist("nccl", True))
+    finally:
+        del os.environ["SOCP_SWEEP_GATHER"]
