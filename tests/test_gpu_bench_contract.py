@@ -131,24 +131,26 @@ def test_rccl_code_path_with_one_rank():
     assert abs(d["value"] - 1024 * 15 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
 
 
-def test_six_rank_rehearsal_of_the_driver_job():
+def test_four_rank_rehearsal_of_the_driver_job():
     """keep the 8-GPU path one command from a measurement.  The driver's job is `bench.py --gpus 8`, one rank per GPU;
-    no 8-GPU node can be asked for here, and a one-GPU box admits at most SIX processes on its card (gpurun's process guard), so
-    the rehearsal is the largest the box allows: six ranks sharing device 0, collectives over gloo -- the N > 1 code path of the driver
-    otherwise (self-launch, rendezvous, barrier + max over ranks, one gather of the records, the strong-scaling legs sharded in
-    contiguous blocks of an ODD total).  Every rank reports, every strong-scaling leg states what the recorded one-GPU curve
-    expects of it (`expected`) and how the measurement compares (`measured_over_expected`).  (Eight ranks of the same plumbing run
-    on the CPU: tests/test_sweep_gloo.py; eight emulated ranks through the C++ entry points: test_gpu_multistart.py.)"""
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "6", "--backend", "gloo", "--share-device0",
+    no 8-GPU node can be asked for here, and a one-GPU box admits at most SIX processes on its card (gpurun's process guard: this
+    test runner is one of them), so the rehearsal on the card is four ranks sharing device 0, collectives over gloo -- the N > 1
+    code path of the driver otherwise (self-launch, rendezvous, barrier + max over ranks, one gather of the records, the
+    strong-scaling legs sharded in contiguous blocks of an ODD total).  Every rank reports, every strong-scaling leg states what
+    the recorded one-GPU curve expects of it (`expected`) and how the measurement compares (`measured_over_expected`).  (EIGHT
+    ranks of the same plumbing run on the CPU: tests/test_sweep_gloo.py; eight emulated ranks through the C++ entry points:
+    test_gpu_multistart.py.)"""
+    W = 4
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(W), "--backend", "gloo", "--share-device0",
                           "--steps", "1", "--warmup", "1", "--starts", "256", "--rk4-steps", "1000", "--sweep-starts", "301", "--sweep-c5-starts", "67"],
                          capture_output=True, text=True, timeout=1200)
     d = _line(out)
-    assert d["n_gpus"] == 6 and d["ranks_reported"] == 6 and d["finite_jacobians"] == [256] * 6
-    assert abs(d["value"] - 6 * 256 * 15 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    assert d["n_gpus"] == W and d["ranks_reported"] == W and d["finite_jacobians"] == [256] * W
+    assert abs(d["value"] - W * 256 * 15 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
     legs = [d[k] for k in ("sweep", "sweep_large", "sweep_xl", "sweep_config5")]
     for leg in legs:
-        assert leg["scaling"] == "strong" and leg["n_gpus"] == 6
-        assert leg["starts_per_gpu"] == -(-leg["total_starts"] // 6)                 # the largest block of the contiguous split
+        assert leg["scaling"] == "strong" and leg["n_gpus"] == W
+        assert leg["starts_per_gpu"] == -(-leg["total_starts"] // W)                 # the largest block of the contiguous split
         assert leg["converged"] + leg.get("stopped_by_round_limit", 0) >= 0.95 * leg["total_starts"]
     assert d["sweep"]["total_starts"] == 301 and d["sweep_config5"]["total_starts"] == 67
     # the expectation: present whenever a recorded curve applies (the Goddard legs' curve is recorded for 10^4 steps: a 1000-step
