@@ -353,7 +353,9 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
         pool.cfg.lazy_q = e ? (e[0] == '0' ? 0 : 1) : (n >= 192 ? 1 : 0);
         // ... and forms the back substitution's row sums in parallel (solver_dev.hpp: dogleg).  SOCP_SOLVER_FAST_SUMS=0: the serial chains.
         const char *f = std::getenv("SOCP_SOLVER_FAST_SUMS");
-        pool.cfg.fast_sums = (f && f[0] == '0') ? 0 : 1;
+        // (from n = 112 up: measured on one box against the round-4 library, profiles/r05_r04_vs_now.txt -- M = 9 sweeps, n = 127,
+        // -11 %; KD chains and M = 6 sweeps, n = 85, +10 %: their chains are 42 additions long on average, no longer than the reduction)
+        pool.cfg.fast_sums = f ? (f[0] == '0' ? 0 : 1) : (n >= 112 ? 1 : 0);
     }
     const EnginePlan plan_sizes(n, P, nodes, S, stride);
     pool.ws_stride = (long)plan_sizes.ws_stride;

@@ -913,18 +913,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         {
             const int nstrips = npanels, nch_all = (n + 15) >> 4;
             const int t = tid & 15, r0 = tid >> 4;
-            // (rounds are counted from the LAST strip: the short round, if any, is the one of the first strips, which few panels reach)
-            for (int hi = nstrips; hi > 0; hi -= 4) {
-                const int s0 = hi >= 4 ? hi - 4 : 0;
-                const int sw = s0 + wave;                                    // this wavefront's strip
-                const bool have = sw < hi;
-                f64x4 S[NCH];
+            // (rounds are counted from the LAST strip: the short round, if any, is the one of the first strips, which few panels reach.
+            // A wavefront holds TWO strips where its registers allow -- strips of <= 8 chunks, n <= 128 --: a panel then serves eight
+            // strips per trip through LDS, and two applies stand behind the next panel's fetch instead of one)
+            constexpr int SPW = NCH <= 8 ? 2 : 1, RS = 4 * SPW;
+            for (int hi = nstrips; hi > 0; hi -= RS) {
+                const int s0 = hi >= RS ? hi - RS : 0;
+                int sw[SPW];
+                bool have[SPW];
+                f64x4 S[SPW][NCH];
                 {
                     const int gi = here(g), mi = here(m);
 #pragma unroll
-                    for (int cc = 0; cc < NCH; cc++) {
+                    for (int u = 0; u < SPW; u++) {
+                        sw[u] = s0 + 4 * u + wave;                           // this wavefront's strip(s)
+                        have[u] = sw[u] < hi;
 #pragma unroll
-                        for (int r = 0; r < 4; r++) S[cc][r] = (cc == sw && gi + 4 * r == mi && 16 * sw + mi < n) ? 1.0 : 0.0;
+                        for (int cc = 0; cc < NCH; cc++) {
+#pragma unroll
+                            for (int r = 0; r < 4; r++) S[u][cc][r] = (cc == sw[u] && gi + 4 * r == mi && 16 * sw[u] + mi < n) ? 1.0 : 0.0;
+                        }
                     }
                 }
                 const int ptop = hi - 1;
@@ -952,13 +960,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
                     double *Vc = lds + ((ptop - q) & 1) * kPanelDoubles, *Tc = Vc + 16 * NCH * kLdV;
                     double *Vn = lds + ((ptop - q + 1) & 1) * kPanelDoubles, *Tn = Vn + 16 * NCH * kLdV;
                     if (q > 0) fetch(q - 1);
-                    if (have && q <= sw) strip_apply<NCH>(S, nch_all, Vc, Tc, lane, q);
+#pragma unroll
+                    for (int u = 0; u < SPW; u++)
+                        if (have[u] && q <= sw[u]) strip_apply<NCH>(S[u], nch_all, Vc, Tc, lane, q);
                     if (q > 0) deposit(Vn, Tn);
                     prof.mark(FP_QSTRIPS);
                     __syncthreads();
                     prof.mark(FP_QWAIT);
                 }
-                if (have) strip_store<NCH>(S, A, ld, n, 0, nch_all, 16 * sw, n, g, m);
+#pragma unroll
+                for (int u = 0; u < SPW; u++)
+                    if (have[u]) strip_store<NCH>(S[u], A, ld, n, 0, nch_all, 16 * sw[u], n, g, m);
             }
         }
         if (tid == 0) { states[p].sing = sing ? 1 : 0; states[p].pad = 1; }

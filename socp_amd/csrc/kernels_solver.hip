@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <type_traits>
 
 #include "solver_launch.hpp"
 
@@ -36,17 +37,18 @@ __global__ void start_kernel(Config c, State *states, double *ws, long ws_stride
 // spills cost them 7 % (2048 x (n = 253), bit-equal solver: 0.080 -> 0.086 s with four).  WPE: 4 = trial launches, 3 = factor launches.
 #define SOCP_SOLVER_OCCUPANCY __attribute__((amdgpu_waves_per_eu(MAXT <= 256 ? WPE : (MAXT <= 512 ? 2 : 4))))
 #endif
-template <int MAXT, int WPE>
+template <int MAXT, int WPE, bool RING = false>
 __global__ __launch_bounds__(MAXT) SOCP_SOLVER_OCCUPANCY void advance_kernel(Config c, State *states, double *ws, long ws_stride, const int *__restrict__ list,
                                                        const int *__restrict__ flags, int count, int lds_matrix_doubles)
 {
     extern __shared__ double lds[];
-    // rows of R fetched ahead of the serial chains (solver_dev.hpp: ring_fetch), 16 doubles per thread: its one entry of the next 16 rows
-    // where a workgroup has a thread per column, two entries of 8 rows / four of 4 where the launch shrank it (launch_advance)
-#ifndef SOCP_SOLVER_RING_ROWS
-#define SOCP_SOLVER_RING_ROWS 16
-#endif
-    using Exec = BlockExecRing<(MAXT <= 64 ? 4 : (MAXT <= 128 ? 2 : 1)), (MAXT <= 64 ? SOCP_SOLVER_RING_ROWS / 4 : (MAXT <= 128 ? SOCP_SOLVER_RING_ROWS / 2 : SOCP_SOLVER_RING_ROWS))>;
+    // RING: rows of R fetched ahead of the serial chains (solver_dev.hpp: ring_fetch).  For ONE-WAVEFRONT workgroups of LARGE problems
+    // only -- launches that were shrunk until every problem is resident (launch_advance) with n > 128: a thread owns three or four
+    // entries of a row there and a step's trip to memory is what the problem waits for (config 5, 2048 / 16 384 starts: -18 % / -13 %
+    // of the sweep against the round-4 library on one box).  Everything else keeps the plain loops: with one or two entries per
+    // thread the ring's bookkeeping -- clamped loads, dump stores, the idle steps of a group -- costs more than the wait it removes
+    // (KD chains and M = 6 sweeps, n = 85: +10 ... +16 % with rings of any shape; profiles/r05_r04_vs_now.txt).
+    using Exec = std::conditional_t<RING, BlockExecRing<4, 4>, BlockExec>;
     Exec ex;
     for (int b = blockIdx.x; b < count; b += gridDim.x) {
         const int p = list[b];
@@ -244,18 +246,24 @@ hipError_t launch_advance(hipStream_t st, const PoolDev &pool, const int *d_list
         hipLaunchKernelGGL((advance_kernel<MAXT, WPE>), dim3(grid), dim3(threads), lds_bytes, st, pool.cfg, pool.states, pool.ws,          \
                            pool.ws_stride, d_list, d_flags, count, lds_matrix);                                                            \
     } while (0)
-    // Wavefronts per SIMD the TRIAL launches are built for (profiles/r05_trial_wpe_ab.txt).  One-wavefront workgroups -- large problems
-    // whose launch was shrunk until every problem is resident: four entries of a row per thread, 16 doubles of row ring -- get 256
-    // registers (two per SIMD: a 2048-problem launch has no more wavefronts than that anyway): config 5, 2048 starts 0.0203 -> 0.0185 s
-    // against four.  The others keep round 4's four (KD chains and M = 6 sweeps 5 % faster than with two, M = 9 2 % slower).
-#ifndef SOCP_SOLVER_TRIAL_WPE
-#define SOCP_SOLVER_TRIAL_WPE(MAXT) ((MAXT) <= 64 ? 2 : 4)
-#endif
+    // The TRIAL launches keep round 4's four wavefronts per SIMD -- except the one-wavefront workgroups of large problems (n > 128):
+    // those get the row rings and 256 registers (two per SIMD: a 2048-problem launch has no more wavefronts than that anyway, and
+    // the rings are what hides their memory latency now): config 5, 2048 starts 0.0203 -> 0.0185 s against four
+    // (profiles/r05_trial_wpe_ab.txt).
 #define SOCP_LAUNCH_ADVANCE(MAXT)                                                                                                          \
     do {                                                                                                                                   \
         if (factor_phase) SOCP_LAUNCH_ADVANCE_W(MAXT, 3);                                                                                  \
-        else SOCP_LAUNCH_ADVANCE_W(MAXT, SOCP_SOLVER_TRIAL_WPE(MAXT));                                                                     \
+        else SOCP_LAUNCH_ADVANCE_W(MAXT, 4);                                                                                               \
     } while (0)
+    if (!factor_phase && threads <= 64 && n > 128) {
+        if (lds_bytes > 65536) {
+            const hipError_t raised = raise_lds_limit<advance_kernel<64, 2, true>>();
+            if (raised != hipSuccess) return raised;
+        }
+        hipLaunchKernelGGL((advance_kernel<64, 2, true>), dim3(grid), dim3(threads), lds_bytes, st, pool.cfg, pool.states, pool.ws, pool.ws_stride, d_list, d_flags,
+                           count, lds_matrix);
+        return hipGetLastError();
+    }
     if (threads <= 64) SOCP_LAUNCH_ADVANCE(64);
     else if (threads <= 128) SOCP_LAUNCH_ADVANCE(128);
     else if (threads <= 256) SOCP_LAUNCH_ADVANCE(256);

@@ -269,29 +269,15 @@ SOCP_HD double dot_run(const double *v, const double *a, long stride, int lo, in
 }
 
 // sum + a[lo] + a[lo + 1] + ... + a[hi - 1], added in that order
-// (the back substitution's chain: n - j DEPENDENT additions per step, 32 000 per trial step at n = 253, every one of them on the
-// critical path of the problem.  The entries come from LDS, and with load-then-add batches every batch paid an LDS round trip before
-// its eight additions could start -- 40 cycles per addition, 57 % of a config-5 trial round (profiles/r05n_solver_phases.txt).  The
-// next batch is therefore fetched BEFORE the current one is added: the chain then runs at the adder's own latency.)
 SOCP_HD double sum_run(const double *a, int lo, int hi, double sum)
 {
     int i = lo;
-    if (i + kBatch <= hi) {
-        double cur[kBatch];
+    for (; i + kBatch <= hi; i += kBatch) {
+        double av[kBatch];
 #pragma unroll
-        for (int u = 0; u < kBatch; u++) cur[u] = a[i + u];
-        i += kBatch;
-        for (; i + kBatch <= hi; i += kBatch) {
-            double nxt[kBatch];
+        for (int u = 0; u < kBatch; u++) av[u] = a[i + u];
 #pragma unroll
-            for (int u = 0; u < kBatch; u++) nxt[u] = a[i + u];
-#pragma unroll
-            for (int u = 0; u < kBatch; u++) sum += cur[u];
-#pragma unroll
-            for (int u = 0; u < kBatch; u++) cur[u] = nxt[u];
-        }
-#pragma unroll
-        for (int u = 0; u < kBatch; u++) sum += cur[u];
+        for (int u = 0; u < kBatch; u++) sum += av[u];
     }
     for (; i < hi; i++) sum += a[i];
     return sum;
@@ -827,8 +813,18 @@ SOCP_HD void dogleg(const E &ex, int n, Work &w, double delta, Prof *pf = nullpt
         ex.sync();                                           // the row, qtb, and the x[j + 1] thread 0 stored before arriving here
         if (ex.leader()) {                                   // (the other wavefronts go on to fetch the next row)
             double sum = 0.0;
-            if (j + 1 < n) sum += row[j + 1] * xl[j + 1];
-            sum = sum_run(row, j + 2, n, sum);
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (fast_sums) {                                 // (throughput flavour: the products summed in parallel, see the ringed loop)
+                double part = 0.0;
+                for (int i = j + 2 + (ex.tid & 63); i < n; i += 64) part += row[i];
+                sum = wave_sum(part);
+                if (j + 1 < n) sum += row[j + 1] * xl[j + 1];
+            } else
+#endif
+            {
+                if (j + 1 < n) sum += row[j + 1] * xl[j + 1];
+                sum = sum_run(row, j + 2, n, sum);
+            }
             double temp = row[j];
             if (temp == 0) {
                 long l = j;
