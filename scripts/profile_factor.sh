@@ -13,6 +13,29 @@ $M > $OUT/${TAG}_factor_unprofiled.json 2> /dev/null; cat $OUT/${TAG}_factor_unp
 rm -rf $OUT/pf_*
 timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pf_stats -- $M > /dev/null 2>&1
 f=$(find $OUT/pf_stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && grep -E "Name|factor" $f > $OUT/${TAG}_factor_kernel_stats.csv; cat $OUT/${TAG}_factor_kernel_stats.csv | cut -c1-200
+# (the stats' averages mix the warm-up launch of 8 problems with the measured ones: per-dispatch durations of the MEASURED launches here)
+python3 - "$TAG" "$N" "$COUNT" <<'PY'
+import csv, glob, json, sys
+tag, n, count = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+out = {"tag": tag, "n": n, "count": count, "source": "rocprofv3 --kernel-trace of scripts/measure_factor.py %d %d 3 (launches over all %d problems only: the warm-up launch of 8 is left out)" % (n, count, count)}
+for f in glob.glob("gpurun_out/pf_stats/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        key = "factor_fast_kernel" if "factor_fast_kernel" in k else ("factor_only_kernel" if "factor_only_kernel" in k else None)
+        if key and int(r["Grid_Size_X"]) >= 64 * count:
+            out.setdefault(key, {"kernel": k.split("(")[0], "dispatch_ms": []})["dispatch_ms"].append(round((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6, 4))
+for v in out.values():
+    if isinstance(v, dict) and v.get("dispatch_ms"):
+        v["average_ms"] = sum(v["dispatch_ms"]) / len(v["dispatch_ms"])
+        v["tflops"] = 8.0 / 3.0 * n ** 3 * count / (v["average_ms"] * 1e-3) / 1e12
+        v["frac_of_fp64_peak_78.6"] = v["tflops"] / 78.6
+try:
+    out["hip_events_unprofiled"] = json.load(open("gpurun_out/%s_factor_unprofiled.json" % tag))
+except Exception:
+    pass
+json.dump(out, open("gpurun_out/%s_factor_timing.json" % tag, "w"), indent=1)
+print(json.dumps(out)[:600])
+PY
 export SOCP_MEASURE_ONLY=fast
 timeout -k 5 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pf_fetch -- $M > /dev/null 2>&1
 timeout -k 5 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pf_write -- $M > /dev/null 2>&1
