@@ -356,6 +356,10 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
         // (from n = 112 up: measured on one box against the round-4 library, profiles/r05_r04_vs_now.txt -- M = 9 sweeps, n = 127,
         // -11 %; KD chains and M = 6 sweeps, n = 85, +10 %: their chains are 42 additions long on average, no longer than the reduction)
         pool.cfg.fast_sums = f ? (f[0] == '0' ? 0 : 1) : (n >= 112 ? 1 : 0);
+        // ... and takes the predicted reduction of a Gauss-Newton step as exact instead of forming qtf + R p (solver_dev.hpp: after_trial).
+        // SOCP_SOLVER_GN_SHORTCUT=0: MINPACK's product.
+        const char *gs = std::getenv("SOCP_SOLVER_GN_SHORTCUT");
+        pool.cfg.gn_shortcut = (gs && gs[0] == '0') ? 0 : 1;
     }
     const EnginePlan plan_sizes(n, P, nodes, S, stride);
     pool.ws_stride = (long)plan_sizes.ws_stride;

@@ -47,6 +47,7 @@ struct Config {
     double xtol, epsfcn, factor;
     int lazy_q = 0;    // throughput flavour: Broyden's rotations are kept as a list and Q stays as factorised (see lazy_capacity)
     int fast_sums = 0; // throughput flavour: the back substitution's row sums are formed in parallel (dogleg), summation order free
+    int gn_shortcut = 0;   // throughput flavour: the predicted reduction of a Gauss-Newton step is taken as what it is (after_trial)
 };
 
 // per-problem iteration state (Core of minpack.cpp)
@@ -55,7 +56,8 @@ struct State {
     int req;           // Request left pending by the last advance
     int eval_sel;      // RQ_FVEC: 0 -> evaluate at x, result to fvec; 1 -> evaluate at wa2 (trial point), result to wa4
     int pad;           // 1: the Jacobian in A has already been factorised by the factor kernel (sing holds its flag)
-    int lazy, pad2;    // lazy_q: rank-1 updates since A was last brought up to date (their rotations are in the V area)
+    int lazy;          // lazy_q: rank-1 updates since A was last brought up to date (their rotations are in the V area)
+    int gn;            // the pending trial step is the Gauss-Newton step of a nonsingular R (Config::gn_shortcut reads it)
     double delta, xnorm, fnorm, pnorm;
 };
 
@@ -734,7 +736,7 @@ SOCP_HD void ring_fetch(double (&slot)[E], const double *s, int n, int j, int ti
 // (alternating), f3 = qtb, f4 = scaled vectors whose norm is taken, f5 = the gradient direction.  Every thread returns with
 // the step complete (synchronised).
 template <class E>
-SOCP_HD void dogleg(const E &ex, int n, Work &w, double delta, Prof *pf = nullptr, bool fast_sums = false)
+SOCP_HD bool dogleg(const E &ex, int n, Work &w, double delta, Prof *pf = nullptr, bool fast_sums = false)
 {
     const double *r = w.r, *diag = w.diag;
     double *x = w.wa1, *xl = w.f[0], *qtb = w.f[3], *sc = w.f[4], *g = w.f[5];
@@ -843,7 +845,7 @@ SOCP_HD void dogleg(const E &ex, int n, Work &w, double delta, Prof *pf = nullpt
     if (qnorm <= delta) {
         SOCP_PAR_FOR(j, 0, n) x[j] = xl[j];
         ex.sync();
-        return;
+        return true;                                         // the Gauss-Newton step itself
     }
     // scaled gradient direction: element i collects r(j, i) qtb[j] for j = 0 .. i in that order, then is divided
     SOCP_PAR_FOR(i, 0, n) {
@@ -879,6 +881,7 @@ SOCP_HD void dogleg(const E &ex, int n, Work &w, double delta, Prof *pf = nullpt
     const double temp = (1 - alpha) * min_of(sgnorm, delta);
     SOCP_PAR_FOR(j, 0, n) x[j] = temp * g[j] + alpha * xl[j];
     ex.sync();
+    return false;
 }
 
 SOCP_HD void givens(double a, double b, double &cs, double &sn, double &tau)
@@ -1338,7 +1341,8 @@ struct Machine {
     {
         const int n = c.n;
         prof.mark(15, ex.tid);
-        dogleg(ex, n, w, s.delta, &prof, c.fast_sums != 0);
+        const bool gauss_newton = dogleg(ex, n, w, s.delta, &prof, c.fast_sums != 0);
+        s.gn = (gauss_newton && !s.sing) ? 1 : 0;           // (sing: a zero on R's diagonal -- the back substitution then divided by a stand-in)
         prof.mark(PF_DOGLEG, ex.tid);
         double *sc = w.f[0];
         SOCP_PAR_FOR(j, 0, n) {
@@ -1411,8 +1415,17 @@ struct Machine {
         double actred = -1;
         if (fnorm1 < s.fnorm) { const double q = fnorm1 / s.fnorm; actred = 1 - q * q; }
         // predicted reduction from |qtf + R p|
-        SOCP_PAR_FOR(i, 0, n) {
-            pr[i] = w.qtf[i] + dot_run(pc, w.r + row_off(n, i) - i, 1, i, n, 0.0);
+        if (c.gn_shortcut && s.gn) {
+            // Throughput flavour: p is the Gauss-Newton step -- the back substitution's solution of R x = qtf, negated -- so qtf + R p is
+            // what that solve left over: rounding noise, 1e-16 of |qtf|, and the predicted reduction 1 - (noise / |f|)^2 rounds to
+            // exactly 1 either way.  MINPACK forms the product regardless (a pass over R per trial step: 15 % of a config-5 trial
+            // round, a quarter of a megabyte per problem); here it is taken as the zero it stands for.  Broyden's update below uses
+            // the same vector: v moves at rounding level.  Not when R has a zero on its diagonal (the solve divided by a stand-in).
+            SOCP_PAR_FOR(i, 0, n) pr[i] = 0.0;
+        } else {
+            SOCP_PAR_FOR(i, 0, n) {
+                pr[i] = w.qtf[i] + dot_run(pc, w.r + row_off(n, i) - i, 1, i, n, 0.0);
+            }
         }
         ex.sync();
         const double temp = enorm(n, pr);
