@@ -8,22 +8,23 @@
 // Q = H_0 H_1 ... H_{n-1}) is computed as a BLOCKED Householder QR with compact-WY panels of 16 reflectors, the trailing-matrix
 // update on the FP64 matrix cores (v_mfma_f64_16x16x4_f64), summation order free:
 //
-//   one workgroup (4 wavefronts) per problem; for every panel of 16 columns
-//     wave 0   factorises the panel in registers (a 16-column strip, <= 256 rows: lane = (row group g, column m), 4 rows per
-//              16-row chunk and lane), publishing V to LDS as it goes, then T of  H_j0 .. H_j0+15 = I - V T V^T  (larft recurrence
-//              on the Gram matrix V^T V, itself one MFMA pass)
-//     all      every later 16-column strip (and the strip that holds fvec, column n) goes through the panel ONCE:
-//                 W = V^T S (MFMA, K = rows)   Y = T^T W (4 MFMA)   S -= V Y (MFMA, K = 16)
-//              with the strip in registers in the MFMA C/D layout (row = 16 chunk + g + 4 reg, column = lane & 15).  Because a sum
-//              over K has no prescribed order here, the K slot of lane group g in step `reg` is simply DEFINED to be that row:
-//              the strip's own registers are the B operand of the first product and the accumulator of the last one -- no
-//              layout change, no LDS round trip; only the A operands (V, T) come from LDS, each read conflict-free.
-//   qform      Q = (I - V_0 T_0 V_0^T) ... (I - V_last T_last V_last^T) I accumulated backward over the panels (dorgqr's order):
-//              panel p touches rows and columns >= 16 p only, its own 16 columns start as identity columns in registers.
+//   one workgroup (4 wavefronts) per problem (round 5's structure; round 4 ran one panel per pass with a look-ahead wavefront):
+//     the panel   a 16-column strip (<= 256 rows) factorised by ONE wavefront in a ROW layout -- a lane owns rows, all 16 columns of a
+//                 row in its registers -- with one batched wave-wide reduction per column (panel_rows, wave_reduce.hpp), V published to
+//                 LDS at the end, then T of  H_j0 .. H_j0+15 = I - V T V^T  (larft's recurrence on the Gram matrix V^T V, one MFMA pass)
+//     qrfac       TWO panels per pass: [A] panel pp; [C] the strip that is panel pp + 1 through panel pp, then factorised; [E] every
+//                 later 16-column strip (and the one that holds fvec, column n) through BOTH panels in one load / store:
+//                   W = V^T S (MFMA, K = rows)   Y = T^T W (4 MFMA)   S -= V Y (MFMA, K = 16)
+//                 with the strip in registers in the MFMA C/D layout (row = 16 chunk + g + 4 reg, column = lane & 15).  Because a sum
+//                 over K has no prescribed order here, the K slot of lane group g in step `reg` is simply DEFINED to be that row: the
+//                 strip's own registers are the B operand of the first product and the accumulator of the last one -- no layout
+//                 change, no LDS round trip; only the A operands (V, T) come from LDS, each read conflict-free.
+//     qform       Q = (I - V_0 T_0 V_0^T) ... (I - V_last T_last V_last^T) I: a strip of Q STAYS in a wavefront's registers (it starts
+//                 as identity columns) while every panel that reaches it streams through LDS, last panel first; never read, written once.
 //
-// A strip is read once and written once per PANEL: n^3 / 16 x 8 B ~ 8 MB per problem and phase at n = 253 (17 GB for 2048
-// problems) instead of 173 MB per problem.  Results differ from the order-preserving kernel at rounding level; the engine uses
-// this kernel only when asked for the throughput flavour (SOCP_SOLVER_DEVICE_FAST, or AUTO on a throughput-flavour context).
+// HBM traffic at n = 253: 4.7 x the algorithmic bytes (round 4: 8.3 x; the order-preserving kernel: 130 x).  Results differ from the
+// order-preserving kernel at rounding level; the engine uses this kernel only when asked for the throughput flavour
+// (SOCP_SOLVER_DEVICE_FAST, or AUTO on a throughput-flavour context).
 // Sizes: 39 <= n <= 256 (fast_factor_applies: the strip of a panel must fit the registers of one wavefront); others keep `factor`.
 #include <algorithm>
 #include <atomic>
@@ -60,28 +61,6 @@ __device__ __forceinline__ double from_lane(double x, int src)
     const int lo = __builtin_amdgcn_readlane(__double2loint(x), src);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
     return __hiloint2double(hi, lo);
-}
-// x of the lane whose index differs in bit 0 (CTRL = 0xB1: quad_perm [1, 0, 3, 2]) or bit 1 (0x4E: [2, 3, 0, 1]): data-parallel
-// primitives, no LDS round trip
-template <int CTRL>
-__device__ __forceinline__ double quad_swap(double x)
-{
-    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xF, 0xF, true);
-    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xF, 0xF, true);
-    return __hiloint2double(hi, lo);
-}
-// sum / maximum over the four lanes of a quad (the panel wave keeps the four row groups of a column in one quad)
-__device__ __forceinline__ double quad_sum(double x)
-{
-    x += quad_swap<0xB1>(x);
-    x += quad_swap<0x4E>(x);
-    return x;
-}
-__device__ __forceinline__ double quad_max(double x)
-{
-    x = fmax(x, quad_swap<0xB1>(x));
-    x = fmax(x, quad_swap<0x4E>(x));
-    return x;
 }
 // LDS written by some lanes of this wavefront, read by others: the wave's LDS operations execute in order; keep the compiler
 // from moving the reads above the writes
@@ -148,11 +127,11 @@ __device__ __forceinline__ void strip_store(const f64x4 (&S)[NCH], double *__res
 }
 
 // |column|_2 of the strip's columns from its registers -- the Jacobian's column norms (MINPACK's acnorm) are taken when a strip is
-// first loaded, at panel 0, where every strip holds whole columns: no pass of its own over the matrix.  QUAD: the panel wave's layout
-// (a column's row groups in one quad) / the MFMA layout (row groups 16 lanes apart).  Plain sum of squares where that is safe, the
+// first loaded, at panel 0, where every strip holds whole columns: no pass of its own over the matrix.  MFMA layout (a column's row
+// groups 16 lanes apart).  Plain sum of squares where that is safe, the
 // column's largest entry as scale otherwise (tiny / huge entries, zero columns; a NaN is handed on).  Every lane returns its
 // column's norm.
-template <int NCH, bool QUAD>
+template <int NCH>
 __device__ __forceinline__ double strip_column_norm(const f64x4 (&S)[NCH])
 {
     double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
@@ -162,8 +141,8 @@ __device__ __forceinline__ double strip_column_norm(const f64x4 (&S)[NCH])
         q2 = __builtin_fma(S[cc][2], S[cc][2], q2); q3 = __builtin_fma(S[cc][3], S[cc][3], q3);
     }
     double ss = (q0 + q1) + (q2 + q3);
-    if (QUAD) ss = quad_sum(ss);
-    else { ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32); }
+    ss += __shfl_xor(ss, 16);
+    ss += __shfl_xor(ss, 32);
     if (ss != ss) return ss;
     if (ss > 1e-280 && ss < 1e280) return sqrt(ss);
     double amax = 0.0;
@@ -172,8 +151,8 @@ __device__ __forceinline__ double strip_column_norm(const f64x4 (&S)[NCH])
 #pragma unroll
         for (int r = 0; r < 4; r++) amax = fmax(amax, fabs(S[cc][r]));
     }
-    if (QUAD) amax = quad_max(amax);
-    else { amax = fmax(amax, __shfl_xor(amax, 16)); amax = fmax(amax, __shfl_xor(amax, 32)); }
+    amax = fmax(amax, __shfl_xor(amax, 16));
+    amax = fmax(amax, __shfl_xor(amax, 32));
     if (!(amax > 0 && amax < INFINITY)) return amax;                         // a zero column, or an infinity handed on
     double s2 = 0.0;
 #pragma unroll
@@ -181,8 +160,8 @@ __device__ __forceinline__ double strip_column_norm(const f64x4 (&S)[NCH])
 #pragma unroll
         for (int r = 0; r < 4; r++) { const double x = S[cc][r] / amax; s2 += x * x; }
     }
-    if (QUAD) s2 = quad_sum(s2);
-    else { s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32); }
+    s2 += __shfl_xor(s2, 16);
+    s2 += __shfl_xor(s2, 32);
     return amax * sqrt(s2);
 }
 
@@ -290,7 +269,7 @@ struct FProf {
 };
 #endif
 enum { FP_NORMS = 0, FP_PANEL = 1, FP_PANEL_WAIT = 2, FP_TRAIL = 3, FP_TRAIL_WAIT = 4, FP_RPACK = 5, FP_QLOAD = 6, FP_QSTRIPS = 7, FP_QWAIT = 8,
-       FP_LA_APPLY = 9, FP_LA_CONVERT = 10, FP_COLS = 11, FP_LA_STORE = 12, FP_T = 13, FP_COL_NORM = 14, FP_COL_APPLY = 15 };
+       FP_LA_APPLY = 9, FP_LA_CONVERT = 10, FP_COLS = 11, FP_LA_STORE = 12, FP_T = 13 };
 
 // 1 / x and 1 / sqrt(x) to double precision from the hardware estimates (relative error ~2^-24) in one cubic step each (error ~1e-22);
 // for arguments well inside the exponent range only -- the callers below check that
@@ -307,222 +286,8 @@ __device__ __forceinline__ double rsqrt_in_range(double x)
     return __builtin_fma(y * d, __builtin_fma(0.375, d, 0.5), y);
 }
 
-// A panel of 16 columns (np of them reflectors) held by ONE wavefront in registers, a column's four row groups in one quad of lanes
-// (g = lane & 3, m = lane >> 2: P[cc][reg] = entry (16 cc + g + 4 reg, m) of the panel, row 0 = the panel's first diagonal row): the
-// norm and the dot products are reduced with two quad permutes each.  Factorises it in place (R above the diagonal, the vectors
-// from the diagonal down, as MINPACK stores them) and leaves rdiag[0 .. np) and V (zero above the diagonal) in LDS; returns tau_t in
-// lane t (panel_T's input).
-template <int NCH>
-__device__ __forceinline__ double panel_core(f64x4 (&S)[NCH], int np, int nch, double *Vl, double *__restrict__ rdiag, int lane, FProf &prof)
-{
-    double tau_mine = 0.0, rdiag_mine = 0.0;                                 // lane t (t < 16) keeps tau_t and diag(R)_t
-    double ss_carried = 0.0;                                                 // this lane's share of |its column|^2 below row t, from the last axpy pass
-    bool have_ss = false;
-    // a real loop over the panel's columns (unrolled 16 times the body exceeds what the compiler will unroll, and then every
-    // "constant" index below becomes a run-time register index, i.e. scratch): t is uniform, lanes and registers are SELECTED
-#pragma unroll 1
-    for (int t = 0; t < 16; t++) {
-        lane = here(lane);
-        const int g = lane & 3, m = lane >> 2;
-        bool live = t < np;
-        double ajnorm = 0.0, ajj = 0.0, inv = 0.0, s1 = 1.0;
-        const unsigned long long t_col = prof.stamp();
-        if (live) {
-            // |column t| over the rows from the diagonal down (row >= t: a question in chunk 0 only); every lane does its own
-            // column, the quad of column t is the one that counts.  Four partial sums: the chain of dependent adds is the latency.
-            // (the previous column's axpy pass has already summed the squares of what it wrote: a pass of its own only for the
-            // panel's first column and after a skipped reflector)
-            double mine_ss = ss_carried;
-            if (!have_ss) {
-                double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
-                { const double x = (g >= t) ? S[0][0] : 0.0; q0 = x * x; }
-                { const double x = (g + 4 >= t) ? S[0][1] : 0.0; q1 = x * x; }
-                { const double x = (g + 8 >= t) ? S[0][2] : 0.0; q2 = x * x; }
-                { const double x = (g + 12 >= t) ? S[0][3] : 0.0; q3 = x * x; }
-#pragma unroll
-                for (int cb = 0; cb < NCH; cb += kBlk) {                     // (chunks of a block beyond the matrix hold zeros)
-                    if (cb < nch) {
-#pragma unroll
-                        for (int cc = (cb ? cb : 1); cc < cb + kBlk && cc < NCH; cc++) {
-                            q0 = __builtin_fma(S[cc][0], S[cc][0], q0); q1 = __builtin_fma(S[cc][1], S[cc][1], q1);
-                            q2 = __builtin_fma(S[cc][2], S[cc][2], q2); q3 = __builtin_fma(S[cc][3], S[cc][3], q3);
-                        }
-                    }
-                }
-                mine_ss = (q0 + q1) + (q2 + q3);
-            }
-            const double ss = from_lane(quad_sum(mine_ss), 4 * t);
-            bool plain = false;
-            if (ss != ss) {
-                ajnorm = ss;                                                 // a NaN in the column: handed on, as MINPACK's enorm does
-            } else if (!(ss > 1e-280 && ss < 1e280)) {
-                // outside the range in which a plain sum of squares is safe (or zero): scale by the largest entry
-                double amax = 0.0;
-#pragma unroll
-                for (int cc = 0; cc < NCH; cc++) {
-                    if (cc < nch) {
-#pragma unroll
-                        for (int r = 0; r < 4; r++) amax = fmax(amax, (16 * cc + g + 4 * r >= t) ? fabs(S[cc][r]) : 0.0);
-                    }
-                }
-                amax = from_lane(quad_max(amax), 4 * t);
-                if (amax > 0 && amax < INFINITY) {
-                    double s2 = 0.0;
-#pragma unroll
-                    for (int cc = 0; cc < NCH; cc++) {
-                        if (cc < nch) {
-#pragma unroll
-                            for (int r = 0; r < 4; r++) {
-                                const double x = (16 * cc + g + 4 * r >= t) ? S[cc][r] / amax : 0.0;
-                                s2 += x * x;
-                            }
-                        }
-                    }
-                    ajnorm = amax * sqrt(from_lane(quad_sum(s2), 4 * t));
-                } else {
-                    ajnorm = amax;                                           // a zero column (no reflector), or an infinity handed on
-                }
-            } else {
-                ajnorm = ss * rsqrt_in_range(ss);
-                plain = true;
-            }
-            // a(j, j): row t is chunk 0, row group t & 3, register t >> 2, of column t
-            const int rsel = t >> 2;
-            const double diag_reg = rsel == 0 ? S[0][0] : rsel == 1 ? S[0][1] : rsel == 2 ? S[0][2] : S[0][3];
-            ajj = from_lane(diag_reg, 4 * t + (t & 3));
-            if (ajnorm != 0 && ajj < 0) ajnorm = -ajnorm;
-            if (lane == t) rdiag_mine = -ajnorm;                             // (stored after the loop: no global store inside it)
-            live = ajnorm != 0;
-            // 1 / ajnorm: the quick reciprocal where the sum of squares was in range (|ajnorm| in 1e-140 .. 1e140); otherwise a
-            // division, of ajnorm 2^600 when ajnorm is so small that its reciprocal would overflow (s1 is 1 in every other case)
-            if (plain) {
-                inv = rcp_in_range(ajnorm);
-            } else if (live) {
-                s1 = (fabs(ajnorm) < 1e-290) ? 0x1p600 : 1.0;
-                inv = 1.0 / (ajnorm * s1);
-            }
-        }
-        prof.add(FP_COL_NORM, t_col);
-        double tau_t = 0.0;
-        if (live) {
-            const double vjj = (ajj * s1) * inv + 1.0;                       // in [1, 2]: ajnorm carries a(j, j)'s sign
-            tau_t = rcp_in_range(vjj);
-            // v = a / ajnorm + e_t from the diagonal down, in straight-line code: every lane multiplies, all but column t's by exactly 1
-            // (a divergent branch around 4 NCH register updates makes the compiler keep two copies of the strip)
-            const bool mine = m == t;
-            if (s1 != 1.0) {                                                 // (uniform, rare: the column first goes up by 2^600, exactly)
-                const double f1 = mine ? s1 : 1.0;
-#pragma unroll
-                for (int r = 0; r < 4; r++) S[0][r] *= (mine && g + 4 * r >= t) ? s1 : 1.0;
-#pragma unroll
-                for (int cc = 1; cc < NCH; cc++) {
-#pragma unroll
-                    for (int r = 0; r < 4; r++) S[cc][r] *= f1;
-                }
-            }
-            const double f2 = mine ? inv : 1.0;
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int rr = g + 4 * r;
-                const double x = S[0][r] * ((mine && rr >= t) ? inv : 1.0);
-                S[0][r] = (mine && rr == t) ? x + 1.0 : x;
-            }
-#pragma unroll
-            for (int cb = 0; cb < NCH; cb += kBlk) {
-                if (cb < nch) {
-#pragma unroll
-                    for (int cc = (cb ? cb : 1); cc < cb + kBlk && cc < NCH; cc++) {
-#pragma unroll
-                        for (int r = 0; r < 4; r++) S[cc][r] *= f2;
-                    }
-                }
-            }
-        }
-        if (lane == t) tau_mine = tau_t;
-        // column t of V (zero above its diagonal; all zero for a skipped reflector or a column that is not one)
-        if (m == t) {
-            double *vp = Vl + g * kLdV + t;
-#pragma unroll
-            for (int r = 0; r < 4; r++) vp[4 * r * kLdV] = (live && g + 4 * r >= t) ? S[0][r] : 0.0;
-#pragma unroll
-            for (int cb = 0; cb < NCH; cb += kBlk) {
-                if (cb < nch) {
-#pragma unroll
-                    for (int cc = (cb ? cb : 1); cc < cb + kBlk && cc < NCH; cc++) {
-#pragma unroll
-                        for (int r = 0; r < 4; r++) vp[(16 * cc + 4 * r) * kLdV] = live ? S[cc][r] : 0.0;
-                    }
-                }
-            }
-        }
-        wave_lds_fence();
-        const unsigned long long t_apply = prof.stamp();
-        if (live) {
-            // the later columns of the strip through reflector t:  a -= v (v . a) / v_t
-            const double *vp = Vl + g * kLdV + t;
-            double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
-#pragma unroll
-            for (int cb = 0; cb < NCH; cb += kBlk) {
-                if (cb < nch) {
-                    double v[4 * kBlk];                                      // (all reads of the block in flight: see strip_apply)
-#pragma unroll
-                    for (int q = 0; q < 4 * kBlk; q++) v[q] = vp[(16 * cb + 4 * q) * kLdV];
-                    SOCP_SCHED_FENCE();
-#pragma unroll
-                    for (int q = 0; q < 4 * kBlk; q += 4) {
-                        if (cb + q / 4 < NCH) {
-                            d0 = __builtin_fma(v[q], S[cb + q / 4][0], d0); d1 = __builtin_fma(v[q + 1], S[cb + q / 4][1], d1);
-                            d2 = __builtin_fma(v[q + 2], S[cb + q / 4][2], d2); d3 = __builtin_fma(v[q + 3], S[cb + q / 4][3], d3);
-                        }
-                    }
-                    SOCP_SCHED_FENCE();
-                }
-            }
-            const double dot = quad_sum((d0 + d1) + (d2 + d3));
-            const double coef = (m > t) ? dot * tau_t : 0.0;
-            wave_lds_fence();                                                // (re-read v below rather than hold 4 NCH more registers)
-            // ... and while the columns are rewritten, the squares of what is written below row t: the next column's norm
-            double n0 = 0.0, n1 = 0.0, n2 = 0.0, n3 = 0.0;
-#pragma unroll
-            for (int cb = 0; cb < NCH; cb += kBlk) {
-                if (cb < nch) {
-                    double v[4 * kBlk];
-#pragma unroll
-                    for (int q = 0; q < 4 * kBlk; q++) v[q] = vp[(16 * cb + 4 * q) * kLdV];
-                    SOCP_SCHED_FENCE();
-#pragma unroll
-                    for (int q = 0; q < 4 * kBlk; q += 4) {
-                        const int cc = cb + q / 4;
-                        if (cc < NCH) {
-#pragma unroll
-                            for (int r = 0; r < 4; r++) S[cc][r] = __builtin_fma(-coef, v[q + r], S[cc][r]);
-                            if (cc == 0) {
-                                { const double x = (g > t) ? S[0][0] : 0.0; n0 = x * x; }
-                                { const double x = (g + 4 > t) ? S[0][1] : 0.0; n1 = x * x; }
-                                { const double x = (g + 8 > t) ? S[0][2] : 0.0; n2 = x * x; }
-                                { const double x = (g + 12 > t) ? S[0][3] : 0.0; n3 = x * x; }
-                            } else {
-                                n0 = __builtin_fma(S[cc][0], S[cc][0], n0); n1 = __builtin_fma(S[cc][1], S[cc][1], n1);
-                                n2 = __builtin_fma(S[cc][2], S[cc][2], n2); n3 = __builtin_fma(S[cc][3], S[cc][3], n3);
-                            }
-                        }
-                    }
-                    SOCP_SCHED_FENCE();
-                }
-            }
-            ss_carried = (n0 + n1) + (n2 + n3);
-            have_ss = true;
-        } else {
-            have_ss = false;                                                 // nothing was rewritten: the next column sums its own squares
-        }
-        prof.add(FP_COL_APPLY, t_apply);
-    }
-    if (lane < np) rdiag[lane] = rdiag_mine;
-    return tau_mine;
-}
-
 // ---------------------------------------------------------------------------------------------------------------------------
-// The panel in the ROW layout (round 5).  panel_core above keeps a column's four row groups in a quad of lanes, so every column
+// The panel in the ROW layout (round 5).  Round 4's panel kept a column's four row groups in a quad of lanes, so every column
 // step costs every lane a dot product and an axpy over its 4 NCH entries PLUS the reflector read back from LDS twice (192 LDS
 // operations per column): 110 000 cycles per panel at n = 253, and the chain panel -> apply -> panel was what a problem's time was
 // made of (profiles/r05a_factor_phases.txt).  Here a lane owns ROWS: P[q][m] = entry (64 q + lane, m) of the 16-column panel, all
@@ -757,14 +522,6 @@ __device__ __forceinline__ void panel_T(int nch, double tau_mine, const double *
     }
 }
 
-// a strip from the MFMA layout (lane = 16 g + m) to the panel wave's (lane = 4 m + g): the lane that will hold (g, m) fetches from
-// the lane that holds it now -- through the LDS crossbar (ds_bpermute), no LDS storage
-__device__ __forceinline__ double to_quad_layout(double x, int lane)
-{
-    const int src = 16 * (lane & 3) + (lane >> 2);
-    return __shfl(x, src);
-}
-
 // One workgroup of 256 threads per problem.  LDS (doubles): two panels' V[16 NCH][kLdV] and T[256] (qrfac: the panel being applied and
 // the next one being factorised -- look-ahead; qform: the two panels applied in one pass), Gl[256]
 // WPE: wavefronts per SIMD the registers are budgeted for -- 2 for the 16-chunk strip (128 of 256 VGPRs are the strip), more for the
@@ -805,7 +562,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
                 const unsigned long long t_la = prof.stamp();
                 strip_load<NCH>(S, A, ld, n, j0, nch, j0, n + 1, g, m);      // (column n = fvec rides along when it falls into this strip)
                 if (pp == 0) {
-                    const double nrm = strip_column_norm<NCH, false>(S);
+                    const double nrm = strip_column_norm<NCH>(S);
                     if (g == 0 && m < n) acnorm[m] = nrm;
                 }
                 double P[Rows<NCH>::NQ][16];
@@ -841,7 +598,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
                     const unsigned long long t_la = prof.stamp();
                     strip_load<NCH>(S, A, ld, n, j0, nch, j1, n + 1, g, m);
                     if (pp == 0) {
-                        const double nrm = strip_column_norm<NCH, false>(S);
+                        const double nrm = strip_column_norm<NCH>(S);
                         if (g == 0 && 16 + m < n) acnorm[16 + m] = nrm;
                     }
                     strip_apply<NCH>(S, nch, V0, T0, lane);
@@ -883,7 +640,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
                 f64x4 S[NCH];
                 strip_load<NCH>(S, A, ld, n, j0, nch, c0, n + 1, g, m);
                 if (pp == 0) {
-                    const double nrm = strip_column_norm<NCH, false>(S);
+                    const double nrm = strip_column_norm<NCH>(S);
                     if (g == 0 && c0 + m < n) acnorm[c0 + m] = nrm;
                 }
                 strip_apply<NCH>(S, nch, V0, T0, lane);
