@@ -485,7 +485,11 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
             // the chains that have just received a Jacobian come first in the list (adv_jac of them) and go in their own launch
             if (adv_jac > 0 && fast_factor) hip_ok(socp::devsolver::launch_factor_fast(main_stream, pool, dList.i(), adv_jac));
             else if (adv_jac > 0 && blocked_factor) hip_ok(socp::devsolver::launch_factor(main_stream, pool, dList.i(), adv_jac));
-            hip_ok(socp::devsolver::launch_advance(main_stream, pool, dList.i(), adv_jac, dFlags.i(), true));
+            // (the chains whose factor work a factor KERNEL has just done advance like the others: what is left for them is the
+            // refresh's tail and a dogleg step -- a trial launch's work, not a factorisation's; as a "factor phase" launch, a thread per
+            // column and three wavefronts per SIMD, that tail was the longest launch of a KD-chain round: 1.6 ms against 0.7 ms for a
+            // whole trial step of the same 4096 problems)
+            hip_ok(socp::devsolver::launch_advance(main_stream, pool, dList.i(), adv_jac, dFlags.i(), !(fast_factor || blocked_factor)));
             hip_ok(socp::devsolver::launch_advance(main_stream, pool, dList.i() + adv_jac, count - adv_jac, dFlags.i() + adv_jac, false));
             adv_jac = 0;
             hip_ok(socp::devsolver::launch_gather_status(main_stream, pool, dList.i(), count, static_cast<Status *>(dStatus.p)));
