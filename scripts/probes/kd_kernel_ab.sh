@@ -1,6 +1,6 @@
 # kernel-level A/B of the KD-chain sweep (n = 85): round-4 library against the product build (rocprofv3 --kernel-trace --stats)
 export TMPDIR=/tmp
-for B in _build_r04 _build; do
+for B in ${BUILDS:-_build_r04 _build}; do
   export SOCP_LIB_PATH=$PWD/socp_amd/$B/libsocp_hip.so
   rm -rf gpurun_out/kd_$B
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kd_$B -- python3 -m socp_amd.sweep --starts 4096 --continuation kd --rk4-steps 10 --solver ${SOLVER:-device} > /dev/null 2>&1

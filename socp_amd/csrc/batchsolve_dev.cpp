@@ -353,9 +353,9 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
         pool.cfg.lazy_q = e ? (e[0] == '0' ? 0 : 1) : (n >= 192 ? 1 : 0);
         // ... and forms the back substitution's row sums in parallel (solver_dev.hpp: dogleg).  SOCP_SOLVER_FAST_SUMS=0: the serial chains.
         const char *f = std::getenv("SOCP_SOLVER_FAST_SUMS");
-        // (from n = 112 up: measured on one box against the round-4 library, profiles/r05_r04_vs_now.txt -- M = 9 sweeps, n = 127,
-        // -11 %; KD chains and M = 6 sweeps, n = 85, +10 %: their chains are 42 additions long on average, no longer than the reduction)
-        pool.cfg.fast_sums = f ? (f[0] == '0' ? 0 : 1) : (n >= 112 ? 1 : 0);
+        // (every size: KD chains and M = 6 sweeps, n = 85, -3 ... -4 %, M = 9, n = 127, -11 %; profiles/r05_fast_sums_ab.txt.  An earlier
+        // A/B of this round said +10 % at n = 85 -- with the row rings still in those launches, which was what cost the time)
+        pool.cfg.fast_sums = (f && f[0] == '0') ? 0 : 1;
         // ... and takes the predicted reduction of a Gauss-Newton step as exact instead of forming qtf + R p (solver_dev.hpp: after_trial).
         // SOCP_SOLVER_GN_SHORTCUT=0: MINPACK's product.
         const char *gs = std::getenv("SOCP_SOLVER_GN_SHORTCUT");
