@@ -167,3 +167,38 @@ def test_engine_with_q_kept_as_factorised(M, P, spread, monkeypatch):
     _same_solutions(eager, lazy)
     assert np.max(lazy["nfev_total"]) > 150                             # long solves are among them: lists of 10 / 16 updates overflow
     ctx.close()
+
+
+@pytest.mark.parametrize("family", ["M6", "config5"])
+def test_engine_shortcuts_of_the_throughput_flavour_are_rounding_level(family, monkeypatch):
+    """Round 5's two liberties of the throughput flavour inside the trial step, each behind a switch: the back substitution's products
+    summed in parallel instead of as one chain (SOCP_SOLVER_FAST_SUMS), and the predicted reduction of a Gauss-Newton step taken as the
+    rounding noise it is instead of recomputed from R p (SOCP_SOLVER_GN_SHORTCUT).  Each one, and both, against MINPACK's forms in the
+    same flavour and against the bit-equal solver: same `info`, converged unknowns within north_star's 1e-8 -- and the switches do switch
+    (the iterates differ at rounding level)."""
+    from socp_amd import capi, sweep
+    if family == "M6":
+        ctx = capi.Context(capi.MODEL_GODDARD)
+        ctx.set_params(sweep.GODDARD_PARAMS)
+        ctx.set_step_number(10)
+        ctx.set_variant(capi.VARIANT_LANE_FAST)
+        sweep.goddard_multiple_shooting_problem(ctx, 6)
+        Z0 = sweep.goddard_multiple_shooting_starts(ctx, sweep.goddard_starts(160, 0.05), 6)
+        kw = dict(kind=capi.CHAIN_PLAIN, xtol=1e-10)
+    else:
+        ctx, Z0, kw = sweep.interceptor_config5_sweep(48, variant="fast")
+    exact = ctx.chains_solve(Z0, solver=capi.SOLVER_DEVICE, **kw)
+    runs = {}
+    for sums, gn in (("0", "0"), ("1", "0"), ("0", "1"), ("1", "1")):
+        monkeypatch.setenv("SOCP_SOLVER_FAST_SUMS", sums)
+        monkeypatch.setenv("SOCP_SOLVER_GN_SHORTCUT", gn)
+        runs[sums + gn] = ctx.chains_solve(Z0, solver=capi.SOLVER_DEVICE_FAST, **kw)
+    monkeypatch.delenv("SOCP_SOLVER_FAST_SUMS")
+    monkeypatch.delenv("SOCP_SOLVER_GN_SHORTCUT")
+    default = ctx.chains_solve(Z0, solver=capi.SOLVER_DEVICE_FAST, **kw)
+    assert np.array_equal(default["z"], runs["11"]["z"])                  # both are on by default
+    for key in ("10", "01", "11"):
+        _same_solutions(exact, runs[key])
+        _same_solutions(runs["00"], runs[key])
+        assert not np.array_equal(runs[key]["z"], runs["00"]["z"])       # (the switch did switch)
+    ctx.close()
