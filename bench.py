@@ -32,7 +32,8 @@ Objects in the JSON line beside the contract's fields (N = 1; `--lean` drops the
   north_star_128  north_star's target size: Goddard, M = 9 segments, n = 128 unknowns: one FD Jacobian (1152 trajectories
                   of 1e4 steps as the reference integrates them; fewer with the segment dedup), ms, the reference's
                   trajectory count over that time (reference_trajectories_per_s: a time-to-same-Jacobian rate) and its
-                  ratio to cpu_baseline (B1) -- north_star asks for >= 10x.
+                  ratio to cpu_baseline (B1) -- north_star asks for >= 10x -- and to 16 perfectly scaling cores at the measured
+                  one-core rate (x_over_16xP1: the ratio that does not swing with the host's other tenants).
   sweep, sweep_large, sweep_xl   STRONG scaling: fixed totals of 65 536 / 524 288 / 4 194 304 single-shooting starts (BASELINE
                   configs[3] class: full Newton solves in lock-step, 1e4 RK4 steps, 40-round budget) sharded over the ranks;
                   wall time barrier to barrier, max over ranks.  A sweep's wall time is rounds x max(one trajectory latency,
@@ -45,8 +46,12 @@ Objects in the JSON line beside the contract's fields (N = 1; `--lean` drops the
                   Dormand-Prince, tol 1e-8; Newton solvers on the device with the matrix-core Jacobian refresh) sharded the same
                   way -- 2048 per rank at N = 8.  PARITY UNPINNED (Boost and Eigen are absent: integrator and model are restated
                   from the published algorithm / the reference's text).  `predicted` / `expected` from its own one-GPU curve.
+  solver_kernels  the sweeps' second kernel with a roofline of its own: factor_fast = 2048 Jacobian refreshes of n = 253 (the factor
+                  launch of a config-5 round) on the FP64 matrix cores, HIP-event time, fraction of the FP64 peak; traffic = the
+                  recorded PMC figure (profiles/r05_factor_pmc.json), not measured in this run.
   cpu_baseline    B1: the reference's own model::ComputeTraj (oracle/_ref, kind "reference") or the C oracle (kind
-                  "port") on this box's host cores, bounded sample.  cpu_baseline.b0 = "as shipped": the reference's
+                  "port") on this box's host cores, bounded sample: `value` = MEDIAN of five samples, `spread`, `best`,
+                  `worst`, `samples` beside it (all cores and one core).  cpu_baseline.b0 = "as shipped": the reference's
                   shooting.cpp + its per-call std::threads, bound to this library's hybrd (oracle/_ref/link), one
                   continuation solve at 1e4 steps per segment, trajectories/s = nfev x M / wall.
 """
@@ -489,6 +494,35 @@ def north_star_128(capi, device, rk4_steps, cpu_traj_per_s, p1_traj_per_s=None):
     return out
 
 
+def solver_kernel_rooflines(capi, device):
+    """The roofline of the sweeps' second-largest kernel beside the headline one: the Jacobian refresh of the device solvers in the
+    throughput flavour (kernels_factor_fast.hip, blocked Householder QR on the FP64 matrix cores), 2048 problems of n = 253 -- the
+    factor launch of BASELINE config 5 -- timed with HIP events inside socp_qr_factor_batch.  flop = 8/3 n^3 per problem (qrfac + qform),
+    algorithmic bytes = J in, Q and R out; traffic is the PMC figure recorded under profiles/ (separate --pmc passes)."""
+    n, count = 253, 2048
+    rng = np.random.default_rng(1)
+    J = rng.standard_normal((count, n, n))
+    J[:, np.arange(n), np.arange(n)] += 0.5 * np.sqrt(n)
+    b = rng.standard_normal((count, n))
+    capi.qr_factor_batch(J[:8], b[:8], flavour=capi.FACTOR_FAST, outputs=False, device=device)
+    ms = capi.qr_factor_batch(J, b, flavour=capi.FACTOR_FAST, reps=3, outputs=False, device=device)["kernel_ms"]
+    flop = 8.0 / 3.0 * n ** 3 * count
+    alg = 8.0 * count * (2 * n * n + n * (n + 1) / 2)
+    traffic, source = None, None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r05_factor_pmc.json")) as f:
+            rec = json.load(f)
+        if rec.get("n") == n and rec.get("count") == count:
+            traffic, source = rec["hbm_bytes"], "profiles/r05_factor_pmc.json (RECORDED: 2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes)"
+    except Exception:
+        pass
+    tflops = flop / (ms * 1e-3) / 1e12
+    return {"factor_fast": {"workload": "2048 Jacobian refreshes of n = 253 (qrfac + Q^T f + R + qform), throughput flavour", "kernel": "factor_fast_kernel<16, 2>",
+                            "kernel_ms": ms, "roofline": {"bound": "mfma_fp64", "achieved": tflops, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": tflops / PEAK_FP64_TFLOPS,
+                                                          "algorithmic_bytes": alg, "traffic": traffic, "traffic_over_algorithmic": traffic / alg if traffic else None,
+                                                          "traffic_source": source, "traffic_measured_in_this_run": False}}}
+
+
 def predict_wall(curve, starts):
     """Wall time of a `starts`-start sweep on ONE GPU read off a measured one-GPU curve [(starts, wall_s), ...]: log-log
     interpolation between the measured sizes; below the smallest one its wall time (a sweep cannot take less than its rounds x one
@@ -828,6 +862,7 @@ def main():
             out["north_star_128"] = north_star_128(capi, local_rank, args.rk4_steps, cpu_v, p1_v)
             if cpu_v:
                 out["north_star_128"]["cpu_baseline_value"] = cpu_v
+            out["solver_kernels"] = solver_kernel_rooflines(capi, local_rank)
         sys.stdout.flush()
         os.write(record_fd, (json.dumps(out) + "\n").encode())
 

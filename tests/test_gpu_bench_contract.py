@@ -88,6 +88,11 @@ def test_bench_line_contract():
     assert abs(g["headline_over_16xP1"] - d["value"] / (16 * c["p1"]["value"])) <= 1e-9 * g["headline_over_16xP1"]
     assert "reference_trajectories_per_s" in ns["fast"] and "trajectories_per_s" not in ns["fast"]
     assert ns["fast"]["integrated_trajectories_per_s"] <= ns["fast"]["reference_trajectories_per_s"]
+    # the sweeps' second kernel with a roofline of its own: the matrix-core Jacobian refresh
+    ff = d["solver_kernels"]["factor_fast"]
+    assert ff["kernel_ms"] > 0 and 0 < ff["roofline"]["frac"] < 1 and ff["roofline"]["bound"] == "mfma_fp64"
+    assert abs(ff["roofline"]["frac"] - ff["roofline"]["achieved"] / ff["roofline"]["peak"]) < 1e-12
+    assert ff["roofline"]["traffic"] is None or ff["roofline"]["traffic_over_algorithmic"] > 1.0
     # CPU baseline as SURVEY 8d asks: one thread and all cores, pinned; the host is named
     assert c["p1"]["cores"] == 1 and c["p1"]["value"] > 0 and c["cores"] >= c["p1"]["cores"] and c["pinned"] in (True, False)
     assert isinstance(c["cpu_model"], str) and c["cpu_model"]
