@@ -28,6 +28,7 @@
 // Sizes: 39 <= n <= 256 (fast_factor_applies: the strip of a panel must fit the registers of one wavefront); others keep `factor`.
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 #include <utility>
 
 #include "solver_launch.hpp"
@@ -526,7 +527,8 @@ __device__ __forceinline__ void panel_T(int nch, double tau_mine, const double *
 // the next one being factorised -- look-ahead; qform: the two panels applied in one pass), Gl[256]
 // WPE: wavefronts per SIMD the registers are budgeted for -- 2 for the 16-chunk strip (128 of 256 VGPRs are the strip), more for the
 // smaller strips: the kernel is latency-bound, other problems' wavefronts are what fills its waits
-template <int NCH, int WPE>
+// PHASE: 0 = the whole refresh in one launch; 1 = qrfac (+ R, Q^T f, the flags) only; 2 = qform only (A/B: SOCP_FACTOR_SPLIT)
+template <int NCH, int WPE, int PHASE = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void factor_fast_kernel(Config c, State *states, double *ws, long ws_stride, const int *__restrict__ list, int count)
 {
     extern __shared__ double lds[];
@@ -539,6 +541,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         Work w(ws + (long)p * ws_stride, n, ld, lds);
         double *A = w.A, *rdiag = w.wa1, *acnorm = w.wa2, *Tsave = w.V;
         FProf prof(tid);
+        const int npanels = (n + 15) >> 4;
+        int sing = 0;
+        if constexpr (PHASE != 2) {
         // ---- fvec rides along as column n (the column norms of the Jacobian are taken from the strips as they are first loaded)
         for (int i = tid; i < n; i += 256) A[(long)i * ld + n] = w.fvec[i];
         __syncthreads();
@@ -550,7 +555,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         //       from panel pp's first row: 16 zero rows on top, so one strip of registers meets both panels at the same offsets);
         //   [E] all four wavefronts take the strips right of both panels through pp and pp + 1 in ONE load / store.
         // The wavefronts take turns at [A] and [C] (two workgroups share a CU: their serial parts should not share a SIMD).
-        const int npanels = (n + 15) >> 4;
         double *V0 = lds, *T0 = V0 + 16 * NCH * kLdV, *V1 = lds + kPanelDoubles, *T1 = V1 + 16 * NCH * kLdV;
         for (int pp = 0; pp < npanels; pp += 2) {
             const int j0 = 16 * pp, j1 = j0 + 16, nch = (n - j0 + 15) >> 4;
@@ -658,8 +662,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         // ---- (Q^T fvec and the packed R have been written row block by row block as the strips passed) "singular":
         int zero = 0;
         for (int j = tid; j < n; j += 256) zero |= (rdiag[j] == 0) ? 1 : 0;
-        const int sing = __syncthreads_or(zero);
+        sing = __syncthreads_or(zero);
         prof.mark(FP_RPACK);
+        if (PHASE == 1 && tid == 0) { states[p].sing = sing ? 1 : 0; states[p].pad = 1; }
+        }   // PHASE != 2
+        if constexpr (PHASE != 1) {
         // ---- qform (round 5): a strip of Q STAYS in a wavefront's registers while every panel that reaches it streams through LDS.
         // Q = H_0 ... H_last applied to the identity: the 16 columns c0 .. c0 + 15 start as identity columns and are touched by the
         // panels p <= c0 / 16 only (a later panel acts on rows below the columns' ones), last panel first.  So a strip is never READ
@@ -730,7 +737,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
                     if (have[u]) strip_store<NCH>(S[u], A, ld, n, 0, nch_all, 16 * sw[u], n, g, m);
             }
         }
-        if (tid == 0) { states[p].sing = sing ? 1 : 0; states[p].pad = 1; }
+        }   // PHASE != 1
+        if (PHASE == 0 && tid == 0) { states[p].sing = sing ? 1 : 0; states[p].pad = 1; }
         __syncthreads();
     }
 }
@@ -749,16 +757,27 @@ hipError_t raise_lds_limit_fast()
     return e;
 }
 
-template <int NCH, int WPE>
-hipError_t launch_nch(hipStream_t st, const PoolDev &pool, const int *d_list, int count)
+template <int NCH, int WPE, int PHASE>
+hipError_t launch_phase(hipStream_t st, const PoolDev &pool, const int *d_list, int count)
 {
     const size_t lds_bytes = sizeof(double) * (size_t)(2 * (16 * NCH * kLdV + 256) + 256);
     if (lds_bytes > 65536) {
-        const hipError_t raised = raise_lds_limit_fast<factor_fast_kernel<NCH, WPE>>();
+        const hipError_t raised = raise_lds_limit_fast<factor_fast_kernel<NCH, WPE, PHASE>>();
         if (raised != hipSuccess) return raised;
     }
-    hipLaunchKernelGGL((factor_fast_kernel<NCH, WPE>), dim3((unsigned)count), dim3(256), lds_bytes, st, pool.cfg, pool.states, pool.ws, pool.ws_stride, d_list, count);
+    hipLaunchKernelGGL((factor_fast_kernel<NCH, WPE, PHASE>), dim3((unsigned)count), dim3(256), lds_bytes, st, pool.cfg, pool.states, pool.ws, pool.ws_stride, d_list, count);
     return hipGetLastError();
+}
+template <int NCH, int WPE>
+hipError_t launch_nch(hipStream_t st, const PoolDev &pool, const int *d_list, int count)
+{
+    // Two launches -- qrfac, then qform -- rather than one: each half is a smaller function (the register allocator spills 27 + 55
+    // registers instead of 93 at 16 chunks) and every workgroup of a launch is in the same phase: 5.65 -> 5.03 ms at 2048 x n = 253,
+    // 3.87 -> 3.55 ms at n = 200, 1.38 -> 1.33 ms at 4096 x n = 85 (profiles/r05_factor_split_ab.txt).  SOCP_FACTOR_SPLIT=0: one launch.
+    static const bool split = [] { const char *e = std::getenv("SOCP_FACTOR_SPLIT"); return !(e && e[0] == '0'); }();
+    if (!split) return launch_phase<NCH, WPE, 0>(st, pool, d_list, count);
+    const hipError_t e = launch_phase<NCH, WPE, 1>(st, pool, d_list, count);
+    return e != hipSuccess ? e : launch_phase<NCH, WPE, 2>(st, pool, d_list, count);
 }
 
 }  // namespace
