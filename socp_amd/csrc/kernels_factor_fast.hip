@@ -22,7 +22,8 @@
 //     qform       Q = (I - V_0 T_0 V_0^T) ... (I - V_last T_last V_last^T) I: a strip of Q STAYS in a wavefront's registers (it starts
 //                 as identity columns) while every panel that reaches it streams through LDS, last panel first; never read, written once.
 //
-// HBM traffic at n = 253: 4.7 x the algorithmic bytes (round 4: 8.3 x; the order-preserving kernel: 130 x).  Results differ from the
+// Two launches per refresh: qrfac (PHASE 1), then qform (PHASE 2).  HBM traffic at n = 253: 4.4 x the algorithmic bytes (round 4:
+// 8.3 x; the order-preserving kernel: 130 x).  Results differ from the
 // order-preserving kernel at rounding level; the engine uses this kernel only when asked for the throughput flavour
 // (SOCP_SOLVER_DEVICE_FAST, or AUTO on a throughput-flavour context).
 // Sizes: 39 <= n <= 256 (fast_factor_applies: the strip of a panel must fit the registers of one wavefront); others keep `factor`.
