@@ -517,7 +517,7 @@ def solver_kernel_rooflines(capi, device):
     except Exception:
         pass
     tflops = flop / (ms * 1e-3) / 1e12
-    return {"factor_fast": {"workload": "2048 Jacobian refreshes of n = 253 (qrfac + Q^T f + R + qform), throughput flavour", "kernel": "factor_fast_kernel<16, 2>",
+    return {"factor_fast": {"workload": "2048 Jacobian refreshes of n = 253 (qrfac + Q^T f + R + qform), throughput flavour", "kernel": "factor_fast_kernel<16, 2, 1> (qrfac) + factor_fast_kernel<16, 2, 2> (qform), two launches",
                             "kernel_ms": ms, "roofline": {"bound": "mfma_fp64", "achieved": tflops, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": tflops / PEAK_FP64_TFLOPS,
                                                           "algorithmic_bytes": alg, "traffic": traffic, "traffic_over_algorithmic": traffic / alg if traffic else None,
                                                           "traffic_source": source, "traffic_measured_in_this_run": False}}}

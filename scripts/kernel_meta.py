@@ -58,6 +58,7 @@ def main():
             names = demangle([r["name"] for r in recs])
             for r, nm in zip(recs, names):
                 nm = re.sub(r"^void ", "", nm)
+                nm = nm.replace("(anonymous namespace)::", "")
                 nm = re.sub(r"\(.*$", "", nm)
                 rows.append({"object": os.path.basename(obj), "kernel": nm.replace("socp::", ""),
                              "vgpr": int(r.get("vgpr_count", 0)), "agpr": int(r.get("agpr_count", 0)), "sgpr": int(r.get("sgpr_count", 0)),

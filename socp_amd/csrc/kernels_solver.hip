@@ -37,7 +37,7 @@ __global__ void start_kernel(Config c, State *states, double *ws, long ws_stride
 // spills cost them 7 % (2048 x (n = 253), bit-equal solver: 0.080 -> 0.086 s with four).  WPE: 4 = trial launches, 3 = factor launches.
 #define SOCP_SOLVER_OCCUPANCY __attribute__((amdgpu_waves_per_eu(MAXT <= 256 ? WPE : (MAXT <= 512 ? 2 : 4))))
 #endif
-template <int MAXT, int WPE, bool RING = false>
+template <int MAXT, int WPE, bool RING = false, bool FACTOR = true>
 __global__ __launch_bounds__(MAXT) SOCP_SOLVER_OCCUPANCY void advance_kernel(Config c, State *states, double *ws, long ws_stride, const int *__restrict__ list,
                                                        const int *__restrict__ flags, int count, int lds_matrix_doubles)
 {
@@ -48,7 +48,10 @@ __global__ __launch_bounds__(MAXT) SOCP_SOLVER_OCCUPANCY void advance_kernel(Con
     // of the sweep against the round-4 library on one box).  Everything else keeps the plain loops: with one or two entries per
     // thread the ring's bookkeeping -- clamped loads, dump stores, the idle steps of a group -- costs more than the wait it removes
     // (KD chains and M = 6 sweeps, n = 85: +10 ... +16 % with rings of any shape; profiles/r05_r04_vs_now.txt).
-    using Exec = std::conditional_t<RING, BlockExecRing<4, 4>, BlockExec>;
+    // FACTOR = false: the builds of the TRIAL launches (their fresh Jacobians, if any, come from a factor kernel: launch_advance) carry no
+    // factorisation
+    using Rows = std::conditional_t<RING, BlockExecRing<4, 4>, BlockExec>;
+    using Exec = std::conditional_t<FACTOR, Rows, NoInlineFactor<Rows>>;
     Exec ex;
     for (int b = blockIdx.x; b < count; b += gridDim.x) {
         const int p = list[b];
@@ -237,14 +240,14 @@ hipError_t launch_advance(hipStream_t st, const PoolDev &pool, const int *d_list
             }
         }
     }
-#define SOCP_LAUNCH_ADVANCE_W(MAXT, WPE)                                                                                                   \
+#define SOCP_LAUNCH_ADVANCE_W(MAXT, WPE, FACTOR)                                                                                           \
     do {                                                                                                                                   \
         if (lds_bytes > 65536) {                                                                                                           \
-            const hipError_t raised = raise_lds_limit<advance_kernel<MAXT, WPE>>();                                                        \
+            const hipError_t raised = raise_lds_limit<advance_kernel<MAXT, WPE, false, FACTOR>>();                                         \
             if (raised != hipSuccess) return raised;                                                                                       \
         }                                                                                                                                  \
-        hipLaunchKernelGGL((advance_kernel<MAXT, WPE>), dim3(grid), dim3(threads), lds_bytes, st, pool.cfg, pool.states, pool.ws,          \
-                           pool.ws_stride, d_list, d_flags, count, lds_matrix);                                                            \
+        hipLaunchKernelGGL((advance_kernel<MAXT, WPE, false, FACTOR>), dim3(grid), dim3(threads), lds_bytes, st, pool.cfg, pool.states,    \
+                           pool.ws, pool.ws_stride, d_list, d_flags, count, lds_matrix);                                                   \
     } while (0)
     // The TRIAL launches keep round 4's four wavefronts per SIMD -- except the one-wavefront workgroups of large problems (n > 128):
     // those get the row rings and 256 registers (two per SIMD: a 2048-problem launch has no more wavefronts than that anyway, and
@@ -252,23 +255,23 @@ hipError_t launch_advance(hipStream_t st, const PoolDev &pool, const int *d_list
     // (profiles/r05_trial_wpe_ab.txt).
 #define SOCP_LAUNCH_ADVANCE(MAXT)                                                                                                          \
     do {                                                                                                                                   \
-        if (factor_phase) SOCP_LAUNCH_ADVANCE_W(MAXT, 3);                                                                                  \
-        else SOCP_LAUNCH_ADVANCE_W(MAXT, 4);                                                                                               \
+        if (factor_phase) SOCP_LAUNCH_ADVANCE_W(MAXT, 3, true);                                                                            \
+        else SOCP_LAUNCH_ADVANCE_W(MAXT, 4, false);                                                                                        \
     } while (0)
     if (!factor_phase && threads <= 64 && n > 128) {
         if (lds_bytes > 65536) {
-            const hipError_t raised = raise_lds_limit<advance_kernel<64, 2, true>>();
+            const hipError_t raised = raise_lds_limit<advance_kernel<64, 2, true, false>>();
             if (raised != hipSuccess) return raised;
         }
-        hipLaunchKernelGGL((advance_kernel<64, 2, true>), dim3(grid), dim3(threads), lds_bytes, st, pool.cfg, pool.states, pool.ws, pool.ws_stride, d_list, d_flags,
+        hipLaunchKernelGGL((advance_kernel<64, 2, true, false>), dim3(grid), dim3(threads), lds_bytes, st, pool.cfg, pool.states, pool.ws, pool.ws_stride, d_list, d_flags,
                            count, lds_matrix);
         return hipGetLastError();
     }
     if (threads <= 64) SOCP_LAUNCH_ADVANCE(64);
     else if (threads <= 128) SOCP_LAUNCH_ADVANCE(128);
     else if (threads <= 256) SOCP_LAUNCH_ADVANCE(256);
-    else if (threads <= 512) SOCP_LAUNCH_ADVANCE_W(512, 3);
-    else SOCP_LAUNCH_ADVANCE_W(1024, 3);
+    else if (threads <= 512) SOCP_LAUNCH_ADVANCE_W(512, 3, true);
+    else SOCP_LAUNCH_ADVANCE_W(1024, 3, true);
 #undef SOCP_LAUNCH_ADVANCE
 #undef SOCP_LAUNCH_ADVANCE_W
     return hipGetLastError();

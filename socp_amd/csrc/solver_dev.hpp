@@ -120,11 +120,18 @@ struct BlockExec {
     }
     // row rings (r1updt, the dogleg's back substitution): kRingE entries of a row per thread, kRingB rows in flight; 0 = none
     static constexpr int kRingE = 0, kRingB = 0;
+    // whether Machine::after_jacobian carries the factorisation itself (false: the launch's fresh Jacobians have all been through a
+    // factor kernel -- the trial launches' builds leave the code, and the registers it costs them, out)
+    static constexpr bool kInlineFactor = true;
 };
 // the advance kernels' executor: a thread owns at most E entries of a row of R (n <= E * threads; larger problems take the plain loops)
 template <int E, int B>
 struct BlockExecRing : BlockExec {
     static constexpr int kRingE = E, kRingB = B;
+};
+template <class Base>
+struct NoInlineFactor : Base {
+    static constexpr bool kInlineFactor = false;
 };
 #endif
 struct SerialExec {
@@ -133,6 +140,7 @@ struct SerialExec {
     SOCP_HD void sync_lds() const {}
     SOCP_HD bool leader() const { return true; }
     static constexpr int kRingE = 0, kRingB = 0;
+    static constexpr bool kInlineFactor = true;
 };
 
 // Development aid (-DSOCP_SOLVER_PROFILE, device only): thread 0 of every workgroup adds the clock ticks between marks to
@@ -161,13 +169,28 @@ enum { PF_TRIAL_HEAD = 0, PF_QTW = 1, PF_R1UPDT = 2, PF_R1MPYQ = 3, PF_DOGLEG = 
 // Elements are dealt out by ABSOLUTE index: element i belongs to thread i mod nt whatever the loop bounds are.  r1updt relies
 // on it (a thread keeps "its" w[i] and s(., i) across rotation steps without a barrier), and a thread re-visits the same
 // columns of A from reflector to reflector.
+SOCP_HD int par_first_plain(int lo, int tid, int nt)
+{
+    const int m = (lo < nt) ? lo : lo % nt;
+    const int d = tid - m;
+    return lo + (d < 0 ? d + nt : d);
+}
 SOCP_HD int par_first(int lo, int tid, int nt)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // The thread index re-defined where a loop starts: every loop's first address is otherwise computed ONCE, at the top of the
+    // kernel (the state machine's hundred loops are all invariant in the problem loop), and held -- or spilled -- from there on:
+    // the four-wavefront builds kept 24 such addresses in scratch memory and 150 scalar values in the lanes of three more registers.
+    asm volatile("" : "+v"(tid));
+#endif
     const int m = (lo < nt) ? lo : lo % nt;                  // (one division at most, none in the common case n <= nt)
     const int d = tid - m;
     return lo + (d < 0 ? d + nt : d);
 }
 #define SOCP_PAR_FOR(i, lo, hi) for (int i = par_first((lo), ex.tid, ex.nt); i < (hi); i += ex.nt)
+// (the loops of the order-preserving factorisation, two or three per reflector: there the addresses held from one reflector to the next
+// are worth their registers -- config 5 with the bit-equal solver, n = 253: 0.0805 s against 0.0857 s with them re-derived per loop)
+#define SOCP_PAR_FOR_KEPT(i, lo, hi) for (int i = par_first_plain((lo), ex.tid, ex.nt); i < (hi); i += ex.nt)
 
 constexpr double kEpsMch = DBL_EPSILON;
 constexpr double kGiant = DBL_MAX;
@@ -458,9 +481,9 @@ SOCP_HD bool factor(const E &ex, int n, int ld, Work &w, Prof *pf = nullptr)
     double *va = w.f[1], *vb = w.f[2];                       // the reflector in hand, the next one (they swap every step)
     double *sums = w.f[3];                                   // sums[k], k = 0 .. n: column k's dot product with the reflector in hand
                                                              // (n + 1 entries: runs one into w.f[4], unused here)
-    SOCP_PAR_FOR(j, 0, n) acnorm[j] = enorm(n, A + j, ld);
-    SOCP_PAR_FOR(i, 0, n) A[(long)i * ld + n] = w.fvec[i];
-    SOCP_PAR_FOR(i, 0, n) col[i] = A[(long)i * ld];
+    SOCP_PAR_FOR_KEPT(j, 0, n) acnorm[j] = enorm(n, A + j, ld);
+    SOCP_PAR_FOR_KEPT(i, 0, n) A[(long)i * ld + n] = w.fvec[i];
+    SOCP_PAR_FOR_KEPT(i, 0, n) col[i] = A[(long)i * ld];
     ex.sync();
     // reflector 0 from column 0 as it stands, and every later column's dot product with it
     bool cur = false;
@@ -472,7 +495,7 @@ SOCP_HD bool factor(const E &ex, int n, int ld, Work &w, Prof *pf = nullptr)
         if (ajnorm != 0 && col[0] < 0) ajnorm = -ajnorm;
         cur = ajnorm != 0;
         if (cur) {
-            SOCP_PAR_FOR(i, 0, n) {
+            SOCP_PAR_FOR_KEPT(i, 0, n) {
                 double t = col[i] / ajnorm;
                 if (i == 0) t += 1;
                 A[(long)i * ld] = t;
@@ -481,7 +504,7 @@ SOCP_HD bool factor(const E &ex, int n, int ld, Work &w, Prof *pf = nullptr)
         }
         if (ex.tid == 0) rdiag[0] = -ajnorm;
         ex.sync();
-        if (cur) SOCP_PAR_FOR(k, 1, n + 1) sums[k] = dot_run(va, A + k, ld, 0, n, 0.0);
+        if (cur) SOCP_PAR_FOR_KEPT(k, 1, n + 1) sums[k] = dot_run(va, A + k, ld, 0, n, 0.0);
         ex.sync();
     }
     SOCP_PF(8);
@@ -492,13 +515,13 @@ SOCP_HD bool factor(const E &ex, int n, int ld, Work &w, Prof *pf = nullptr)
         bool next = false;
         if (cur) {
             const double temp = sums[c1] / piv;
-            SOCP_PAR_FOR(i, j, n) {
+            SOCP_PAR_FOR_KEPT(i, j, n) {
                 const double t = A[(long)i * ld + c1] - temp * va[i];
                 A[(long)i * ld + c1] = t;
                 col[i] = t;
             }
         } else if (c1 < n) {
-            SOCP_PAR_FOR(i, c1, n) col[i] = A[(long)i * ld + c1];
+            SOCP_PAR_FOR_KEPT(i, c1, n) col[i] = A[(long)i * ld + c1];
         }
         ex.sync();
         SOCP_PF(9);
@@ -509,7 +532,7 @@ SOCP_HD bool factor(const E &ex, int n, int ld, Work &w, Prof *pf = nullptr)
             if (ajnorm != 0 && col[c1] < 0) ajnorm = -ajnorm;
             next = ajnorm != 0;
             if (next) {
-                SOCP_PAR_FOR(i, c1, n) {
+                SOCP_PAR_FOR_KEPT(i, c1, n) {
                     double t = col[i] / ajnorm;
                     if (i == c1) t += 1;
                     A[(long)i * ld + c1] = t;
@@ -522,25 +545,25 @@ SOCP_HD bool factor(const E &ex, int n, int ld, Work &w, Prof *pf = nullptr)
         SOCP_PF(10);
         // the columns from j + 2 on (and fvec's): reflector j's axpy, reflector j + 1's dot product
         if (cur && next) {
-            SOCP_PAR_FOR(k, j + 2, n + 1) sums[k] = axpy_dot_run(A + k, ld, va, vb, j, c1, n, sums[k] / piv);
+            SOCP_PAR_FOR_KEPT(k, j + 2, n + 1) sums[k] = axpy_dot_run(A + k, ld, va, vb, j, c1, n, sums[k] / piv);
         } else if (cur) {
-            SOCP_PAR_FOR(k, j + 2, n + 1) axpy_run(A + k, ld, va, j, n, sums[k] / piv);
+            SOCP_PAR_FOR_KEPT(k, j + 2, n + 1) axpy_run(A + k, ld, va, j, n, sums[k] / piv);
         } else if (next) {
-            SOCP_PAR_FOR(k, j + 2, n + 1) sums[k] = dot_run(vb, A + k, ld, c1, n, 0.0);
+            SOCP_PAR_FOR_KEPT(k, j + 2, n + 1) sums[k] = dot_run(vb, A + k, ld, c1, n, 0.0);
         }
         ex.sync();
         SOCP_PF(11);
         double *const t = va; va = vb; vb = t;
         cur = next;
     }
-    SOCP_PAR_FOR(i, 0, n) w.qtf[i] = A[(long)i * ld + n];
+    SOCP_PAR_FOR_KEPT(i, 0, n) w.qtf[i] = A[(long)i * ld + n];
     // R by rows: row i = [rdiag[i], A(i, i+1 .. n-1)]
     for (int i = 0; i < n; i++) {
         const long off = row_off(n, i);
-        SOCP_PAR_FOR(k, i, n) w.r[off + (k - i)] = (k == i) ? rdiag[i] : A[(long)i * ld + k];
+        SOCP_PAR_FOR_KEPT(k, i, n) w.r[off + (k - i)] = (k == i) ? rdiag[i] : A[(long)i * ld + k];
     }
     bool sing = false;
-    SOCP_PAR_FOR(j, 0, n) col[j] = rdiag[j];
+    SOCP_PAR_FOR_KEPT(j, 0, n) col[j] = rdiag[j];
     ex.sync();
     for (int j = 0; j < n; j++) if (col[j] == 0) sing = true;
     // qform, MINPACK's in-place order: the strict upper triangle is cleared, then for k = n-1 .. 0 column k's Householder
@@ -548,11 +571,11 @@ SOCP_HD bool factor(const E &ex, int n, int ld, Work &w, Prof *pf = nullptr)
     // columns j >= k take reflector k's axpy they accumulate their dot product with reflector k - 1, whose vector is simply
     // column k - 1 as stored (no reflector of this sweep touches it before its turn).
     for (int i = 0; i < n; i++)
-        SOCP_PAR_FOR(j, i + 1, n) A[(long)i * ld + j] = 0;
-    SOCP_PAR_FOR(i, n - 1, n) { va[i] = A[(long)i * ld + n - 1]; A[(long)i * ld + n - 1] = 1.0; }
+        SOCP_PAR_FOR_KEPT(j, i + 1, n) A[(long)i * ld + j] = 0;
+    SOCP_PAR_FOR_KEPT(i, n - 1, n) { va[i] = A[(long)i * ld + n - 1]; A[(long)i * ld + n - 1] = 1.0; }
     ex.sync();
     cur = va[n - 1] != 0;
-    if (cur) SOCP_PAR_FOR(jc, n - 1, n) sums[jc] = dot_run(va, A + jc, ld, n - 1, n, 0.0);
+    if (cur) SOCP_PAR_FOR_KEPT(jc, n - 1, n) sums[jc] = dot_run(va, A + jc, ld, n - 1, n, 0.0);
     ex.sync();
     SOCP_PF(12);
     for (int k = n - 1; k >= 0; k--) {
@@ -560,7 +583,7 @@ SOCP_HD bool factor(const E &ex, int n, int ld, Work &w, Prof *pf = nullptr)
         const double piv = cur ? va[k] : 1.0;
         bool next = false;
         if (k > 0) {
-            SOCP_PAR_FOR(i, k - 1, n) { vb[i] = A[(long)i * ld + k - 1]; A[(long)i * ld + k - 1] = (i == k - 1) ? 1.0 : 0.0; }
+            SOCP_PAR_FOR_KEPT(i, k - 1, n) { vb[i] = A[(long)i * ld + k - 1]; A[(long)i * ld + k - 1] = (i == k - 1) ? 1.0 : 0.0; }
             ex.sync();
             next = vb[k - 1] != 0;
         }
@@ -572,15 +595,15 @@ SOCP_HD bool factor(const E &ex, int n, int ld, Work &w, Prof *pf = nullptr)
             odd += vb[k - 1] * 1.0;
             odd = dot_const_run(vb, 0.0, k, n, odd);
             if (ex.tid == (k - 1) % ex.nt) sums[k - 1] = odd;
-            SOCP_PAR_FOR(jc, k, n) sums[jc] = axpy_dot_run(A + jc, ld, va, vb, k, k - 1, n, sums[jc] / piv);
+            SOCP_PAR_FOR_KEPT(jc, k, n) sums[jc] = axpy_dot_run(A + jc, ld, va, vb, k, k - 1, n, sums[jc] / piv);
         } else if (cur) {
-            SOCP_PAR_FOR(jc, k, n) axpy_run(A + jc, ld, va, k, n, sums[jc] / piv);
+            SOCP_PAR_FOR_KEPT(jc, k, n) axpy_run(A + jc, ld, va, k, n, sums[jc] / piv);
         } else if (next) {
             double odd = 0.0;                                // (column k - 1 as above: on the vector alone)
             odd += vb[k - 1] * 1.0;
             odd = dot_const_run(vb, 0.0, k, n, odd);
             if (ex.tid == (k - 1) % ex.nt) sums[k - 1] = odd;
-            SOCP_PAR_FOR(jc, k, n) sums[jc] = dot_run(vb, A + jc, ld, k - 1, n, 0.0);
+            SOCP_PAR_FOR_KEPT(jc, k, n) sums[jc] = dot_run(vb, A + jc, ld, k - 1, n, 0.0);
         }
         ex.sync();
         double *const t = va; va = vb; vb = t;
@@ -1331,7 +1354,18 @@ struct Machine {
     double *fast_matrix = nullptr;   // device: an LDS buffer of n * ld doubles for the factor work (null: work in place)
     double *blocked_panel = nullptr, *blocked_block = nullptr;   // buffers of factor_blocked (the host simulation's way to run it)
     SOCP_HD Machine(const E &e, const Config &cfg, State &state, double *base, double *fast_vectors = nullptr)
-        : ex(e), c(cfg), st(state), s(state), w(base, cfg.n, cfg.ld, fast_vectors) {}
+        : ex(e), c(cfg), st(state), s(state), w(base, cfg.n, cfg.ld, fast_vectors)
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        // every thread has loaded the same 96 bytes: say so (v_readfirstlane), and the state starts in SCALAR registers -- 24 vector
+        // registers less across the whole advance, a third of what the four-wavefront builds spilled
+        static_assert(sizeof(State) % sizeof(int) == 0, "State is read word by word");
+        int words[sizeof(State) / sizeof(int)];
+        __builtin_memcpy(words, &s, sizeof(State));
+        for (unsigned k = 0; k < sizeof(State) / sizeof(int); k++) words[k] = __builtin_amdgcn_readfirstlane(words[k]);
+        __builtin_memcpy(&s, words, sizeof(State));
+#endif
+    }
 
     SOCP_HD void store() { ex.sync(); if (ex.tid == 0) st = s; }
     SOCP_HD void finish(int code) { s.info = code; s.phase = PH_DONE; s.req = RQ_DONE; }
@@ -1359,7 +1393,7 @@ struct Machine {
         prof.mark(PF_STEP_TAIL, ex.tid);
     }
 
-    SOCP_HD void after_jacobian()
+    SOCP_HD bool after_jacobian()
     {
         const int n = c.n;
         if (c.analytic) s.njev += 1; else s.nfev += n;
@@ -1368,6 +1402,11 @@ struct Machine {
             // the factor kernel (kernels_solver.hip: factor_blocked on this problem) has been here: A = Q, r, qtf, wa1, wa2 are in place
             sing = s.sing != 0;
             s.pad = 0;
+        } else if constexpr (!E::kInlineFactor) {
+            // (never reached: launch_advance picks such a build only behind a factor kernel.  Should the engine ever break that rule,
+            // the problem ends as "terminated" instead of iterating on an unfactored matrix)
+            finish(-3);
+            return false;
         } else if (blocked_panel) {
             sing = factor_blocked(ex, n, c.ld, w, blocked_panel, blocked_block);
         } else if (fast_matrix) {
@@ -1401,6 +1440,7 @@ struct Machine {
         if (c.mode != 2) SOCP_PAR_FOR(j, 0, n) w.diag[j] = max_of(w.diag[j], w.wa2[j]);
         ex.sync();
         prof.mark(PF_JAC_TAIL, ex.tid);
+        return true;
     }
 
     SOCP_HD void after_trial()
@@ -1524,8 +1564,7 @@ struct Machine {
             request_jac();
             break;
         case PH_JAC:
-            after_jacobian();
-            request_trial();
+            if (after_jacobian()) request_trial();
             break;
         case PH_TRIAL:
             after_trial();
