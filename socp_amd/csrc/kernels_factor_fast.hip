@@ -12,7 +12,8 @@
 //     the panel   a 16-column strip (<= 256 rows) factorised by ONE wavefront in a ROW layout -- a lane owns rows, all 16 columns of a
 //                 row in its registers -- with one batched wave-wide reduction per column (panel_rows, wave_reduce.hpp), V published to
 //                 LDS at the end, then T of  H_j0 .. H_j0+15 = I - V T V^T  (larft's recurrence on the Gram matrix V^T V, one MFMA pass)
-//     qrfac       TWO panels per pass: [A] panel pp; [C] the strip that is panel pp + 1 through panel pp, then factorised; [E] every
+//     qrfac       TWO panels per pass: both strips of the pair into the LDS tiles by all wavefronts (pair_tiles_load); [A] panel pp;
+//                 [C] the strip that is panel pp + 1 through panel pp, then factorised (the vectors go back to A by the idle wavefronts); [E] every
 //                 later 16-column strip (and the one that holds fvec, column n) through BOTH panels in one load / store:
 //                   W = V^T S (MFMA, K = rows)   Y = T^T W (4 MFMA)   S -= V Y (MFMA, K = 16)
 //                 with the strip in registers in the MFMA C/D layout (row = 16 chunk + g + 4 reg, column = lane & 15).  Because a sum
@@ -524,18 +525,107 @@ __device__ __forceinline__ void panel_T(int nch, double tau_mine, const double *
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The pair's two strips through the LDS tiles (round 5, STAGED).  With one wavefront per panel doing everything itself, a panel's
+// 83 000 cycles were 28 000 of column steps and the rest that wavefront loading its strip (15 000: 64 loads per lane behind the other
+// workgroup's traffic), converting, storing the vectors back (10 000) -- while three wavefronts waited.  Here the strips travel
+// through the tiles that will hold V anyway: ALL wavefronts bring both strips of the pair in (a quarter each) before the first
+// panel starts; the panel wavefronts read their strip from LDS; the vectors go back to A from the tiles by the wavefronts that
+// have nothing else to do ([A]'s during [C], [C]'s at the head of the trailing pass).  No register array lives across a barrier.
+template <int NCH>
+__device__ __forceinline__ void pair_tiles_load(double *V0, double *V1, const double *__restrict__ A, int ld, int n, int j0, int nch, bool two, int wave, int lane)
+{
+    lane = here(lane);
+    const int g = lane >> 4, m = lane & 15;
+    const bool ok0 = j0 + m <= n, ok1 = two && j0 + 16 + m <= n;             // (column n = fvec rides along)
+#pragma unroll
+    for (int q = 0; q < (NCH + 3) / 4; q++) {
+        const int cc = wave + 4 * q;                                         // (uniform)
+        if (cc < NCH) {
+            double v0[4] = {0.0, 0.0, 0.0, 0.0}, v1[4] = {0.0, 0.0, 0.0, 0.0};
+            if (cc < nch) {                                                  // (chunks below the matrix: zeros, no loads issued)
+                const double *p = A + (long)(j0 + 16 * cc + g) * ld + j0 + m;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const bool in = j0 + 16 * cc + g + 4 * r < n;
+                    v0[r] = (in && ok0) ? p[0] : 0.0;
+                    v1[r] = (in && ok1) ? p[16] : 0.0;
+                    p += 4L * ld;
+                }
+            }
+            double *t0 = V0 + (16 * cc + g) * kLdV + m, *t1 = V1 + (16 * cc + g) * kLdV + m;
+#pragma unroll
+            for (int r = 0; r < 4; r++) { t0[4 * r * kLdV] = v0[r]; t1[4 * r * kLdV] = v1[r]; }
+        }
+    }
+}
+// a tile's vectors back to A: columns c0 .. c0 + 15 (<= n), rows j0 + 16 first .., chunk cc by share `idx` of `shares` (uniform)
+template <int NCH>
+__device__ __forceinline__ void tile_store(const double *tile, double *__restrict__ A, int ld, int n, int j0, int nch, int c0, int first, int idx, int shares, int lane)
+{
+    lane = here(lane);
+    const int g = lane >> 4, m = lane & 15;
+    if (c0 + m > n) return;
+#pragma unroll
+    for (int q = 0; q < NCH; q++) {
+        const int cc = first + idx + shares * q;                             // (uniform)
+        if (cc < NCH && cc < nch) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = 16 * cc + g + 4 * r;
+                if (j0 + row < n) A[(long)(j0 + row) * ld + c0 + m] = tile[row * kLdV + m];
+            }
+        }
+    }
+}
+// |column|_2 of a tile's 16 columns (pair 0: whole columns), one wavefront: lane = (column, quarter of the rows); strip_column_norm's rule
+template <int NCH>
+__device__ __forceinline__ void tile_column_norms(const double *tile, double *__restrict__ out, int ncols, int lane)
+{
+    lane = here(lane);
+    const int col = lane & 15, part = lane >> 4;
+    const double *p = tile + (part * 4 * NCH) * kLdV + col;
+    double ss = 0.0;
+#pragma unroll 8
+    for (int i = 0; i < 4 * NCH; i++) { const double v = p[i * kLdV]; ss = __builtin_fma(v, v, ss); }
+    ss += __shfl_xor(ss, 16);
+    ss += __shfl_xor(ss, 32);
+    double nrm = ss;
+    if (ss == ss) {
+        if (ss > 1e-280 && ss < 1e280) {
+            nrm = sqrt(ss);
+        } else {
+            double amax = 0.0;
+            for (int i = 0; i < 4 * NCH; i++) amax = fmax(amax, fabs(p[i * kLdV]));
+            amax = fmax(amax, __shfl_xor(amax, 16));
+            amax = fmax(amax, __shfl_xor(amax, 32));
+            nrm = amax;
+            if (amax > 0 && amax < INFINITY) {
+                double s2 = 0.0;
+                for (int i = 0; i < 4 * NCH; i++) { const double x = p[i * kLdV] / amax; s2 += x * x; }
+                s2 += __shfl_xor(s2, 16);
+                s2 += __shfl_xor(s2, 32);
+                nrm = amax * sqrt(s2);
+            }
+        }
+    }
+    if (part == 0 && col < ncols) out[col] = nrm;
+}
+
 // One workgroup of 256 threads per problem.  LDS (doubles): two panels' V[16 NCH][kLdV] and T[256] (qrfac: the panel being applied and
 // the next one being factorised -- look-ahead; qform: the two panels applied in one pass), Gl[256]
 // WPE: wavefronts per SIMD the registers are budgeted for -- 2 for the 16-chunk strip (128 of 256 VGPRs are the strip), more for the
 // smaller strips: the kernel is latency-bound, other problems' wavefronts are what fills its waits
 // PHASE: 0 = the whole refresh in one launch; 1 = qrfac (+ R, Q^T f, the flags) only; 2 = qform only (A/B: SOCP_FACTOR_SPLIT)
-template <int NCH, int WPE, int PHASE = 0>
+// STAGED: the pair's strips travel through the LDS tiles (pair_tiles_load / tile_store above) instead of the panel wavefronts' registers
+template <int NCH, int WPE, int PHASE = 0, bool STAGED = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void factor_fast_kernel(Config c, State *states, double *ws, long ws_stride, const int *__restrict__ list, int count)
 {
     extern __shared__ double lds[];
     constexpr int kPanelDoubles = 16 * NCH * kLdV + 256;
     double *Gl = lds + 2 * kPanelDoubles;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, m = lane & 15;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, g = lane >> 4, m = lane & 15;
+    // (the wavefront's number as the SCALAR it is: which wavefront takes a panel, a chunk, a strip are scalar branches then)
     const int n = c.n, ld = c.ld;
     for (int b = blockIdx.x; b < count; b += gridDim.x) {
         const int p = list[b];
@@ -561,6 +651,82 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             const int j0 = 16 * pp, j1 = j0 + 16, nch = (n - j0 + 15) >> 4;
             const bool two = pp + 1 < npanels;
             const int wa = pp & 3, wb = (pp + 1) & 3;                        // (pp is even: wa in {0, 2}, wb in {1, 3})
+            if constexpr (STAGED) {
+                const unsigned long long t_la = prof.stamp();
+                pair_tiles_load<NCH>(V0, V1, A, ld, n, j0, nch, two, wave, lane);
+                __syncthreads();
+                prof.add(FP_LA_APPLY, t_la);
+                // (pair 0 holds whole columns: the Jacobian's column norms.  A tile is read by the wavefront that will overwrite it, or
+                // before the barrier that lets that wavefront start)
+                if (pp == 0 && two && wave == 3) tile_column_norms<NCH>(V1, acnorm + 16, n - 16, lane);
+                if (wave == wa) {
+                    const int np0 = (n - j0 < 16) ? n - j0 : 16;
+                    if (pp == 0) tile_column_norms<NCH>(V0, acnorm, n, lane);
+                    double P[Rows<NCH>::NQ][16];
+                    const unsigned long long t_cv = prof.stamp();
+                    tile_to_rows<NCH, 0>(P, V0, lane);
+                    wave_lds_fence();
+                    prof.add(FP_LA_CONVERT, t_cv);
+                    const unsigned long long t_cols = prof.stamp();
+                    unsigned alive;
+                    const double tau = panel_rows<NCH>(P, np0, Gl, rdiag + j0, lane, alive);
+                    prof.add(FP_COLS, t_cols);
+                    const unsigned long long t_st = prof.stamp();
+                    r_rows_from_rows(P[0], w.r, w.qtf, n, j0, lane);
+                    rows_to_tile_V<NCH, 0>(P, alive, V0, lane);
+                    wave_lds_fence();
+                    if (lane < np0) w.r[row_off(n, j0 + lane)] = rdiag[j0 + lane];
+                    prof.add(FP_LA_STORE, t_st);
+                    const unsigned long long t_T = prof.stamp();
+                    panel_T<NCH>(nch, tau, V0, T0, Gl, Tsave + 256 * pp, lane);
+                    prof.add(FP_T, t_T);
+                }
+                prof.mark(FP_PANEL);
+                __syncthreads();
+                prof.mark(FP_PANEL_WAIT);
+                if (two) {
+                    if (wave == wb) {
+                        f64x4 S[NCH];
+                        const unsigned long long t_la2 = prof.stamp();
+                        tile_to_strip<NCH>(S, V1, lane);
+                        wave_lds_fence();
+                        strip_apply<NCH>(S, nch, V0, T0, lane);
+                        prof.add(FP_LA_APPLY, t_la2);
+                        const unsigned long long t_cv = prof.stamp();
+                        r_rows_out(S[0], w.r, w.qtf, n, j0, j1, g, m, false);
+                        SOCP_SCHED_FENCE();
+                        double P[Rows<NCH>::NQ][16];
+                        strip_to_tile<NCH, 1>(S, V1, lane);
+                        wave_lds_fence();
+                        tile_to_rows<NCH, 1>(P, V1, lane);
+                        wave_lds_fence();
+                        const int np1 = (n - j1 < 16) ? n - j1 : 16;
+                        prof.add(FP_LA_CONVERT, t_cv);
+                        const unsigned long long t_cols = prof.stamp();
+                        unsigned alive;
+                        const double tau = panel_rows<NCH>(P, np1, Gl, rdiag + j1, lane, alive);
+                        prof.add(FP_COLS, t_cols);
+                        const unsigned long long t_st = prof.stamp();
+                        r_rows_from_rows(P[0], w.r, w.qtf, n, j1, lane);
+                        rows_to_tile_V<NCH, 1>(P, alive, V1, lane);
+                        wave_lds_fence();
+                        if (lane < np1) w.r[row_off(n, j1 + lane)] = rdiag[j1 + lane];
+                        prof.add(FP_LA_STORE, t_st);
+                        const unsigned long long t_T = prof.stamp();
+                        panel_T<NCH>(nch, tau, V1, T1, Gl, Tsave + 256 * (pp + 1), lane);
+                        prof.add(FP_T, t_T);
+                    } else {
+                        // panel pp's vectors back to A (qform reads them from there): the three wavefronts without a panel
+                        tile_store<NCH>(V0, A, ld, n, j0, nch, j0, 0, (wave - wb - 1) & 3, 3, lane);
+                    }
+                    prof.mark(FP_PANEL);
+                    __syncthreads();
+                    prof.mark(FP_PANEL_WAIT);
+                    tile_store<NCH>(V1, A, ld, n, j0, nch, j1, 1, wave, 4, lane);     // (its first chunk: rows of R, zeros in the tile)
+                } else {
+                    tile_store<NCH>(V0, A, ld, n, j0, nch, j0, 0, wave, 4, lane);
+                }
+            } else {
             if (wave == wa) {
                 f64x4 S[NCH];
                 const int np0 = (n - j0 < 16) ? n - j0 : 16;
@@ -640,6 +806,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
                 __syncthreads();
                 prof.mark(FP_PANEL_WAIT);
             }
+            }   // !STAGED
             // [E] the strips right of the panel(s); their first 16 (32) rows leave as rows of R and are not written back
             for (int c0 = j0 + (two ? 32 : 16) + 16 * wave; c0 <= n; c0 += 64) {
                 f64x4 S[NCH];
@@ -758,15 +925,15 @@ hipError_t raise_lds_limit_fast()
     return e;
 }
 
-template <int NCH, int WPE, int PHASE>
+template <int NCH, int WPE, int PHASE, bool STAGED = false>
 hipError_t launch_phase(hipStream_t st, const PoolDev &pool, const int *d_list, int count)
 {
     const size_t lds_bytes = sizeof(double) * (size_t)(2 * (16 * NCH * kLdV + 256) + 256);
     if (lds_bytes > 65536) {
-        const hipError_t raised = raise_lds_limit_fast<factor_fast_kernel<NCH, WPE, PHASE>>();
+        const hipError_t raised = raise_lds_limit_fast<factor_fast_kernel<NCH, WPE, PHASE, STAGED>>();
         if (raised != hipSuccess) return raised;
     }
-    hipLaunchKernelGGL((factor_fast_kernel<NCH, WPE, PHASE>), dim3((unsigned)count), dim3(256), lds_bytes, st, pool.cfg, pool.states, pool.ws, pool.ws_stride, d_list, count);
+    hipLaunchKernelGGL((factor_fast_kernel<NCH, WPE, PHASE, STAGED>), dim3((unsigned)count), dim3(256), lds_bytes, st, pool.cfg, pool.states, pool.ws, pool.ws_stride, d_list, count);
     return hipGetLastError();
 }
 template <int NCH, int WPE>
@@ -777,7 +944,9 @@ hipError_t launch_nch(hipStream_t st, const PoolDev &pool, const int *d_list, in
     // 3.87 -> 3.55 ms at n = 200, 1.38 -> 1.33 ms at 4096 x n = 85 (profiles/r05_factor_split_ab.txt).  SOCP_FACTOR_SPLIT=0: one launch.
     static const bool split = [] { const char *e = std::getenv("SOCP_FACTOR_SPLIT"); return !(e && e[0] == '0'); }();
     if (!split) return launch_phase<NCH, WPE, 0>(st, pool, d_list, count);
-    const hipError_t e = launch_phase<NCH, WPE, 1>(st, pool, d_list, count);
+    // (the pair's strips through the LDS tiles; SOCP_FACTOR_STAGED=0: through the panel wavefronts' registers)
+    static const bool staged = [] { const char *e = std::getenv("SOCP_FACTOR_STAGED"); return !(e && e[0] == '0'); }();
+    const hipError_t e = staged ? launch_phase<NCH, WPE, 1, true>(st, pool, d_list, count) : launch_phase<NCH, WPE, 1>(st, pool, d_list, count);
     return e != hipSuccess ? e : launch_phase<NCH, WPE, 2>(st, pool, d_list, count);
 }
 
