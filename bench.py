@@ -22,8 +22,11 @@ Objects in the JSON line beside the contract's fields (N = 1; `--lean` drops the
                   trajectory, so neither "mfma" nor "hbm" bounds it: the binding resource is FP64 vector issue.
                   `bound` is therefore "valu_fp64" (peak = 256 CU x 4 SIMD x 16 FP64 lanes x 2 flop x 2.4 GHz =
                   78.6 TFLOP/s, half the FP32 vector peak of MI355X_MICROARCH.md); the HBM view the contract asks for
-                  is in roofline.hbm.  `traffic` is NOT measured in this run: it is the PMC figure of the same launch
-                  recorded under profiles/ (`traffic_source` names the file).
+                  is in roofline.hbm.  `traffic` IS measured in this run (N = 1, not --lean): this file runs twice more as a
+                  child process under `rocprofv3 --pmc` (FETCH_SIZE, then WRITE_SIZE; the guide's recipe and corrections) around
+                  two launches of the same kernel at the same size (live_traffic); `traffic_recorded` keeps the figure committed
+                  under profiles/ beside it, and is what `traffic` falls back to if the profiler cannot run
+                  (`traffic_measured_in_this_run`, `traffic_live_measurement` say which).
   exact           the same workload on the bit-identical (reference operation order) flavour -- what a drop-in user gets
                   by default (SOCP_VARIANT_AUTO) -- from a second timed region: value, kernel_ms, roofline frac.
   parity          after the timed regions: FD-batch rows of the first starts recomputed by the CPU oracle (checker, never
@@ -48,7 +51,7 @@ Objects in the JSON line beside the contract's fields (N = 1; `--lean` drops the
                   from the published algorithm / the reference's text).  `predicted` / `expected` from its own one-GPU curve.
   solver_kernels  the sweeps' second kernel with a roofline of its own: factor_fast = 2048 Jacobian refreshes of n = 253 (the factor
                   launch of a config-5 round) on the FP64 matrix cores, HIP-event time, fraction of the FP64 peak; traffic = the
-                  recorded PMC figure (profiles/r05_factor_pmc.json), not measured in this run.
+                  counters of this run as above (its two launches summed), the recorded figure (profiles/r05_factor_pmc.json) beside it.
   cpu_baseline    B1: the reference's own model::ComputeTraj (oracle/_ref, kind "reference") or the C oracle (kind
                   "port") on this box's host cores, bounded sample: `value` = MEDIAN of five samples, `spread`, `best`,
                   `worst`, `samples` beside it (all cores and one core).  cpu_baseline.b0 = "as shipped": the reference's
@@ -104,6 +107,9 @@ def parse_args(argv=None):
     ap.add_argument("--lean", action="store_true",
                     help="N = 1: only the headline timed region, roofline and cpu_baseline (no exact / parity / "
                          "single_problem / north_star_128 legs)")
+    ap.add_argument("--traffic-child", nargs="?", const="headline", default=None, choices=["headline", "factor"],
+                    help="internal (live_traffic): two launches of the headline kernel at the headline size and nothing else -- the program "
+                         "rocprofv3 --pmc runs")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-launched N > 1 job (0: pick a free one)")
     ap.add_argument("--sweep-starts", type=int, default=None,
                     help="the `sweep` leg: a multi-start sweep of this many single-shooting starts IN TOTAL, sharded over the ranks "
@@ -420,6 +426,83 @@ def recorded_traffic(P, variant, rk4_steps):
     return None, None
 
 
+def traffic_child(args):
+    """What `rocprofv3 --pmc <counter> -- python3 bench.py --traffic-child` runs: the headline kernel, same flavour, same size, twice."""
+    import torch
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    if args.traffic_child == "factor":
+        from socp_amd import capi
+        J, b = factor_workload()
+        capi.qr_factor_batch(J, b, flavour=capi.FACTOR_FAST, reps=2, outputs=False, device=0)
+        return 0
+    ctx = setup_context(0, args.rk4_steps, args.variant)
+    P = args.starts
+    d_Z = torch.from_numpy(make_starts(P, seed=20250905)).to(dev)
+    d_rows = torch.empty((P, ROWS, N_UNKNOWN), dtype=torch.float64, device=dev)
+    for _ in range(2):
+        ctx.fd_rows_dev(P, d_Z.data_ptr(), EPSFCN, d_rows.data_ptr())
+    torch.cuda.synchronize(dev)
+    return 0
+
+
+def live_traffic(args, kernel="fdrows_lane_kernel", child="headline", limit_s=150.0):
+    """HBM bytes of one launch of the headline kernel from the PMC counters, measured NOW on this box: this file run twice as a child
+    process under `rocprofv3 --pmc` -- FETCH_SIZE, then WRITE_SIZE, a pass each, no trace domain beside them (the guide's recipe:
+    /opt/skills/guides/MI355X_MICROARCH.md, HBM section; FETCH_SIZE / WRITE_SIZE in KiB, reads doubled on gfx950).  The children are
+    ordinary child processes with a time limit (killed by the process group THIS call started); any failure returns (None, why) and
+    the line keeps the recorded figure.  Not under a profiler (the profiling scripts run bench.py --lean) and at N = 1 only."""
+    import csv
+    import glob
+    import shutil
+    import signal
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="socp_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--traffic-child", child,
+               "--starts", str(args.starts), "--rk4-steps", str(args.rk4_steps), "--variant", args.variant]
+        try:
+            proc = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=d, start_new_session=True,
+                                    env=dict(os.environ, TMPDIR="/tmp"))
+            try:
+                rc = proc.wait(timeout=limit_s)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                proc.wait()
+                return None, "rocprofv3 --pmc %s: no result in %.0f s" % (counter, limit_s)
+            if rc != 0:
+                return None, "rocprofv3 --pmc %s: exit code %d" % (counter, rc)
+            rows = {}                                                        # per kernel NAME (the refresh is two kernels: their sum)
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for r in csv.DictReader(fh):
+                        if kernel in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter:
+                            rows.setdefault(r["Kernel_Name"], []).append((float(r.get("Grid_Size", 0) or 0), float(r["Counter_Value"])))
+            if not rows:
+                return None, "rocprofv3 --pmc %s: no dispatch of %s in its output" % (counter, kernel)
+            top = max(g for v in rows.values() for g, _ in v)                # (the launches over the whole workload, not a warm-up's)
+            total = 0.0
+            for v in rows.values():
+                x = sorted(c for g, c in v if g == top)
+                if x:
+                    total += x[len(x) // 2]
+            vals[counter] = total
+        except Exception as exc:                                             # (a measurement aid must never take the bench line down)
+            return None, "rocprofv3 --pmc %s: %s" % (counter, exc)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return 2.0 * vals["FETCH_SIZE"] * 1024.0 + vals["WRITE_SIZE"] * 1024.0, (
+        "MEASURED IN THIS RUN: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, a pass each, around two launches of the kernel in a child process "
+        "(bench.py --traffic-child); 2 x FETCH_SIZE KiB + WRITE_SIZE KiB, median of the launches")
+
+
 def parity_leg(Z_host, rows_by_variant, rk4_steps, K):
     """FD-batch rows of the first K starts against the CPU oracle (the checker; never inside a timed region)."""
     from oracle import oracle as orc
@@ -494,16 +577,23 @@ def north_star_128(capi, device, rk4_steps, cpu_traj_per_s, p1_traj_per_s=None):
     return out
 
 
-def solver_kernel_rooflines(capi, device):
-    """The roofline of the sweeps' second-largest kernel beside the headline one: the Jacobian refresh of the device solvers in the
-    throughput flavour (kernels_factor_fast.hip, blocked Householder QR on the FP64 matrix cores), 2048 problems of n = 253 -- the
-    factor launch of BASELINE config 5 -- timed with HIP events inside socp_qr_factor_batch.  flop = 8/3 n^3 per problem (qrfac + qform),
-    algorithmic bytes = J in, Q and R out; traffic is the PMC figure recorded under profiles/ (separate --pmc passes)."""
-    n, count = 253, 2048
+def factor_workload(n=253, count=2048):
+    """2048 well-conditioned random Jacobians of n = 253 and their right-hand sides: the factor launch of BASELINE config 5"""
     rng = np.random.default_rng(1)
     J = rng.standard_normal((count, n, n))
     J[:, np.arange(n), np.arange(n)] += 0.5 * np.sqrt(n)
     b = rng.standard_normal((count, n))
+    return J, b
+
+
+def solver_kernel_rooflines(capi, device, args=None, live=False):
+    """The roofline of the sweeps' second-largest kernel beside the headline one: the Jacobian refresh of the device solvers in the
+    throughput flavour (kernels_factor_fast.hip, blocked Householder QR on the FP64 matrix cores), 2048 problems of n = 253 -- the
+    factor launch of BASELINE config 5 -- timed with HIP events inside socp_qr_factor_batch.  flop = 8/3 n^3 per problem (qrfac + qform),
+    algorithmic bytes = J in, Q and R out; traffic = the PMC counters of this run (live_traffic, child mode `factor`) or, failing that, the figure
+    recorded under profiles/ (separate --pmc passes)."""
+    n, count = 253, 2048
+    J, b = factor_workload()
     capi.qr_factor_batch(J[:8], b[:8], flavour=capi.FACTOR_FAST, outputs=False, device=device)
     ms = capi.qr_factor_batch(J, b, flavour=capi.FACTOR_FAST, reps=3, outputs=False, device=device)["kernel_ms"]
     flop = 8.0 / 3.0 * n ** 3 * count
@@ -516,11 +606,20 @@ def solver_kernel_rooflines(capi, device):
             traffic, source = rec["hbm_bytes"], "profiles/r05_factor_pmc.json (RECORDED: 2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes)"
     except Exception:
         pass
+    recorded = {"bytes": traffic, "source": source}
+    measured, note = False, "not attempted"
+    if live and args is not None:
+        got, why = live_traffic(args, kernel="factor_fast_kernel", child="factor")
+        if got is not None:
+            traffic, source, measured, note = got, why.replace("two launches of the kernel", "two refreshes (a qrfac and a qform launch each: their sum)"), True, "ok"
+        else:
+            note = why
     tflops = flop / (ms * 1e-3) / 1e12
     return {"factor_fast": {"workload": "2048 Jacobian refreshes of n = 253 (qrfac + Q^T f + R + qform), throughput flavour", "kernel": "factor_fast_kernel<16, 2, 1> (qrfac) + factor_fast_kernel<16, 2, 2> (qform), two launches",
                             "kernel_ms": ms, "roofline": {"bound": "mfma_fp64", "achieved": tflops, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": tflops / PEAK_FP64_TFLOPS,
                                                           "algorithmic_bytes": alg, "traffic": traffic, "traffic_over_algorithmic": traffic / alg if traffic else None,
-                                                          "traffic_source": source, "traffic_measured_in_this_run": False}}}
+                                                          "traffic_source": source, "traffic_measured_in_this_run": measured, "traffic_live_measurement": note,
+                                                          "traffic_recorded": recorded}}}
 
 
 def predict_wall(curve, starts):
@@ -653,6 +752,8 @@ def sweep_leg(torch, dist, capi, args, world, rank, local_rank, dev, use_dist, t
 
 def main():
     args = parse_args()
+    if args.traffic_child:
+        sys.exit(traffic_child(args))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))            # nothing above has touched the GPU (torch is not even imported yet)
 
@@ -743,7 +844,15 @@ def main():
         total_traj = traj_per_step_rank * world * args.steps
         value = total_traj / elapsed_max
         tflops, gbs = roofline_of(traj_per_step_rank, kernel_ms, args.rk4_steps)
-        traffic, traffic_source = recorded_traffic(P, args.variant, args.rk4_steps)
+        rec_traffic, rec_source = recorded_traffic(P, args.variant, args.rk4_steps)
+        traffic, traffic_source, traffic_live = rec_traffic, rec_source, False
+        live_note = "not attempted (N > 1, --lean, under a profiler, or SOCP_BENCH_LIVE_PMC=0)"
+        if world == 1 and not args.lean and os.environ.get("SOCP_BENCH_LIVE_PMC", "1") != "0" and "rocprof" not in os.environ.get("LD_PRELOAD", ""):
+            got, why = live_traffic(args)
+            if got is not None:
+                traffic, traffic_source, traffic_live, live_note = got, why, True, "ok"
+            else:
+                live_note = why
         smooth = GODDARD_PARAMS[6] > 0
         # VGPR budget -> waves per SIMD the launcher may use: fast smooth law 156 VGPRs (3), fast general law 252-254 (2),
         # exact 248 (2) -- socp_amd/csrc/launch.hpp picks min(that, ceil(waves / 1024))
@@ -765,7 +874,8 @@ def main():
                          "frac": tflops / PEAK_FP64_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "fdrows_lane_kernel", "kernel_ms": kernel_ms,
                          "flop_per_trajectory": FLOP_PER_RK4_STEP * args.rk4_steps, "flop_per_rk4_step": FLOP_PER_RK4_STEP,
-                         "traffic_measured_in_this_run": False,
+                         "traffic_measured_in_this_run": traffic_live, "traffic_live_measurement": live_note,
+                         "traffic_recorded": {"bytes": rec_traffic, "source": rec_source},
                          "hbm": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                  "frac": gbs / PEAK_HBM_GBS, "bytes_per_trajectory": BYTES_PER_TRAJ}},
             # Newton-level rates: with M = 1 a residual evaluation is one trajectory, and a forward-difference
@@ -862,7 +972,7 @@ def main():
             out["north_star_128"] = north_star_128(capi, local_rank, args.rk4_steps, cpu_v, p1_v)
             if cpu_v:
                 out["north_star_128"]["cpu_baseline_value"] = cpu_v
-            out["solver_kernels"] = solver_kernel_rooflines(capi, local_rank)
+            out["solver_kernels"] = solver_kernel_rooflines(capi, local_rank, args, live=traffic_live)   # (live where the headline's measurement worked)
         sys.stdout.flush()
         os.write(record_fd, (json.dumps(out) + "\n").encode())
 
