@@ -69,6 +69,38 @@ def test_fast_factor_special_columns():
     assert np.max(np.abs(fa["Q"][1] @ fa["R"][1] - J[1])) <= 1e-12 * np.linalg.norm(J[1])
 
 
+_AB_FORM = r"""
+import numpy as np
+from socp_amd import capi
+for n in (39, 64, 85, 127, 200, 253, 256):
+    rng = np.random.default_rng(100 + n)
+    J = rng.standard_normal((3, n, n)); J[:, np.arange(n), np.arange(n)] += 0.5 * np.sqrt(n)
+    J[1][:, 3] = 0.0; J[2][:, n // 2] *= 1e-170                      # a zero column, a tiny one: the rescaling path of the panel
+    b = rng.standard_normal((3, n))
+    ex = capi.qr_factor_batch(J, b, flavour=capi.FACTOR_EXACT)
+    fa = capi.qr_factor_batch(J, b, flavour=capi.FACTOR_FAST)
+    scale = np.linalg.norm(J, axis=(1, 2))[:, None, None]
+    assert np.max(np.abs(fa["Q"] @ fa["R"] - J) / scale) <= 1e-13, n
+    assert np.max(np.abs(np.transpose(fa["Q"], (0, 2, 1)) @ fa["Q"] - np.eye(n)[None])) <= 1e-13 * n, n
+    assert np.max(np.abs(fa["R"] - ex["R"]) / scale) <= 1e-11 and np.max(np.abs(fa["qtb"] - ex["qtb"])) <= 1e-11 * np.max(np.abs(b)) * np.sqrt(n), n
+    assert np.max(np.abs(fa["acnorm"] - ex["acnorm"]) / np.maximum(ex["acnorm"], 1e-300)) <= 1e-12, n
+print("forms ok")
+"""
+
+
+@pytest.mark.parametrize("env", [{"SOCP_FACTOR_STAGED": "0"}, {"SOCP_FACTOR_SPLIT": "0"}], ids=["strips_through_registers", "one_launch"])
+def test_the_other_forms_of_the_refresh_stay_correct(env):
+    """The kernel keeps its earlier forms behind switches for A/B (SOCP_FACTOR_STAGED=0: the pair's strips through the panel wavefronts'
+    registers; SOCP_FACTOR_SPLIT=0: qrfac and qform in one launch).  The switches are read once per process: a child process per form,
+    the same bars as above, special columns included."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", _AB_FORM], capture_output=True, text=True, timeout=300, cwd=root, env=dict(os.environ, **env))
+    assert out.returncode == 0 and "forms ok" in out.stdout, (out.stdout[-1500:], out.stderr[-1500:])
+
+
 def test_fast_factor_refuses_sizes_it_is_not_built_for():
     from socp_amd import capi
     for n in (14, 32, 33, 38, 257):
