@@ -23,7 +23,7 @@
 //     qform       Q = (I - V_0 T_0 V_0^T) ... (I - V_last T_last V_last^T) I: a strip of Q STAYS in a wavefront's registers (it starts
 //                 as identity columns) while every panel that reaches it streams through LDS, last panel first; never read, written once.
 //
-// Two launches per refresh: qrfac (PHASE 1), then qform (PHASE 2).  HBM traffic at n = 253: 4.4 x the algorithmic bytes (round 4:
+// Two launches per refresh: qrfac (PHASE 1), then qform (PHASE 2).  HBM traffic at n = 253: 4.2 x the algorithmic bytes (round 4:
 // 8.3 x; the order-preserving kernel: 130 x).  Results differ from the
 // order-preserving kernel at rounding level; the engine uses this kernel only when asked for the throughput flavour
 // (SOCP_SOLVER_DEVICE_FAST, or AUTO on a throughput-flavour context).
@@ -192,8 +192,13 @@ __device__ __forceinline__ void r_rows_out(const f64x4 &top, double *__restrict_
 // chunk still computes, and each pass pays an LDS round trip per chunk -- measured: 6 000 cycles per column of the panel, most of
 // the kernel.  Chunks of a block beyond the last row compute on zeros (the strip's registers and V's rows there are zero).  The
 // block also bounds what the scheduler may hoist: 4 kBlk operands in flight beside the strip's 4 NCH registers.
+// Two chunks per block (round 5; round 4 measured four as best, with the lane-mask branches of that kernel): eight operands in flight
+// are enough to cover the LDS round trip, a strip whose chunk count is not a multiple of four computes on fewer zero chunks
+// (n = 200: 13 chunks -> 14 instead of 16), and qform spills 37 registers instead of 53.  2048 x n = 253: 4.66 -> 4.46 ms,
+// n = 200: 3.33 -> 3.07 ms; one chunk per block 4.58 / 3.10, three 4.58 / 3.19, eight 5.76 / 3.97 (profiles/r05_factor_blk_ab.txt).
+// (Reading the NEXT block's operands while this block's products run -- two register sets, written out by hand -- is slower: 4.65 ms.)
 #ifndef SOCP_FACTOR_BLK
-#define SOCP_FACTOR_BLK 4
+#define SOCP_FACTOR_BLK 2
 #endif
 constexpr int kBlk = SOCP_FACTOR_BLK;
 #define SOCP_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
