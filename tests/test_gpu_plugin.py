@@ -174,6 +174,9 @@ def _guarded(torch, rows, n, guard=64):
     """a device buffer of `rows` x n doubles with `guard` rows of a sentinel bit pattern before and after it"""
     sent = np.float64(-7.25e300)
     buf = torch.full(((rows + 2 * guard) * n,), float(sent), dtype=torch.float64, device="cuda")
+    # (the fill runs on torch's stream, the kernels under test on the context's own, non-blocking one: without this the fill can land
+    # AFTER a kernel's stores and the rows "keep" the sentinel -- seen once in five runs of the suite)
+    torch.cuda.synchronize()
     return buf, buf[guard * n:(guard + rows) * n], sent
 
 
