@@ -446,7 +446,7 @@ def traffic_child(args):
     return 0
 
 
-def live_traffic(args, kernel="fdrows_lane_kernel", child="headline", limit_s=150.0):
+def live_traffic(args, kernel="fdrows_lane_kernel", child="headline", limit_s=90.0):
     """HBM bytes of one launch of the headline kernel from the PMC counters, measured NOW on this box: this file run twice as a child
     process under `rocprofv3 --pmc` -- FETCH_SIZE, then WRITE_SIZE, a pass each, no trace domain beside them (the guide's recipe:
     /opt/skills/guides/MI355X_MICROARCH.md, HBM section; FETCH_SIZE / WRITE_SIZE in KiB, reads doubled on gfx950).  The children are
