@@ -608,18 +608,29 @@ def solver_kernel_rooflines(capi, device, args=None, live=False):
         pass
     recorded = {"bytes": traffic, "source": source}
     measured, note = False, "not attempted"
-    if live and args is not None:
-        got, why = live_traffic(args, kernel="factor_fast_kernel", child="factor")
-        if got is not None:
-            traffic, source, measured, note = got, why.replace("two launches of the kernel", "two refreshes (a qrfac and a qform launch each: their sum)"), True, "ok"
-        else:
-            note = why
     tflops = flop / (ms * 1e-3) / 1e12
-    return {"factor_fast": {"workload": "2048 Jacobian refreshes of n = 253 (qrfac + Q^T f + R + qform), throughput flavour", "kernel": "factor_fast_kernel<16, 2, 1> (qrfac) + factor_fast_kernel<16, 2, 2> (qform), two launches",
-                            "kernel_ms": ms, "roofline": {"bound": "mfma_fp64", "achieved": tflops, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": tflops / PEAK_FP64_TFLOPS,
-                                                          "algorithmic_bytes": alg, "traffic": traffic, "traffic_over_algorithmic": traffic / alg if traffic else None,
-                                                          "traffic_source": source, "traffic_measured_in_this_run": measured, "traffic_live_measurement": note,
-                                                          "traffic_recorded": recorded}}}
+    rec = {"factor_fast": {"workload": "2048 Jacobian refreshes of n = 253 (qrfac + Q^T f + R + qform), throughput flavour", "kernel": "factor_fast_kernel<16, 2, 1> (qrfac) + factor_fast_kernel<16, 2, 2> (qform), two launches",
+                           "kernel_ms": ms, "roofline": {"bound": "mfma_fp64", "achieved": tflops, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": tflops / PEAK_FP64_TFLOPS,
+                                                         "algorithmic_bytes": alg, "traffic": traffic, "traffic_over_algorithmic": traffic / alg if traffic else None,
+                                                         "traffic_source": source, "traffic_measured_in_this_run": measured, "traffic_live_measurement": note,
+                                                         "traffic_recorded": recorded}}}
+    if live and args is not None:
+        solver_kernel_live_traffic(rec, args)
+    return rec
+
+
+def solver_kernel_live_traffic(rec, args):
+    """The refresh's HBM traffic measured in this run (two more child runs under rocprofv3 --pmc) written into the record
+    solver_kernel_rooflines made.  Called after EVERY timed leg of the line: a profiler child takes the card for up to
+    90 s and may leave clocks or power state different, so no timed figure may come after one."""
+    r = rec["factor_fast"]["roofline"]
+    got, why = live_traffic(args, kernel="factor_fast_kernel", child="factor")
+    if got is not None:
+        r["traffic"], r["traffic_measured_in_this_run"], r["traffic_live_measurement"] = got, True, "ok"
+        r["traffic_source"] = why.replace("two launches of the kernel", "two refreshes (a qrfac and a qform launch each: their sum)")
+        r["traffic_over_algorithmic"] = got / r["algorithmic_bytes"]
+    else:
+        r["traffic_live_measurement"] = why
 
 
 def predict_wall(curve, starts):
@@ -845,14 +856,11 @@ def main():
         value = total_traj / elapsed_max
         tflops, gbs = roofline_of(traj_per_step_rank, kernel_ms, args.rk4_steps)
         rec_traffic, rec_source = recorded_traffic(P, args.variant, args.rk4_steps)
+        # (the line is built with the figure recorded under profiles/; the in-run PMC measurement -- child processes under rocprofv3 --
+        # replaces it at the very end, after every timed leg: ADVICE r5)
         traffic, traffic_source, traffic_live = rec_traffic, rec_source, False
         live_note = "not attempted (N > 1, --lean, under a profiler, or SOCP_BENCH_LIVE_PMC=0)"
-        if world == 1 and not args.lean and os.environ.get("SOCP_BENCH_LIVE_PMC", "1") != "0" and "rocprof" not in os.environ.get("LD_PRELOAD", ""):
-            got, why = live_traffic(args)
-            if got is not None:
-                traffic, traffic_source, traffic_live, live_note = got, why, True, "ok"
-            else:
-                live_note = why
+        want_live = world == 1 and not args.lean and os.environ.get("SOCP_BENCH_LIVE_PMC", "1") != "0" and "rocprof" not in os.environ.get("LD_PRELOAD", "")
         smooth = GODDARD_PARAMS[6] > 0
         # VGPR budget -> waves per SIMD the launcher may use: fast smooth law 156 VGPRs (3), fast general law 252-254 (2),
         # exact 248 (2) -- socp_amd/csrc/launch.hpp picks min(that, ceil(waves / 1024))
@@ -972,7 +980,17 @@ def main():
             out["north_star_128"] = north_star_128(capi, local_rank, args.rk4_steps, cpu_v, p1_v)
             if cpu_v:
                 out["north_star_128"]["cpu_baseline_value"] = cpu_v
-            out["solver_kernels"] = solver_kernel_rooflines(capi, local_rank, args, live=traffic_live)   # (live where the headline's measurement worked)
+            out["solver_kernels"] = solver_kernel_rooflines(capi, local_rank, args, live=False)
+        if want_live:
+            # every timed figure of the line exists now: the profiler children may have the card
+            got, why = live_traffic(args)
+            rl = out["roofline"]
+            if got is not None:
+                rl["traffic"], rl["traffic_source"], rl["traffic_measured_in_this_run"], rl["traffic_live_measurement"] = got, why, True, "ok"
+                if "solver_kernels" in out:
+                    solver_kernel_live_traffic(out["solver_kernels"], args)      # (live where the headline's measurement worked)
+            else:
+                rl["traffic_live_measurement"] = why
         sys.stdout.flush()
         os.write(record_fd, (json.dumps(out) + "\n").encode())
 

@@ -160,7 +160,11 @@ typedef struct socp_chain_stats {
  * if none converged) -- for SOCP_CHAIN_PLAIN the final iterate whatever info says, as socp_multistart_solve returns it;
  * info / nfev_last of the last solve; nfev_total and solves over the chain; b_reached = largest homotopy value solved
  * (1 = goal reached); param_final = the moving parameter at exit (the reference leaves Rdata there); fnorm = |F| of the last
- * solve's final iterate. */
+ * solve's final iterate.
+ * Return value SOCP_OK: every output array is written for all P chains.  ANY OTHER return value: the contents of the output arrays
+ * are UNDEFINED (a call whose chains run as groups may have written the rows of the groups that finished before another failed --
+ * e.g. an explicit SOCP_SOLVER_DEVICE whose second group could not allocate returns SOCP_ERR_HIP with the first group's rows
+ * written) and the context's trajectory / launch counters include whatever ran before the failure. */
 int socp_chains_solve(struct socp_ctx *ctx, int P, const socp_chain_options *opt, const double *Z0, const double *params,
                       const double *goal, const double *time_prev, const double *x_prev, const double *time_goal,
                       const double *x_goal, double *Zout, int *info, int *nfev_last, int *nfev_total, int *solves,
@@ -175,7 +179,8 @@ int socp_chains_solve_ex(struct socp_ctx *ctx, int P, const socp_chain_options *
  * allocation per call (32 GB + 1.8 GB for 4 M chains of n = 14; 26 GB for 16 384 of n = 253).  They are KEPT for the next call on that
  * device instead of being returned (up to FOUR pairs per device -- one per workspace slot: chain groups of one call run side by side,
  * each on its own pair --, grown when a call needs more, never shrunk; a call can only take the pair of its own slot, so when an
- * allocation fails the idle pairs of the device's other slots are released and it is tried once more): returning and taking tens of GB
+ * allocation fails the idle blocks OF THE SAME KIND -- device memory or pinned memory, whichever could not be had -- of the device's
+ * slots are released and it is tried once more): returning and taking tens of GB
  * costs 0.7-1 s per call on this platform -- freed device memory is cleared before it is handed out again, and an allocation that
  * follows a large free waits for that (measured: a 4.3 GB arena 756 ms after a 32 GB one was freed, 0.4 ms otherwise).  A second
  * engine call on the same device while the first is running takes private allocations.  SOCP_WORKSPACE_CACHE=0 turns the keeping

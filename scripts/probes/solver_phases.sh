@@ -1,7 +1,9 @@
 #!/bin/bash
-# Per-phase clock totals of the device solver (a -DSOCP_SOLVER_PROFILE build of the library must be in place):
+# Per-phase clock totals of the device solver with the bit-equal solvers (a -DSOCP_SOLVER_PROFILE build of the library, selected with
+# SOCP_LIB_PATH -- scripts/variant_build.sh builds one; never copied over the product library):
 #   bash scripts/probes/solver_phases.sh [<library.so>]
-[ -n "$1" ] && cp "$1" socp_amd/_build/libsocp_hip.so
+cd "$(dirname "$0")/../.."
+export SOCP_LIB_PATH=${1:-$(bash scripts/variant_build.sh prof_solver SOLVER_DEFS=-DSOCP_SOLVER_PROFILE)} || exit 1
 export SOCP_MULTISTART_TRACE=1
 for w in "--starts 4096 --continuation kd --rk4-steps 10" "--starts 4096 --segments 9 --rk4-steps 10000" "--model interceptor --starts 2048" "--model interceptor --starts 256"; do
   echo "== $w"

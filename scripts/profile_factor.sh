@@ -71,10 +71,7 @@ json.dump(out, open("gpurun_out/%s_factor_pmc.json" % tag, "w"), indent=1)
 print(json.dumps(out))
 PY
 unset SOCP_MEASURE_ONLY
-touch socp_amd/csrc/kernels_factor_fast.hip
-make -s -C socp_amd/csrc FACTOR_DEFS=-DSOCP_FACTOR_PROFILE > /dev/null 2>&1
-SOCP_MULTISTART_TRACE=1 SOCP_MEASURE_ONLY=fast $M 2>&1 | grep -E "clock ticks|inside wave|kernel_ms" | cut -c1-600 > $OUT/${TAG}_factor_phases.txt; cat $OUT/${TAG}_factor_phases.txt
 rm -rf $OUT/pf_*
-# restore the product build (a profile build left behind would be what every later step of the same call measures)
-touch socp_amd/csrc/kernels_factor_fast.hip
-make -s -C socp_amd/csrc > /dev/null 2>&1
+# 3. the phase clocks: a profile build in its own directory, selected with SOCP_LIB_PATH (the product library is never rebuilt in place)
+bash scripts/factor_phases.sh "$TAG" "$N" "$COUNT" > /dev/null
+cat $OUT/${TAG}_factor_phases.txt

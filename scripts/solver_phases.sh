@@ -1,14 +1,16 @@
 #!/bin/bash
 # Per-phase clock totals of the device solver's kernels in the sweeps it is measured on (on the GPU box, through gpurun):
 #   bash scripts/solver_phases.sh <tag> [solver = device_fast]
-# Builds kernels_solver with -DSOCP_SOLVER_PROFILE (thread 0 of every workgroup adds the ticks between marks to per-phase totals),
-# runs the sweeps with the engine's trace on, restores the product build.  -> gpurun_out/<tag>_solver_phases.txt
+# A -DSOCP_SOLVER_PROFILE build (thread 0 of every workgroup adds the ticks between marks to per-phase totals) in ITS OWN DIRECTORY
+# (scripts/variant_build.sh -> socp_amd/_build_prof_solver), selected with SOCP_LIB_PATH: the product library in socp_amd/_build is
+# never touched, so a run killed at a time limit cannot leave a profiling build behind for later steps.
+# -> gpurun_out/<tag>_solver_phases.txt
 export TMPDIR=/tmp
 cd "$(dirname "$0")/.."
-TAG=${1:-r05}; SOLVER=${2:-device_fast}
+TAG=${1:-r06}; SOLVER=${2:-device_fast}
 OUT=gpurun_out; mkdir -p $OUT
-touch socp_amd/csrc/kernels_solver.hip
-make -s -C socp_amd/csrc SOLVER_DEFS="-DSOCP_SOLVER_PROFILE $SOLVER_EXTRA" > /dev/null 2>&1
+LIB=$(bash scripts/variant_build.sh prof_solver SOLVER_DEFS="-DSOCP_SOLVER_PROFILE $SOLVER_EXTRA") || { echo "solver_phases.sh: the profile build failed"; exit 1; }
+export SOCP_LIB_PATH=$LIB
 export SOCP_MULTISTART_TRACE=1
 {
 for w in "--model interceptor --starts 2048" "--starts 4096 --continuation kd --rk4-steps 10" "--starts 4096 --segments 9 --rk4-steps 10"; do
@@ -17,6 +19,3 @@ for w in "--model interceptor --starts 2048" "--starts 4096 --continuation kd --
 done
 } > $OUT/${TAG}_solver_phases.txt
 cat $OUT/${TAG}_solver_phases.txt
-unset SOCP_MULTISTART_TRACE
-touch socp_amd/csrc/kernels_solver.hip
-make -s -C socp_amd/csrc SOLVER_DEFS="$SOLVER_EXTRA" > /dev/null 2>&1

@@ -216,6 +216,9 @@ extern "C" int socp_chains_solve_ex(socp_ctx *ctx, int P, const socp_chain_optio
                 std::vector<socp_chain_stats> gst(G);
                 std::vector<socp_ctx *> gctx(G, nullptr);
                 gctx[0] = ctx;
+                // (group 0 runs on `ctx` itself: what it counts is taken back below when AUTO repeats every chain on the host engine)
+                long long traj_before = 0, launches_before = 0;
+                socp_ctx_counters(ctx, &traj_before, &launches_before);
                 for (int g = 1; g < G && rc == SOCP_OK; g++) rc = socp_ctx_clone(ctx, socp_ctx_device(ctx), &gctx[g]);
                 if (rc == SOCP_OK) {
                     auto work = [&](int g) {
@@ -247,6 +250,12 @@ extern "C" int socp_chains_solve_ex(socp_ctx *ctx, int P, const socp_chain_optio
                         socp_ctx_add_counters(ctx, traj, launches);
                     }
                     socp_ctx_destroy(gctx[g]);
+                }
+                if (rc == kDeviceEngineAllocFailed) {
+                    // ... and neither are group 0's, which ran on `ctx`: its counters go back to where the call found them
+                    long long traj_now = 0, launches_now = 0;
+                    socp_ctx_counters(ctx, &traj_now, &launches_now);
+                    socp_ctx_add_counters(ctx, traj_before - traj_now, launches_before - launches_now);
                 }
                 if (stats && rc == SOCP_OK) {
                     std::memset(stats, 0, sizeof(*stats));

@@ -65,31 +65,32 @@ bool keep_workspaces()
 }
 hipError_t raw_alloc_once(void **p, size_t bytes, bool host) { return host ? hipHostMalloc(p, bytes, hipHostMallocDefault) : hipMalloc(p, bytes); }
 void raw_free(void *p, bool host) { if (p) (void)(host ? hipHostFree(p) : hipFree(p)); }
-// the idle kept blocks of `device` (every slot nobody is using), device and pinned: freed.  Returns the bytes given back.
-double release_idle_blocks(int device)
+// the idle kept blocks of `device` (every slot nobody is using) of ONE kind -- device memory or pinned host memory, the kind whose
+// allocation has just failed: freed.  Returns the bytes given back.  (Freeing the other kind gives the failed allocation nothing: a
+// pinned block returns no device memory, and this call's own idle pinned block would be re-pinned a moment later -- GBs, ~1 s.)
+double release_idle_blocks(int device, bool host)
 {
     Workspaces &w = workspaces();
     std::lock_guard<std::mutex> lock(w.m);
     double freed = 0;
-    for (int host = 0; host < 2; host++)
-        for (auto &kv : host ? w.host : w.dev) {
-            KeptBlock &b = kv.second;
-            if (kv.first / kSlotsPerDevice != device || b.busy || !b.p) continue;
-            raw_free(b.p, host != 0);
-            freed += (double)b.cap;
-            b.p = nullptr; b.cap = 0;
-        }
+    for (auto &kv : host ? w.host : w.dev) {
+        KeptBlock &b = kv.second;
+        if (kv.first / kSlotsPerDevice != device || b.busy || !b.p) continue;
+        raw_free(b.p, host);
+        freed += (double)b.cap;
+        b.p = nullptr; b.cap = 0;
+    }
     return freed;
 }
 // An allocation for the engine on the CURRENT device.  A call can only take the kept block of its own slot (Arena::alloc), so the
 // idle blocks of the device's OTHER slots -- tens of GB after a two-group sweep of millions of starts -- are memory it cannot use but
-// that stands in its way: when the allocation fails they are released and it is tried once more.
+// that stands in its way: when the allocation fails the idle blocks of the SAME kind are released and it is tried once more.
 hipError_t raw_alloc(void **p, size_t bytes, bool host, int device)
 {
     hipError_t e = raw_alloc_once(p, bytes, host);
     if (e == hipSuccess) return e;
     (void)hipGetLastError();
-    if (release_idle_blocks(device) <= 0) return e;
+    if (release_idle_blocks(device, host) <= 0) return e;
     e = raw_alloc_once(p, bytes, host);
     if (e != hipSuccess) (void)hipGetLastError();
     return e;

@@ -132,14 +132,31 @@ def goddard_north_star_128_problem(ctx, M=9):
     return n, z, mode_t, mode_x, tn, X
 
 
-def single_tensor_gather(dist):
-    """Whether the gather runs as all_gather_into_tensor: the function exists in this torch build and the backend implements it (nccl =
-    RCCL does; gloo does from torch 2.x on CPU tensors; SOCP_SWEEP_GATHER=list forces the list form).  The same answer on every rank."""
-    if os.environ.get("SOCP_SWEEP_GATHER") == "list":
+def torch_at_least(major, minor):
+    """The running torch build is at least major.minor (local version tags such as +rocm7.0 ignored; unparsable: False)."""
+    import re
+    import torch
+    m = re.match(r"(\d+)\.(\d+)", getattr(torch, "__version__", ""))
+    return bool(m) and (int(m.group(1)), int(m.group(2))) >= (major, minor)
+
+
+def single_tensor_gather(dist, device_type="cpu"):
+    """Whether the gather runs as all_gather_into_tensor.  Decided from facts every rank shares -- the torch build, the process group's
+    backend, where the collective's buffers live -- so the answer is the same on every rank:
+    nccl (= RCCL) implements it; gloo does from torch 2.1 on and for CPU tensors only (older builds HAVE the function but
+    ProcessGroupGloo raises "no support for _allgather_base"), anything else takes the list form.
+    SOCP_SWEEP_GATHER=list forces the list form, SOCP_SWEEP_GATHER=tensor the single-tensor one."""
+    forced = os.environ.get("SOCP_SWEEP_GATHER")
+    if forced == "list":
         return False
     if not hasattr(dist, "all_gather_into_tensor"):
         return False
-    return dist.get_backend() in ("nccl", "gloo")
+    if forced == "tensor":
+        return True
+    backend = dist.get_backend()
+    if backend == "nccl":
+        return True
+    return backend == "gloo" and device_type == "cpu" and torch_at_least(2, 1)
 
 
 def run_sweep(Z0, solve_local, dist=None, device=None):
@@ -166,8 +183,13 @@ def run_sweep(Z0, solve_local, dist=None, device=None):
     # out-of-memory condition) would send that rank into a different collective than its peers, and the job would hang.
     # Communication errors propagate.
     full = torch.empty((world * kmax, n + 3), dtype=torch.float64, device=buf.device)
-    if single_tensor_gather(dist):
-        dist.all_gather_into_tensor(full, buf)
+    if single_tensor_gather(dist, buf.device.type):
+        try:
+            dist.all_gather_into_tensor(full, buf)
+        except RuntimeError as exc:
+            # NOT a fallback (see above: a rank must never change the collective's form on its own) -- only the way out named
+            raise RuntimeError("%s  [socp_amd.sweep: the single-tensor gather failed on backend %s; SOCP_SWEEP_GATHER=list on every "
+                               "rank selects the list form]" % (exc, dist.get_backend())) from exc
     else:
         parts = [torch.empty_like(buf) for _ in range(world)]
         dist.all_gather(parts, buf)

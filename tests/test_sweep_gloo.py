@@ -120,8 +120,19 @@ def test_the_gather_form_is_decided_without_communicating():
             return self._b
     assert sweep.single_tensor_gather(FakeDist("nccl", True)) and sweep.single_tensor_gather(FakeDist("gloo", True))
     assert not sweep.single_tensor_gather(FakeDist("nccl", False)) and not sweep.single_tensor_gather(FakeDist("mpi", True))
+    # gloo: CPU buffers only, and only on a torch build whose ProcessGroupGloo implements the single-tensor form
+    assert sweep.single_tensor_gather(FakeDist("nccl", True), "cuda") and not sweep.single_tensor_gather(FakeDist("gloo", True), "cuda")
+    real = sweep.torch_at_least
+    try:
+        sweep.torch_at_least = lambda major, minor: False                 # an old build that HAS the attribute
+        assert not sweep.single_tensor_gather(FakeDist("gloo", True)) and sweep.single_tensor_gather(FakeDist("nccl", True))
+    finally:
+        sweep.torch_at_least = real
+    assert sweep.torch_at_least(2, 1) and not sweep.torch_at_least(99, 0)
     os.environ["SOCP_SWEEP_GATHER"] = "list"
     try:
         assert not sweep.single_tensor_gather(FakeDist("nccl", True))
+        os.environ["SOCP_SWEEP_GATHER"] = "tensor"
+        assert sweep.single_tensor_gather(FakeDist("mpi", True)) and not sweep.single_tensor_gather(FakeDist("mpi", False))
     finally:
         del os.environ["SOCP_SWEEP_GATHER"]
