@@ -656,7 +656,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             const int j0 = 16 * pp, j1 = j0 + 16, nch = (n - j0 + 15) >> 4;
             const bool two = pp + 1 < npanels;
             const int wa = pp & 3, wb = (pp + 1) & 3;                        // (pp is even: wa in {0, 2}, wb in {1, 3})
+#if defined(SOCP_FACTOR_PROBE) && SOCP_FACTOR_PROBE == 1
+            // TIMING PROBE (results are garbage): the trailing passes alone -- what a trailing-only launch would cost
+            if (pp == 0) { for (int i = tid; i < 2 * kPanelDoubles; i += 256) lds[i] = 0.0; __syncthreads(); }
+            if constexpr (false) {
+#else
             if constexpr (STAGED) {
+#endif
                 const unsigned long long t_la = prof.stamp();
                 pair_tiles_load<NCH>(V0, V1, A, ld, n, j0, nch, two, wave, lane);
                 __syncthreads();
@@ -732,6 +738,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
                     tile_store<NCH>(V0, A, ld, n, j0, nch, j0, 0, wave, 4, lane);
                 }
             } else {
+#if defined(SOCP_FACTOR_PROBE) && SOCP_FACTOR_PROBE == 1
+            if constexpr (false) {
+#endif
             if (wave == wa) {
                 f64x4 S[NCH];
                 const int np0 = (n - j0 < 16) ? n - j0 : 16;
@@ -812,6 +821,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
                 prof.mark(FP_PANEL_WAIT);
             }
             }   // !STAGED
+#if defined(SOCP_FACTOR_PROBE) && SOCP_FACTOR_PROBE == 1
+            }
+#endif
+#if defined(SOCP_FACTOR_PROBE) && SOCP_FACTOR_PROBE == 2
+            if (false)            // TIMING PROBE (results are garbage): the panel phases alone
+#endif
             // [E] the strips right of the panel(s); their first 16 (32) rows leave as rows of R and are not written back
             for (int c0 = j0 + (two ? 32 : 16) + 16 * wave; c0 <= n; c0 += 64) {
                 f64x4 S[NCH];
