@@ -617,15 +617,210 @@ __device__ __forceinline__ void tile_column_norms(const double *tile, double *__
     if (part == 0 && col < ncols) out[col] = nrm;
 }
 
-// One workgroup of 256 threads per problem.  LDS (doubles): two panels' V[16 NCH][kLdV] and T[256] (qrfac: the panel being applied and
-// the next one being factorised -- look-ahead; qform: the two panels applied in one pass), Gl[256]
+// ---------------------------------------------------------------------------------------------------------------------------
+// qrfac as a CHAIN OF LAUNCHES (round 6).  Round 5's qrfac was one launch of four-wavefront workgroups in which a problem's panels were
+// factorised by ONE wavefront while the other three waited -- holding their registers and the workgroup's 75 KB of LDS, so that a CU had two
+// problems resident and, in a panel phase, one working wavefront per problem.  Timed on their own (profiles/r06_factor_probe.txt) the
+// two halves of that launch simply ADD: 1.65 ms of panel phases + 1.65 ms of trailing passes at 2048 x n = 253, 0.8 + 0.2 ms at 4096 x n = 85.
+// Now, per pair of panels (pp, pp + 1):
+//   qrfac_panel_kernel   ONE wavefront per problem (64-thread workgroups, one LDS tile): strip pp -> row layout -> the 16 column steps -> V, T;
+//                        strip pp + 1 through panel pp on the matrix cores, then factorised the same way.  Every resident wavefront works; a CU
+//                        holds as many problems as tiles fit (4 at 16 chunks ... 12 at 4).  V goes back to A's lower trapezoid (zero above
+//                        the diagonal), T to the workspace (Tsave), R's rows and Q^T f's entries to their places.
+//   qrfac_trail_kernel   four wavefronts per problem: both panels' V, T from A / Tsave into the two LDS tiles, then every strip right of the pair
+//                        through both panels in one load / store (round 5's [E], unchanged).
+// The kernels are instantiated by strip height and each pair's launches take the height that pair NEEDS (n = 253: 16, 16, 12, 12, 8, 6, 4, 4
+// chunks): late pairs compute on fewer zero rows and fit more problems per CU.  2 ceil(npanels / 2) launches instead of one; they queue behind
+// each other on the stream (no host synchronisation in between).
+template <int NCH, int WPE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void qrfac_panel_kernel(Config c, State *states, double *ws, long ws_stride, const int *__restrict__ list, int count, int pp, int final_launch)
+{
+    extern __shared__ double lds[];
+    double *V0 = lds, *T0 = V0 + 16 * NCH * kLdV, *Gl = T0 + 256;
+    const int lane = threadIdx.x, g = lane >> 4, m = lane & 15;
+    const int n = c.n, ld = c.ld;
+    const int npanels = (n + 15) >> 4;
+    const int j0 = 16 * pp, j1 = j0 + 16, nch = (n - j0 + 15) >> 4;
+    const bool two = pp + 1 < npanels;
+    for (int b = blockIdx.x; b < count; b += gridDim.x) {
+        const int p = list[b];
+        Work w(ws + (long)p * ws_stride, n, ld, lds);
+        double *A = w.A, *rdiag = w.wa1, *acnorm = w.wa2, *Tsave = w.V;
+        FProf prof(lane);
+        if (pp == 0) {
+            // fvec rides along as column n (the Jacobian's column norms are taken from the strips as they are first loaded)
+            for (int i = lane; i < n; i += 64) A[(long)i * ld + n] = w.fvec[i];
+            __syncthreads();
+        }
+        prof.mark(FP_NORMS);
+        {   // ---- panel pp: strip -> row layout -> the 16 columns -> V (LDS tile, A), R's rows, T
+            f64x4 S[NCH];
+            const int np0 = (n - j0 < 16) ? n - j0 : 16;
+            const unsigned long long t_la = prof.stamp();
+            strip_load<NCH>(S, A, ld, n, j0, nch, j0, n + 1, g, m);          // (column n = fvec rides along when it falls into this strip)
+            if (pp == 0) {
+                const double nrm = strip_column_norm<NCH>(S);
+                if (g == 0 && m < n) acnorm[m] = nrm;
+            }
+            double P[Rows<NCH>::NQ][16];
+            strip_to_tile<NCH, 0>(S, V0, lane);
+            prof.add(FP_LA_APPLY, t_la);
+            const unsigned long long t_cv = prof.stamp();
+            wave_lds_fence();
+            tile_to_rows<NCH, 0>(P, V0, lane);
+            wave_lds_fence();
+            prof.add(FP_LA_CONVERT, t_cv);
+            const unsigned long long t_cols = prof.stamp();
+            unsigned alive;
+            const double tau = panel_rows<NCH>(P, np0, V0, rdiag + j0, lane, alive);
+            prof.add(FP_COLS, t_cols);
+            const unsigned long long t_st = prof.stamp();
+            r_rows_from_rows(P[0], w.r, w.qtf, n, j0, lane);
+            rows_to_tile_V<NCH, 0>(P, alive, V0, lane);
+            wave_lds_fence();
+            tile_to_strip<NCH>(S, V0, lane);
+            strip_store<NCH>(S, A, ld, n, j0, nch, j0, n + 1, g, m, 0);      // (A keeps the vectors: the trailing launch and qform read them back)
+            if (lane < np0) w.r[row_off(n, j0 + lane)] = rdiag[j0 + lane];
+            prof.add(FP_LA_STORE, t_st);
+            const unsigned long long t_T = prof.stamp();
+            panel_T<NCH>(nch, tau, V0, T0, Gl, Tsave + 256 * pp, lane);
+            prof.add(FP_T, t_T);
+        }
+        if (two) {
+            // ---- the strip that is panel pp + 1 through panel pp (matrix cores, V and T from the tile), then factorised; the tile is free
+            // once the apply has read it and takes the strip's rows from the second chunk on (16 zero rows on top of its V: the trailing
+            // strips meet both panels at one offset)
+            f64x4 S[NCH];
+            const unsigned long long t_la = prof.stamp();
+            strip_load<NCH>(S, A, ld, n, j0, nch, j1, n + 1, g, m);
+            if (pp == 0) {
+                const double nrm = strip_column_norm<NCH>(S);
+                if (g == 0 && 16 + m < n) acnorm[16 + m] = nrm;
+            }
+            wave_lds_fence();                                                // (T0: written by lanes 0 .. 15, read by all)
+            strip_apply<NCH>(S, nch, V0, T0, lane);
+            prof.add(FP_LA_APPLY, t_la);
+            const unsigned long long t_cv = prof.stamp();
+            // its first 16 rows are rows of R now (packed R / Q^T fvec); the rest is panel pp + 1.  (A keeps nothing of those rows: qform zeroes them.)
+            r_rows_out(S[0], w.r, w.qtf, n, j0, j1, g, m, false);
+            SOCP_SCHED_FENCE();
+            double P[Rows<NCH>::NQ][16];
+            strip_to_tile<NCH, 1>(S, V0, lane);
+            wave_lds_fence();
+            tile_to_rows<NCH, 1>(P, V0, lane);
+            wave_lds_fence();
+            const int np1 = (n - j1 < 16) ? n - j1 : 16;
+            prof.add(FP_LA_CONVERT, t_cv);
+            const unsigned long long t_cols = prof.stamp();
+            unsigned alive;
+            const double tau = panel_rows<NCH>(P, np1, V0, rdiag + j1, lane, alive);
+            prof.add(FP_COLS, t_cols);
+            const unsigned long long t_st = prof.stamp();
+            r_rows_from_rows(P[0], w.r, w.qtf, n, j1, lane);
+            rows_to_tile_V<NCH, 1>(P, alive, V0, lane);
+            wave_lds_fence();
+            tile_to_strip<NCH>(S, V0, lane);
+            strip_store<NCH>(S, A, ld, n, j0, nch, j1, n + 1, g, m, 1);
+            if (lane < np1) w.r[row_off(n, j1 + lane)] = rdiag[j1 + lane];
+            prof.add(FP_LA_STORE, t_st);
+            const unsigned long long t_T = prof.stamp();
+            panel_T<NCH>(nch, tau, V0, T0, Gl, Tsave + 256 * (pp + 1), lane);
+            prof.add(FP_T, t_T);
+        }
+        prof.mark(FP_PANEL);
+        if (final_launch) {
+            // (the last launch of the chain: "singular" = a zero on R's diagonal; the flags the advance kernel reads)
+            __syncthreads();
+            int zero = 0;
+            for (int j = lane; j < n; j += 64) zero |= (rdiag[j] == 0) ? 1 : 0;
+            const int sing = __syncthreads_or(zero);
+            if (lane == 0) { states[p].sing = sing ? 1 : 0; states[p].pad = 1; }
+        }
+        __syncthreads();                                                     // (the tile is free for the next problem of this workgroup)
+    }
+}
+
+template <int NCH, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void qrfac_trail_kernel(Config c, State *states, double *ws, long ws_stride, const int *__restrict__ list, int count, int pp, int final_launch)
+{
+    extern __shared__ double lds[];
+    constexpr int kPanelDoubles = 16 * NCH * kLdV + 256;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, g = lane >> 4, m = lane & 15;
+    const int n = c.n, ld = c.ld;
+    const int npanels = (n + 15) >> 4;
+    const int j0 = 16 * pp, j1 = j0 + 16, nch = (n - j0 + 15) >> 4;
+    const bool two = pp + 1 < npanels;
+    double *V0 = lds, *T0 = V0 + 16 * NCH * kLdV, *V1 = lds + kPanelDoubles, *T1 = V1 + 16 * NCH * kLdV;
+    for (int b = blockIdx.x; b < count; b += gridDim.x) {
+        const int p = list[b];
+        Work w(ws + (long)p * ws_stride, n, ld, lds);
+        double *A = w.A, *rdiag = w.wa1, *acnorm = w.wa2, *Tsave = w.V;
+        FProf prof(tid);
+        {
+            // both panels' vectors from A's lower trapezoid (where the panel launch left them: zero above the diagonal and in the columns that
+            // are no reflectors) into the tiles, rows counted from panel pp's first row -- panel pp + 1's tile with 16 zero rows on top --,
+            // zero from the matrix's last row to the tile's end; T as panel_T left it
+            const int t = tid & 15, r0 = tid >> 4;
+            const bool c0ok = j0 + t <= n, c1ok = two && j1 + t <= n;
+            double x0[NCH], x1[NCH];
+#pragma unroll
+            for (int it = 0; it < NCH; it++) {
+                const int row = r0 + 16 * it, arow = j0 + row;
+                const bool in = it < nch && arow < n;
+                const double *q = A + (long)arow * ld + j0 + t;
+                x0[it] = (in && c0ok) ? q[0] : 0.0;
+                x1[it] = (in && c1ok && it > 0) ? q[16] : 0.0;
+            }
+            const double xt0 = Tsave[256 * pp + tid], xt1 = two ? Tsave[256 * (pp + 1) + tid] : 0.0;
+#pragma unroll
+            for (int it = 0; it < NCH; it++) {
+                V0[(r0 + 16 * it) * kLdV + t] = x0[it];
+                V1[(r0 + 16 * it) * kLdV + t] = x1[it];
+            }
+            T0[tid] = xt0;
+            T1[tid] = xt1;
+        }
+        __syncthreads();
+        prof.mark(FP_QLOAD);
+        // the strips right of the panel(s); their first 16 (32) rows leave as rows of R and are not written back
+        for (int c0 = j0 + (two ? 32 : 16) + 16 * wave; c0 <= n; c0 += 64) {
+            f64x4 S[NCH];
+            strip_load<NCH>(S, A, ld, n, j0, nch, c0, n + 1, g, m);
+            if (pp == 0) {
+                const double nrm = strip_column_norm<NCH>(S);
+                if (g == 0 && c0 + m < n) acnorm[c0 + m] = nrm;
+            }
+            strip_apply<NCH>(S, nch, V0, T0, lane);
+            r_rows_out(S[0], w.r, w.qtf, n, j0, c0, g, m, false);
+            if (two) {
+                strip_apply<NCH>(S, nch, V1, T1, lane);
+                if (NCH > 1) r_rows_out(S[NCH > 1 ? 1 : 0], w.r, w.qtf, n, j1, c0, g, m, false);
+            }
+            strip_store<NCH>(S, A, ld, n, j0, nch, c0, n + 1, g, m, two ? 2 : 1);
+        }
+        prof.mark(FP_TRAIL);
+        if (final_launch) {
+            __syncthreads();
+            int zero = 0;
+            for (int j = tid; j < n; j += 256) zero |= (rdiag[j] == 0) ? 1 : 0;
+            const int sing = __syncthreads_or(zero);
+            if (tid == 0) { states[p].sing = sing ? 1 : 0; states[p].pad = 1; }
+        }
+        __syncthreads();
+        prof.mark(FP_TRAIL_WAIT);
+    }
+}
+
+// Round 5's forms, kept behind a switch for A/B (SOCP_FACTOR_CHAIN=0): qrfac as ONE launch of four-wavefront workgroups (PHASE 1: the pair's
+// strips through the LDS tiles, the panels by one wavefront each while three wait), and qform (PHASE 2), which is what runs behind either qrfac.
+// One workgroup of 256 threads per problem.  LDS (doubles): two panels' V[16 NCH][kLdV] and T[256] (qrfac: the pair being applied; qform:
+// the panel being applied and the next one on its way), Gl[256]
 // WPE: wavefronts per SIMD the registers are budgeted for -- 2 for the 16-chunk strip (128 of 256 VGPRs are the strip), more for the
 // smaller strips: the kernel is latency-bound, other problems' wavefronts are what fills its waits
-// PHASE: 0 = the whole refresh in one launch; 1 = qrfac (+ R, Q^T f, the flags) only; 2 = qform only (A/B: SOCP_FACTOR_SPLIT)
-// STAGED: the pair's strips travel through the LDS tiles (pair_tiles_load / tile_store above) instead of the panel wavefronts' registers
-template <int NCH, int WPE, int PHASE = 0, bool STAGED = false>
+template <int NCH, int WPE, int PHASE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void factor_fast_kernel(Config c, State *states, double *ws, long ws_stride, const int *__restrict__ list, int count)
 {
+    static_assert(PHASE == 1 || PHASE == 2, "qrfac or qform");
     extern __shared__ double lds[];
     constexpr int kPanelDoubles = 16 * NCH * kLdV + 256;
     double *Gl = lds + 2 * kPanelDoubles;
@@ -638,31 +833,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         double *A = w.A, *rdiag = w.wa1, *acnorm = w.wa2, *Tsave = w.V;
         FProf prof(tid);
         const int npanels = (n + 15) >> 4;
-        int sing = 0;
-        if constexpr (PHASE != 2) {
+        if constexpr (PHASE == 1) {
         // ---- fvec rides along as column n (the column norms of the Jacobian are taken from the strips as they are first loaded)
         for (int i = tid; i < n; i += 256) A[(long)i * ld + n] = w.fvec[i];
         __syncthreads();
         prof.mark(FP_NORMS);
-        // ---- qrfac, TWO panels per pass over the trailing matrix (round 5; round 4 ran one panel per pass with a look-ahead wavefront:
-        // a trailing element was read and written once per 16 reflectors, 11 of the launch's 22 GB).  For the panels pp, pp + 1:
+        // ---- qrfac, TWO panels per pass over the trailing matrix.  For the panels pp, pp + 1:
         //   [A] one wavefront factorises panel pp (row layout, panel_rows) -> V, T into buffer 0;
         //   [C] one wavefront takes the strip that is panel pp + 1 through panel pp and factorises it -> buffer 1 (its rows counted
         //       from panel pp's first row: 16 zero rows on top, so one strip of registers meets both panels at the same offsets);
         //   [E] all four wavefronts take the strips right of both panels through pp and pp + 1 in ONE load / store.
         // The wavefronts take turns at [A] and [C] (two workgroups share a CU: their serial parts should not share a SIMD).
+        // The pair's strips travel through the LDS tiles (pair_tiles_load / tile_store above).
         double *V0 = lds, *T0 = V0 + 16 * NCH * kLdV, *V1 = lds + kPanelDoubles, *T1 = V1 + 16 * NCH * kLdV;
         for (int pp = 0; pp < npanels; pp += 2) {
             const int j0 = 16 * pp, j1 = j0 + 16, nch = (n - j0 + 15) >> 4;
             const bool two = pp + 1 < npanels;
             const int wa = pp & 3, wb = (pp + 1) & 3;                        // (pp is even: wa in {0, 2}, wb in {1, 3})
-#if defined(SOCP_FACTOR_PROBE) && SOCP_FACTOR_PROBE == 1
-            // TIMING PROBE (results are garbage): the trailing passes alone -- what a trailing-only launch would cost
-            if (pp == 0) { for (int i = tid; i < 2 * kPanelDoubles; i += 256) lds[i] = 0.0; __syncthreads(); }
-            if constexpr (false) {
-#else
-            if constexpr (STAGED) {
-#endif
+            {
                 const unsigned long long t_la = prof.stamp();
                 pair_tiles_load<NCH>(V0, V1, A, ld, n, j0, nch, two, wave, lane);
                 __syncthreads();
@@ -737,96 +925,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
                 } else {
                     tile_store<NCH>(V0, A, ld, n, j0, nch, j0, 0, wave, 4, lane);
                 }
-            } else {
-#if defined(SOCP_FACTOR_PROBE) && SOCP_FACTOR_PROBE == 1
-            if constexpr (false) {
-#endif
-            if (wave == wa) {
-                f64x4 S[NCH];
-                const int np0 = (n - j0 < 16) ? n - j0 : 16;
-                const unsigned long long t_la = prof.stamp();
-                strip_load<NCH>(S, A, ld, n, j0, nch, j0, n + 1, g, m);      // (column n = fvec rides along when it falls into this strip)
-                if (pp == 0) {
-                    const double nrm = strip_column_norm<NCH>(S);
-                    if (g == 0 && m < n) acnorm[m] = nrm;
-                }
-                double P[Rows<NCH>::NQ][16];
-                strip_to_tile<NCH, 0>(S, V0, lane);
-                prof.add(FP_LA_APPLY, t_la);
-                const unsigned long long t_cv = prof.stamp();
-                wave_lds_fence();
-                tile_to_rows<NCH, 0>(P, V0, lane);
-                wave_lds_fence();
-                prof.add(FP_LA_CONVERT, t_cv);
-                const unsigned long long t_cols = prof.stamp();
-                unsigned alive;
-                const double tau = panel_rows<NCH>(P, np0, V0, rdiag + j0, lane, alive);
-                prof.add(FP_COLS, t_cols);
-                const unsigned long long t_st = prof.stamp();
-                r_rows_from_rows(P[0], w.r, w.qtf, n, j0, lane);
-                rows_to_tile_V<NCH, 0>(P, alive, V0, lane);
-                wave_lds_fence();
-                tile_to_strip<NCH>(S, V0, lane);
-                strip_store<NCH>(S, A, ld, n, j0, nch, j0, n + 1, g, m, 0);  // (A keeps the vectors: qform reads them back)
-                if (lane < np0) w.r[row_off(n, j0 + lane)] = rdiag[j0 + lane];
-                prof.add(FP_LA_STORE, t_st);
-                const unsigned long long t_T = prof.stamp();
-                panel_T<NCH>(nch, tau, V0, T0, Gl, Tsave + 256 * pp, lane);
-                prof.add(FP_T, t_T);
             }
-            prof.mark(FP_PANEL);
-            __syncthreads();
-            prof.mark(FP_PANEL_WAIT);
-            if (two) {
-                if (wave == wb) {
-                    f64x4 S[NCH];
-                    const unsigned long long t_la = prof.stamp();
-                    strip_load<NCH>(S, A, ld, n, j0, nch, j1, n + 1, g, m);
-                    if (pp == 0) {
-                        const double nrm = strip_column_norm<NCH>(S);
-                        if (g == 0 && 16 + m < n) acnorm[16 + m] = nrm;
-                    }
-                    strip_apply<NCH>(S, nch, V0, T0, lane);
-                    prof.add(FP_LA_APPLY, t_la);
-                    const unsigned long long t_cv = prof.stamp();
-                    // its first 16 rows are rows of R now (packed R / Q^T fvec); the rest is panel pp + 1: through LDS (the buffer its V
-                    // will fill) into the row layout.  (A keeps nothing of those rows: qform zeroes them.)
-                    r_rows_out(S[0], w.r, w.qtf, n, j0, j1, g, m, false);
-                    SOCP_SCHED_FENCE();
-                    double P[Rows<NCH>::NQ][16];
-                    strip_to_tile<NCH, 1>(S, V1, lane);
-                    wave_lds_fence();
-                    tile_to_rows<NCH, 1>(P, V1, lane);
-                    wave_lds_fence();
-                    const int np1 = (n - j1 < 16) ? n - j1 : 16;
-                    prof.add(FP_LA_CONVERT, t_cv);
-                    const unsigned long long t_cols = prof.stamp();
-                    unsigned alive;
-                    const double tau = panel_rows<NCH>(P, np1, V1, rdiag + j1, lane, alive);
-                    prof.add(FP_COLS, t_cols);
-                    const unsigned long long t_st = prof.stamp();
-                    r_rows_from_rows(P[0], w.r, w.qtf, n, j1, lane);
-                    rows_to_tile_V<NCH, 1>(P, alive, V1, lane);
-                    wave_lds_fence();
-                    tile_to_strip<NCH>(S, V1, lane);
-                    strip_store<NCH>(S, A, ld, n, j0, nch, j1, n + 1, g, m, 1);
-                    if (lane < np1) w.r[row_off(n, j1 + lane)] = rdiag[j1 + lane];
-                    prof.add(FP_LA_STORE, t_st);
-                    const unsigned long long t_T = prof.stamp();
-                    panel_T<NCH>(nch, tau, V1, T1, Gl, Tsave + 256 * (pp + 1), lane);
-                    prof.add(FP_T, t_T);
-                }
-                prof.mark(FP_PANEL);
-                __syncthreads();
-                prof.mark(FP_PANEL_WAIT);
-            }
-            }   // !STAGED
-#if defined(SOCP_FACTOR_PROBE) && SOCP_FACTOR_PROBE == 1
-            }
-#endif
-#if defined(SOCP_FACTOR_PROBE) && SOCP_FACTOR_PROBE == 2
-            if (false)            // TIMING PROBE (results are garbage): the panel phases alone
-#endif
             // [E] the strips right of the panel(s); their first 16 (32) rows leave as rows of R and are not written back
             for (int c0 = j0 + (two ? 32 : 16) + 16 * wave; c0 <= n; c0 += 64) {
                 f64x4 S[NCH];
@@ -850,11 +949,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         // ---- (Q^T fvec and the packed R have been written row block by row block as the strips passed) "singular":
         int zero = 0;
         for (int j = tid; j < n; j += 256) zero |= (rdiag[j] == 0) ? 1 : 0;
-        sing = __syncthreads_or(zero);
+        const int sing = __syncthreads_or(zero);
         prof.mark(FP_RPACK);
-        if (PHASE == 1 && tid == 0) { states[p].sing = sing ? 1 : 0; states[p].pad = 1; }
-        }   // PHASE != 2
-        if constexpr (PHASE != 1) {
+        if (tid == 0) { states[p].sing = sing ? 1 : 0; states[p].pad = 1; }
+        }   // PHASE == 1
+        if constexpr (PHASE == 2) {
         // ---- qform (round 5): a strip of Q STAYS in a wavefront's registers while every panel that reaches it streams through LDS.
         // Q = H_0 ... H_last applied to the identity: the 16 columns c0 .. c0 + 15 start as identity columns and are touched by the
         // panels p <= c0 / 16 only (a later panel acts on rows below the columns' ones), last panel first.  So a strip is never READ
@@ -925,8 +1024,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
                     if (have[u]) strip_store<NCH>(S[u], A, ld, n, 0, nch_all, 16 * sw[u], n, g, m);
             }
         }
-        }   // PHASE != 1
-        if (PHASE == 0 && tid == 0) { states[p].sing = sing ? 1 : 0; states[p].pad = 1; }
+        }   // PHASE == 2
         __syncthreads();
     }
 }
@@ -945,28 +1043,87 @@ hipError_t raise_lds_limit_fast()
     return e;
 }
 
-template <int NCH, int WPE, int PHASE, bool STAGED = false>
+template <int NCH, int WPE, int PHASE>
 hipError_t launch_phase(hipStream_t st, const PoolDev &pool, const int *d_list, int count)
 {
     const size_t lds_bytes = sizeof(double) * (size_t)(2 * (16 * NCH * kLdV + 256) + 256);
     if (lds_bytes > 65536) {
-        const hipError_t raised = raise_lds_limit_fast<factor_fast_kernel<NCH, WPE, PHASE, STAGED>>();
+        const hipError_t raised = raise_lds_limit_fast<factor_fast_kernel<NCH, WPE, PHASE>>();
         if (raised != hipSuccess) return raised;
     }
-    hipLaunchKernelGGL((factor_fast_kernel<NCH, WPE, PHASE, STAGED>), dim3((unsigned)count), dim3(256), lds_bytes, st, pool.cfg, pool.states, pool.ws, pool.ws_stride, d_list, count);
+    hipLaunchKernelGGL((factor_fast_kernel<NCH, WPE, PHASE>), dim3((unsigned)count), dim3(256), lds_bytes, st, pool.cfg, pool.states, pool.ws, pool.ws_stride, d_list, count);
     return hipGetLastError();
 }
+
+// ---- the chain's launches.  Wavefronts per SIMD the registers are budgeted for: the panel launch holds as many problems per CU as tiles
+// fit (38.9 KB at 16 chunks: 4 = one wavefront per SIMD, which may then use the whole register file; 30 KB at 12: 5; 21.5 KB at 8: 7;
+// 17 KB at 6: 9; 13 KB at 4: 12); the trailing launch is round 5's [E] with round 5's budgets.
+#ifndef SOCP_FACTOR_PANEL_WPE16
+#define SOCP_FACTOR_PANEL_WPE16 1
+#endif
+#ifndef SOCP_FACTOR_PANEL_WPE12
+#define SOCP_FACTOR_PANEL_WPE12 2
+#endif
+#ifndef SOCP_FACTOR_PANEL_WPE8
+#define SOCP_FACTOR_PANEL_WPE8 2
+#endif
+#ifndef SOCP_FACTOR_PANEL_WPE6
+#define SOCP_FACTOR_PANEL_WPE6 2
+#endif
+#ifndef SOCP_FACTOR_PANEL_WPE4
+#define SOCP_FACTOR_PANEL_WPE4 2
+#endif
+template <int NCH> struct ChainBudget;
+template <> struct ChainBudget<16> { static constexpr int panel = SOCP_FACTOR_PANEL_WPE16, trail = 2; };
+template <> struct ChainBudget<12> { static constexpr int panel = SOCP_FACTOR_PANEL_WPE12, trail = 2; };
+template <> struct ChainBudget<8> { static constexpr int panel = SOCP_FACTOR_PANEL_WPE8, trail = 2; };
+template <> struct ChainBudget<6> { static constexpr int panel = SOCP_FACTOR_PANEL_WPE6, trail = 2; };
+template <> struct ChainBudget<4> { static constexpr int panel = SOCP_FACTOR_PANEL_WPE4, trail = 4; };
+
+template <int NCH>
+hipError_t launch_pair(hipStream_t st, const PoolDev &pool, const int *d_list, int count, int pp, bool has_trail, bool last_pair)
+{
+    {
+        const size_t lds_bytes = sizeof(double) * (size_t)(16 * NCH * kLdV + 512);
+        hipLaunchKernelGGL((qrfac_panel_kernel<NCH, ChainBudget<NCH>::panel>), dim3((unsigned)count), dim3(64), lds_bytes, st, pool.cfg, pool.states, pool.ws,
+                           pool.ws_stride, d_list, count, pp, (last_pair && !has_trail) ? 1 : 0);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess || !has_trail) return e;
+    }
+    const size_t lds_bytes = sizeof(double) * (size_t)(2 * (16 * NCH * kLdV + 256));
+    if (lds_bytes > 65536) {
+        const hipError_t raised = raise_lds_limit_fast<qrfac_trail_kernel<NCH, ChainBudget<NCH>::trail>>();
+        if (raised != hipSuccess) return raised;
+    }
+    hipLaunchKernelGGL((qrfac_trail_kernel<NCH, ChainBudget<NCH>::trail>), dim3((unsigned)count), dim3(256), lds_bytes, st, pool.cfg, pool.states, pool.ws,
+                       pool.ws_stride, d_list, count, pp, last_pair ? 1 : 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_qrfac_chain(hipStream_t st, const PoolDev &pool, const int *d_list, int count)
+{
+    const int n = pool.cfg.n, npanels = (n + 15) >> 4;
+    for (int pp = 0; pp < npanels; pp += 2) {
+        const int j0 = 16 * pp, nch = (n - j0 + 15) >> 4;
+        const bool two = pp + 1 < npanels, has_trail = j0 + (two ? 32 : 16) <= n, last_pair = pp + 2 >= npanels;
+        // the strip height this pair needs (chunks from panel pp's first row down to the matrix's last row)
+        hipError_t e;
+        if (nch <= 4) e = launch_pair<4>(st, pool, d_list, count, pp, has_trail, last_pair);
+        else if (nch <= 6) e = launch_pair<6>(st, pool, d_list, count, pp, has_trail, last_pair);
+        else if (nch <= 8) e = launch_pair<8>(st, pool, d_list, count, pp, has_trail, last_pair);
+        else if (nch <= 12) e = launch_pair<12>(st, pool, d_list, count, pp, has_trail, last_pair);
+        else e = launch_pair<16>(st, pool, d_list, count, pp, has_trail, last_pair);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 template <int NCH, int WPE>
 hipError_t launch_nch(hipStream_t st, const PoolDev &pool, const int *d_list, int count)
 {
-    // Two launches -- qrfac, then qform -- rather than one: each half is a smaller function (the register allocator spills 27 + 55
-    // registers instead of 93 at 16 chunks) and every workgroup of a launch is in the same phase: 5.65 -> 5.03 ms at 2048 x n = 253,
-    // 3.87 -> 3.55 ms at n = 200, 1.38 -> 1.33 ms at 4096 x n = 85 (profiles/r05_factor_split_ab.txt).  SOCP_FACTOR_SPLIT=0: one launch.
-    static const bool split = [] { const char *e = std::getenv("SOCP_FACTOR_SPLIT"); return !(e && e[0] == '0'); }();
-    if (!split) return launch_phase<NCH, WPE, 0>(st, pool, d_list, count);
-    // (the pair's strips through the LDS tiles; SOCP_FACTOR_STAGED=0: through the panel wavefronts' registers)
-    static const bool staged = [] { const char *e = std::getenv("SOCP_FACTOR_STAGED"); return !(e && e[0] == '0'); }();
-    const hipError_t e = staged ? launch_phase<NCH, WPE, 1, true>(st, pool, d_list, count) : launch_phase<NCH, WPE, 1>(st, pool, d_list, count);
+    // qrfac as a chain of launches per pair of panels (round 6), then qform; SOCP_FACTOR_CHAIN=0: round 5's single qrfac launch
+    static const bool chain = [] { const char *e = std::getenv("SOCP_FACTOR_CHAIN"); return !(e && e[0] == '0'); }();
+    const hipError_t e = chain ? launch_qrfac_chain(st, pool, d_list, count) : launch_phase<NCH, WPE, 1>(st, pool, d_list, count);
     return e != hipSuccess ? e : launch_phase<NCH, WPE, 2>(st, pool, d_list, count);
 }
 
