@@ -1,9 +1,8 @@
 #!/bin/bash
-# A/B on the GPU box: qrfac as a chain of launches (round 6) against round 5's single launch (SOCP_FACTOR_CHAIN=0), on the product library and on
-# the variant builds named on the command line (socp_amd/_build_<name>; scripts/variant_build.sh):  bash scripts/probes/factor_chain_ab.sh [name ...]
+# A/B on the GPU box: the matrix-core refresh of the product library against variant builds (socp_amd/_build_<name>; scripts/variant_build.sh):
+#   bash scripts/probes/factor_chain_ab.sh [name ...]
 cd "$(dirname "$0")/../.."
-for T in "" "$@"; do for C in 1 0; do for cfg in "253 2048" "200 2048" "127 4096" "85 4096" "48 4096"; do
+for T in "" "$@"; do for cfg in "253 2048" "200 2048" "127 4096" "85 4096" "48 4096"; do
   L=$PWD/socp_amd/_build${T:+_$T}/libsocp_hip.so; [ -f $L ] || continue
-  [ -n "$T" ] && [ $C = 0 ] && continue
-  echo "build_${T:-product} chain=$C | $cfg | $(SOCP_FACTOR_CHAIN=$C SOCP_MEASURE_ONLY=fast SOCP_LIB_PATH=$L python3 scripts/measure_factor.py $cfg 3 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['fast']['kernel_ms'],3))")"
-done; done; done
+  echo "build_${T:-product} | $cfg | $(SOCP_MEASURE_ONLY=fast SOCP_LIB_PATH=$L python3 scripts/measure_factor.py $cfg 3 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['fast']['kernel_ms'],3))")"
+done; done
