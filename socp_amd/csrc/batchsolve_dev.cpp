@@ -546,7 +546,7 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
                     hip_ok(socp::devsolver::launch_gather_jac(main_stream, pool, dIdxA.i(), kc, dJx.d(), dJf.d()));
                     const int r = socp_fd_diff_dev(ctx, kc, dJx.d(), opt->epsfcn, dStage.d(), dJ.d());
                     if (r != SOCP_OK) { rc = r; break; }
-                    hip_ok(socp::devsolver::launch_scatter_jac(main_stream, pool, dIdxA.i(), kc, dJ.d(), fast_factor != 0));
+                    hip_ok(socp::devsolver::launch_scatter_jac(main_stream, pool, dIdxA.i(), kc, dJ.d()));
                     hip_ok(sync_main());                             // (dIdxA is rewritten by the next chunk / the next pass)
                 }
                 jac_from_cache += (long long)reqJc.size();
@@ -662,7 +662,7 @@ int socp_chains_solve_device(socp_ctx *ctx, int P, const socp_chain_options *opt
                                   ? socp_var_jacobian_multi_dev(ctx, kc, dJx.d() + (size_t)j0 * n, dJ.d())
                                   : socp_fd_jacobian_multi_dev(ctx, kc, dJx.d() + (size_t)j0 * n, dJf.d() + (size_t)j0 * n, opt->epsfcn, dJ.d(), opt->dedup);
                 if (r != SOCP_OK) { rc = r; break; }
-                hip_ok(socp::devsolver::launch_scatter_jac(main_stream, pool, dListJ.i() + j0, kc, dJ.d(), fast_factor != 0));
+                hip_ok(socp::devsolver::launch_scatter_jac(main_stream, pool, dListJ.i() + j0, kc, dJ.d()));
             }
             jac_launched += kJ;
         }
@@ -772,7 +772,7 @@ extern "C" int socp_qr_factor_batch(int device, int n, int count, const double *
     }
     double total_ms = 0;
     for (int rep = 0; rep < reps && rc == SOCP_OK; rep++) {
-        ok(launch_scatter_jac(nullptr, pool, dList, count, dJ, flavour == SOCP_FACTOR_FAST));
+        ok(launch_scatter_jac(nullptr, pool, dList, count, dJ));
         ok(launch_scatter_fvec(nullptr, pool, dList, count, dB));
         ok(hipEventRecord(e0, nullptr));
         ok(flavour == SOCP_FACTOR_FAST ? launch_factor_fast(nullptr, pool, dList, count) : launch_factor_exact(nullptr, pool, dList, count));

@@ -82,23 +82,14 @@ __device__ __forceinline__ void wave_lds_fence()
 // compiler hoists 4 NCH row offsets x ld into scalar registers for the whole kernel and spills them), and no per-row lane masks
 // except in the one chunk that can be partly below the matrix (4 NCH hoisted exec masks were the other half of the spills):
 // chunks before the last one are whole, chunks after it are zero -- uniform branches.
-// Where a strip lives: `base` = the address of (row 0, column c0), `pitch` = doubles between consecutive rows.  The row-major matrix:
-// (A + c0, ld); the strip-major copy (solver_dev.hpp: strip_major_index) the refresh works in: (strips + (c0 / 16) strip_rows 16, 16) -- one run.
-struct StripAt {
-    double *base;
-    long pitch;
-};
-__device__ __forceinline__ StripAt in_strips(double *strips, int n, int c0) { return {strips + (long)(c0 >> 4) * strip_rows(n) * 16, 16}; }
-__device__ __forceinline__ StripAt in_matrix(double *A, int ld, int c0) { return {A + c0, ld}; }
-
 template <int NCH>
-__device__ __forceinline__ void strip_load(f64x4 (&S)[NCH], StripAt at, int n, int row0, int nch, int c0, int colmax, int g, int m)
+__device__ __forceinline__ void strip_load(f64x4 (&S)[NCH], const double *__restrict__ A, int ld, int n, int row0, int nch, int c0, int colmax, int g, int m)
 {
     g = here(g); m = here(m);
     const int col = c0 + m;
     const bool cok = col < colmax;
-    const double *p = at.base + (long)(row0 + g) * at.pitch + m;
-    const long step = 4L * at.pitch;
+    const double *p = A + (long)(row0 + g) * ld + col;
+    const long step = 4L * ld;
 #pragma unroll
     for (int cc = 0; cc < NCH; cc++) {
         if (cc + 1 < nch) {
@@ -115,13 +106,14 @@ __device__ __forceinline__ void strip_load(f64x4 (&S)[NCH], StripAt at, int n, i
 }
 // (`skip`: that many chunks at the top are not written -- rows that have left as rows of R; 0, 1 or 2, uniform)
 template <int NCH>
-__device__ __forceinline__ void strip_store(const f64x4 (&S)[NCH], StripAt at, int n, int row0, int nch, int c0, int colmax, int g, int m, int skip = 0)
+__device__ __forceinline__ void strip_store(const f64x4 (&S)[NCH], double *__restrict__ A, int ld, int n, int row0, int nch, int c0, int colmax, int g, int m,
+                                            int skip = 0)
 {
     g = here(g); m = here(m);
     const int col = c0 + m;
     if (col >= colmax) return;
-    double *p = at.base + (long)(row0 + g) * at.pitch + m;
-    const long step = 4L * at.pitch;
+    double *p = A + (long)(row0 + g) * ld + col;
+    const long step = 4L * ld;
 #pragma unroll
     for (int cc = 0; cc < NCH; cc++) {
         if (cc < skip) {
@@ -481,9 +473,10 @@ __device__ __forceinline__ void panel_steps(double (&P)[NQ][16], int np, double 
 // from the diagonal down in P, rdiag[0 .. np) to memory, the alive mask (which columns ARE reflectors); returns tau_t in lane t.
 // `scratch`: 16 doubles of LDS (the row hand-over).
 template <int NCH>
-__device__ __forceinline__ double panel_rows(double (&P)[Rows<NCH>::NQ][16], int np, double *scratch, double *__restrict__ rdiag, int lane, unsigned &alive)
+__device__ __forceinline__ double panel_rows(double (&P)[Rows<NCH>::NQ][16], int np, double *scratch, double *__restrict__ rdiag, int lane, unsigned &alive, double &rdiag_mine)
 {
-    double tau_mine = 0.0, rdiag_mine = 0.0;
+    double tau_mine = 0.0;
+    rdiag_mine = 0.0;
     alive = 0u;
     panel_steps<Rows<NCH>::NQ>(P, np, scratch, lane, tau_mine, rdiag_mine, alive, std::make_integer_sequence<int, 16>());
     if (here(lane) < np) rdiag[lane] = rdiag_mine;
@@ -539,6 +532,93 @@ __device__ __forceinline__ void panel_T(int nch, double tau_mine, const double *
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// The pair's two strips through the LDS tiles (round 5, STAGED).  With one wavefront per panel doing everything itself, a panel's
+// 83 000 cycles were 28 000 of column steps and the rest that wavefront loading its strip (15 000: 64 loads per lane behind the other
+// workgroup's traffic), converting, storing the vectors back (10 000) -- while three wavefronts waited.  Here the strips travel
+// through the tiles that will hold V anyway: ALL wavefronts bring both strips of the pair in (a quarter each) before the first
+// panel starts; the panel wavefronts read their strip from LDS; the vectors go back to A from the tiles by the wavefronts that
+// have nothing else to do ([A]'s during [C], [C]'s at the head of the trailing pass).  No register array lives across a barrier.
+template <int NCH>
+__device__ __forceinline__ void pair_tiles_load(double *V0, double *V1, const double *__restrict__ A, int ld, int n, int j0, int nch, bool two, int wave, int lane)
+{
+    lane = here(lane);
+    const int g = lane >> 4, m = lane & 15;
+    const bool ok0 = j0 + m <= n, ok1 = two && j0 + 16 + m <= n;             // (column n = fvec rides along)
+#pragma unroll
+    for (int q = 0; q < (NCH + 3) / 4; q++) {
+        const int cc = wave + 4 * q;                                         // (uniform)
+        if (cc < NCH) {
+            double v0[4] = {0.0, 0.0, 0.0, 0.0}, v1[4] = {0.0, 0.0, 0.0, 0.0};
+            if (cc < nch) {                                                  // (chunks below the matrix: zeros, no loads issued)
+                const double *p = A + (long)(j0 + 16 * cc + g) * ld + j0 + m;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const bool in = j0 + 16 * cc + g + 4 * r < n;
+                    v0[r] = (in && ok0) ? p[0] : 0.0;
+                    v1[r] = (in && ok1) ? p[16] : 0.0;
+                    p += 4L * ld;
+                }
+            }
+            double *t0 = V0 + (16 * cc + g) * kLdV + m, *t1 = V1 + (16 * cc + g) * kLdV + m;
+#pragma unroll
+            for (int r = 0; r < 4; r++) { t0[4 * r * kLdV] = v0[r]; t1[4 * r * kLdV] = v1[r]; }
+        }
+    }
+}
+// a tile's vectors back to A: columns c0 .. c0 + 15 (<= n), rows j0 + 16 first .., chunk cc by share `idx` of `shares` (uniform)
+template <int NCH>
+__device__ __forceinline__ void tile_store(const double *tile, double *__restrict__ A, int ld, int n, int j0, int nch, int c0, int first, int idx, int shares, int lane)
+{
+    lane = here(lane);
+    const int g = lane >> 4, m = lane & 15;
+    if (c0 + m > n) return;
+#pragma unroll
+    for (int q = 0; q < NCH; q++) {
+        const int cc = first + idx + shares * q;                             // (uniform)
+        if (cc < NCH && cc < nch) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = 16 * cc + g + 4 * r;
+                if (j0 + row < n) A[(long)(j0 + row) * ld + c0 + m] = tile[row * kLdV + m];
+            }
+        }
+    }
+}
+// |column|_2 of a tile's 16 columns (pair 0: whole columns), one wavefront: lane = (column, quarter of the rows); strip_column_norm's rule
+template <int NCH>
+__device__ __forceinline__ void tile_column_norms(const double *tile, double *__restrict__ out, int ncols, int lane)
+{
+    lane = here(lane);
+    const int col = lane & 15, part = lane >> 4;
+    const double *p = tile + (part * 4 * NCH) * kLdV + col;
+    double ss = 0.0;
+#pragma unroll 8
+    for (int i = 0; i < 4 * NCH; i++) { const double v = p[i * kLdV]; ss = __builtin_fma(v, v, ss); }
+    ss += __shfl_xor(ss, 16);
+    ss += __shfl_xor(ss, 32);
+    double nrm = ss;
+    if (ss == ss) {
+        if (ss > 1e-280 && ss < 1e280) {
+            nrm = sqrt(ss);
+        } else {
+            double amax = 0.0;
+            for (int i = 0; i < 4 * NCH; i++) amax = fmax(amax, fabs(p[i * kLdV]));
+            amax = fmax(amax, __shfl_xor(amax, 16));
+            amax = fmax(amax, __shfl_xor(amax, 32));
+            nrm = amax;
+            if (amax > 0 && amax < INFINITY) {
+                double s2 = 0.0;
+                for (int i = 0; i < 4 * NCH; i++) { const double x = p[i * kLdV] / amax; s2 += x * x; }
+                s2 += __shfl_xor(s2, 16);
+                s2 += __shfl_xor(s2, 32);
+                nrm = amax * sqrt(s2);
+            }
+        }
+    }
+    if (part == 0 && col < ncols) out[col] = nrm;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // qrfac as a CHAIN OF LAUNCHES (round 6).  Round 5's qrfac was one launch of four-wavefront workgroups in which a problem's panels were
 // factorised by ONE wavefront while the other three waited -- holding their registers and the workgroup's 75 KB of LDS, so that a CU had two
 // problems resident and, in a panel phase, one working wavefront per problem.  Timed on their own (profiles/r06_factor_probe.txt) the
@@ -566,11 +646,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     for (int b = blockIdx.x; b < count; b += gridDim.x) {
         const int p = list[b];
         Work w(ws + (long)p * ws_stride, n, ld, lds);
-        double *M = w.strips, *rdiag = w.wa1, *acnorm = w.wa2, *Tsave = w.V;
+        double *A = w.A, *rdiag = w.wa1, *acnorm = w.wa2, *Tsave = w.V;
         FProf prof(lane);
         if (pp == 0) {
             // fvec rides along as column n (the Jacobian's column norms are taken from the strips as they are first loaded)
-            for (int i = lane; i < n; i += 64) M[strip_major_index(n, i, n)] = w.fvec[i];
+            for (int i = lane; i < n; i += 64) A[(long)i * ld + n] = w.fvec[i];
             __syncthreads();
         }
         prof.mark(FP_NORMS);
@@ -578,7 +658,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
             f64x4 S[NCH];
             const int np0 = (n - j0 < 16) ? n - j0 : 16;
             const unsigned long long t_la = prof.stamp();
-            strip_load<NCH>(S, in_strips(M, n, j0), n, j0, nch, j0, n + 1, g, m);   // (column n = fvec rides along when it falls into this strip)
+            strip_load<NCH>(S, A, ld, n, j0, nch, j0, n + 1, g, m);          // (column n = fvec rides along when it falls into this strip)
             if (pp == 0) {
                 const double nrm = strip_column_norm<NCH>(S);
                 if (g == 0 && m < n) acnorm[m] = nrm;
@@ -593,15 +673,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
             prof.add(FP_LA_CONVERT, t_cv);
             const unsigned long long t_cols = prof.stamp();
             unsigned alive;
-            const double tau = panel_rows<NCH>(P, np0, V0, rdiag + j0, lane, alive);
+            double rdiag_mine;
+            const double tau = panel_rows<NCH>(P, np0, V0, rdiag + j0, lane, alive, rdiag_mine);
             prof.add(FP_COLS, t_cols);
             const unsigned long long t_st = prof.stamp();
             r_rows_from_rows(P[0], w.r, w.qtf, n, j0, lane);
             rows_to_tile_V<NCH, 0>(P, alive, V0, lane);
             wave_lds_fence();
             tile_to_strip<NCH>(S, V0, lane);
-            strip_store<NCH>(S, in_strips(M, n, j0), n, j0, nch, j0, n + 1, g, m, 0);   // (the strip keeps the vectors: the trailing launch and qform read them back)
-            if (lane < np0) w.r[row_off(n, j0 + lane)] = rdiag[j0 + lane];
+            strip_store<NCH>(S, A, ld, n, j0, nch, j0, n + 1, g, m, 0);      // (A keeps the vectors: the trailing launch and qform read them back)
+            if (lane < np0) w.r[row_off(n, j0 + lane)] = rdiag_mine;
             prof.add(FP_LA_STORE, t_st);
             const unsigned long long t_T = prof.stamp();
             panel_T<NCH>(nch, tau, V0, T0, Gl, Tsave + 256 * pp, lane);
@@ -613,7 +694,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
             // strips meet both panels at one offset)
             f64x4 S[NCH];
             const unsigned long long t_la = prof.stamp();
-            strip_load<NCH>(S, in_strips(M, n, j1), n, j0, nch, j1, n + 1, g, m);
+            strip_load<NCH>(S, A, ld, n, j0, nch, j1, n + 1, g, m);
             if (pp == 0) {
                 const double nrm = strip_column_norm<NCH>(S);
                 if (g == 0 && 16 + m < n) acnorm[16 + m] = nrm;
@@ -634,15 +715,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
             prof.add(FP_LA_CONVERT, t_cv);
             const unsigned long long t_cols = prof.stamp();
             unsigned alive;
-            const double tau = panel_rows<NCH>(P, np1, V0, rdiag + j1, lane, alive);
+            double rdiag_mine;
+            const double tau = panel_rows<NCH>(P, np1, V0, rdiag + j1, lane, alive, rdiag_mine);
             prof.add(FP_COLS, t_cols);
             const unsigned long long t_st = prof.stamp();
             r_rows_from_rows(P[0], w.r, w.qtf, n, j1, lane);
             rows_to_tile_V<NCH, 1>(P, alive, V0, lane);
             wave_lds_fence();
             tile_to_strip<NCH>(S, V0, lane);
-            strip_store<NCH>(S, in_strips(M, n, j1), n, j0, nch, j1, n + 1, g, m, 1);
-            if (lane < np1) w.r[row_off(n, j1 + lane)] = rdiag[j1 + lane];
+            strip_store<NCH>(S, A, ld, n, j0, nch, j1, n + 1, g, m, 1);
+            if (lane < np1) w.r[row_off(n, j1 + lane)] = rdiag_mine;
             prof.add(FP_LA_STORE, t_st);
             const unsigned long long t_T = prof.stamp();
             panel_T<NCH>(nch, tau, V0, T0, Gl, Tsave + 256 * (pp + 1), lane);
@@ -675,10 +757,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     for (int b = blockIdx.x; b < count; b += gridDim.x) {
         const int p = list[b];
         Work w(ws + (long)p * ws_stride, n, ld, lds);
-        double *M = w.strips, *rdiag = w.wa1, *acnorm = w.wa2, *Tsave = w.V;
+        double *A = w.A, *rdiag = w.wa1, *acnorm = w.wa2, *Tsave = w.V;
         FProf prof(tid);
         {
-            // both panels' vectors from their strips' lower trapezoids (where the panel launch left them: zero above the diagonal and in the columns that
+            // both panels' vectors from A's lower trapezoid (where the panel launch left them: zero above the diagonal and in the columns that
             // are no reflectors) into the tiles, rows counted from panel pp's first row -- panel pp + 1's tile with 16 zero rows on top --,
             // zero from the matrix's last row to the tile's end; T as panel_T left it
             const int t = tid & 15, r0 = tid >> 4;
@@ -688,9 +770,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             for (int it = 0; it < NCH; it++) {
                 const int row = r0 + 16 * it, arow = j0 + row;
                 const bool in = it < nch && arow < n;
-                const double *q0 = in_strips(M, n, j0).base + (long)arow * 16 + t, *q1 = q0 + (long)strip_rows(n) * 16;   // (the next strip: panel pp + 1)
-                x0[it] = (in && c0ok) ? *q0 : 0.0;
-                x1[it] = (in && c1ok && it > 0) ? *q1 : 0.0;
+                const double *q = A + (long)arow * ld + j0 + t;
+                x0[it] = (in && c0ok) ? q[0] : 0.0;
+                x1[it] = (in && c1ok && it > 0) ? q[16] : 0.0;
             }
             const double xt0 = Tsave[256 * pp + tid], xt1 = two ? Tsave[256 * (pp + 1) + tid] : 0.0;
 #pragma unroll
@@ -706,7 +788,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         // the strips right of the panel(s); their first 16 (32) rows leave as rows of R and are not written back
         for (int c0 = j0 + (two ? 32 : 16) + 16 * wave; c0 <= n; c0 += 64) {
             f64x4 S[NCH];
-            strip_load<NCH>(S, in_strips(M, n, c0), n, j0, nch, c0, n + 1, g, m);
+            strip_load<NCH>(S, A, ld, n, j0, nch, c0, n + 1, g, m);
             if (pp == 0) {
                 const double nrm = strip_column_norm<NCH>(S);
                 if (g == 0 && c0 + m < n) acnorm[c0 + m] = nrm;
@@ -717,7 +799,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
                 strip_apply<NCH>(S, nch, V1, T1, lane);
                 if (NCH > 1) r_rows_out(S[NCH > 1 ? 1 : 0], w.r, w.qtf, n, j1, c0, g, m, false);
             }
-            strip_store<NCH>(S, in_strips(M, n, c0), n, j0, nch, c0, n + 1, g, m, two ? 2 : 1);
+            strip_store<NCH>(S, A, ld, n, j0, nch, c0, n + 1, g, m, two ? 2 : 1);
         }
         prof.mark(FP_TRAIL);
         if (final_launch) {
@@ -732,30 +814,158 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     }
 }
 
-// qform (round 5's kernel; round 6: the panels' vectors come from the strip-major copy, Q goes to the row-major matrix the iteration reads).
-// One workgroup of 256 threads per problem.  LDS (doubles): two panels' V[16 NCH][kLdV] and T[256]: the panel being applied and the next one
-// on its way.  WPE: wavefronts per SIMD the registers are budgeted for -- 2 for the 16-chunk strip (128 of 256 VGPRs are the strip), more for
-// the smaller strips.
-template <int NCH, int WPE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void qform_kernel(Config c, State *states, double *ws, long ws_stride, const int *__restrict__ list, int count)
+// Round 5's forms: qrfac as ONE launch (what a launch of few problems takes: launch_nch below) of four-wavefront workgroups (PHASE 1: the pair's
+// strips through the LDS tiles, the panels by one wavefront each while three wait), and qform (PHASE 2), which is what runs behind either qrfac.
+// One workgroup of 256 threads per problem.  LDS (doubles): two panels' V[16 NCH][kLdV] and T[256] (qrfac: the pair being applied; qform:
+// the panel being applied and the next one on its way), Gl[256]
+// WPE: wavefronts per SIMD the registers are budgeted for -- 2 for the 16-chunk strip (128 of 256 VGPRs are the strip), more for the
+// smaller strips: the kernel is latency-bound, other problems' wavefronts are what fills its waits
+template <int NCH, int WPE, int PHASE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void factor_fast_kernel(Config c, State *states, double *ws, long ws_stride, const int *__restrict__ list, int count)
 {
+    static_assert(PHASE == 1 || PHASE == 2, "qrfac or qform");
     extern __shared__ double lds[];
     constexpr int kPanelDoubles = 16 * NCH * kLdV + 256;
+    double *Gl = lds + 2 * kPanelDoubles;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, g = lane >> 4, m = lane & 15;
-    // (the wavefront's number as the SCALAR it is: which wavefront takes a strip is a scalar branch then)
+    // (the wavefront's number as the SCALAR it is: which wavefront takes a panel, a chunk, a strip are scalar branches then)
     const int n = c.n, ld = c.ld;
     for (int b = blockIdx.x; b < count; b += gridDim.x) {
         const int p = list[b];
         Work w(ws + (long)p * ws_stride, n, ld, lds);
-        double *A = w.A, *M = w.strips, *Tsave = w.V;
+        double *A = w.A, *rdiag = w.wa1, *acnorm = w.wa2, *Tsave = w.V;
         FProf prof(tid);
         const int npanels = (n + 15) >> 4;
+        if constexpr (PHASE == 1) {
+        // ---- fvec rides along as column n (the column norms of the Jacobian are taken from the strips as they are first loaded)
+        for (int i = tid; i < n; i += 256) A[(long)i * ld + n] = w.fvec[i];
+        __syncthreads();
+        prof.mark(FP_NORMS);
+        // ---- qrfac, TWO panels per pass over the trailing matrix.  For the panels pp, pp + 1:
+        //   [A] one wavefront factorises panel pp (row layout, panel_rows) -> V, T into buffer 0;
+        //   [C] one wavefront takes the strip that is panel pp + 1 through panel pp and factorises it -> buffer 1 (its rows counted
+        //       from panel pp's first row: 16 zero rows on top, so one strip of registers meets both panels at the same offsets);
+        //   [E] all four wavefronts take the strips right of both panels through pp and pp + 1 in ONE load / store.
+        // The wavefronts take turns at [A] and [C] (two workgroups share a CU: their serial parts should not share a SIMD).
+        // The pair's strips travel through the LDS tiles (pair_tiles_load / tile_store above).
+        double *V0 = lds, *T0 = V0 + 16 * NCH * kLdV, *V1 = lds + kPanelDoubles, *T1 = V1 + 16 * NCH * kLdV;
+        for (int pp = 0; pp < npanels; pp += 2) {
+            const int j0 = 16 * pp, j1 = j0 + 16, nch = (n - j0 + 15) >> 4;
+            const bool two = pp + 1 < npanels;
+            const int wa = pp & 3, wb = (pp + 1) & 3;                        // (pp is even: wa in {0, 2}, wb in {1, 3})
+            {
+                const unsigned long long t_la = prof.stamp();
+                pair_tiles_load<NCH>(V0, V1, A, ld, n, j0, nch, two, wave, lane);
+                __syncthreads();
+                prof.add(FP_LA_APPLY, t_la);
+                // (pair 0 holds whole columns: the Jacobian's column norms.  A tile is read by the wavefront that will overwrite it, or
+                // before the barrier that lets that wavefront start)
+                if (pp == 0 && two && wave == 3) tile_column_norms<NCH>(V1, acnorm + 16, n - 16, lane);
+                if (wave == wa) {
+                    const int np0 = (n - j0 < 16) ? n - j0 : 16;
+                    if (pp == 0) tile_column_norms<NCH>(V0, acnorm, n, lane);
+                    double P[Rows<NCH>::NQ][16];
+                    const unsigned long long t_cv = prof.stamp();
+                    tile_to_rows<NCH, 0>(P, V0, lane);
+                    wave_lds_fence();
+                    prof.add(FP_LA_CONVERT, t_cv);
+                    const unsigned long long t_cols = prof.stamp();
+                    unsigned alive;
+                    double rdiag_mine;
+                    const double tau = panel_rows<NCH>(P, np0, Gl, rdiag + j0, lane, alive, rdiag_mine);
+                    prof.add(FP_COLS, t_cols);
+                    const unsigned long long t_st = prof.stamp();
+                    r_rows_from_rows(P[0], w.r, w.qtf, n, j0, lane);
+                    rows_to_tile_V<NCH, 0>(P, alive, V0, lane);
+                    wave_lds_fence();
+                    if (lane < np0) w.r[row_off(n, j0 + lane)] = rdiag_mine;
+                    prof.add(FP_LA_STORE, t_st);
+                    const unsigned long long t_T = prof.stamp();
+                    panel_T<NCH>(nch, tau, V0, T0, Gl, Tsave + 256 * pp, lane);
+                    prof.add(FP_T, t_T);
+                }
+                prof.mark(FP_PANEL);
+                __syncthreads();
+                prof.mark(FP_PANEL_WAIT);
+                if (two) {
+                    if (wave == wb) {
+                        f64x4 S[NCH];
+                        const unsigned long long t_la2 = prof.stamp();
+                        tile_to_strip<NCH>(S, V1, lane);
+                        wave_lds_fence();
+                        strip_apply<NCH>(S, nch, V0, T0, lane);
+                        prof.add(FP_LA_APPLY, t_la2);
+                        const unsigned long long t_cv = prof.stamp();
+                        r_rows_out(S[0], w.r, w.qtf, n, j0, j1, g, m, false);
+                        SOCP_SCHED_FENCE();
+                        double P[Rows<NCH>::NQ][16];
+                        strip_to_tile<NCH, 1>(S, V1, lane);
+                        wave_lds_fence();
+                        tile_to_rows<NCH, 1>(P, V1, lane);
+                        wave_lds_fence();
+                        const int np1 = (n - j1 < 16) ? n - j1 : 16;
+                        prof.add(FP_LA_CONVERT, t_cv);
+                        const unsigned long long t_cols = prof.stamp();
+                        unsigned alive;
+                        double rdiag_mine;
+                        const double tau = panel_rows<NCH>(P, np1, Gl, rdiag + j1, lane, alive, rdiag_mine);
+                        prof.add(FP_COLS, t_cols);
+                        const unsigned long long t_st = prof.stamp();
+                        r_rows_from_rows(P[0], w.r, w.qtf, n, j1, lane);
+                        rows_to_tile_V<NCH, 1>(P, alive, V1, lane);
+                        wave_lds_fence();
+                        if (lane < np1) w.r[row_off(n, j1 + lane)] = rdiag_mine;
+                        prof.add(FP_LA_STORE, t_st);
+                        const unsigned long long t_T = prof.stamp();
+                        panel_T<NCH>(nch, tau, V1, T1, Gl, Tsave + 256 * (pp + 1), lane);
+                        prof.add(FP_T, t_T);
+                    } else {
+                        // panel pp's vectors back to A (qform reads them from there): the three wavefronts without a panel
+                        tile_store<NCH>(V0, A, ld, n, j0, nch, j0, 0, (wave - wb - 1) & 3, 3, lane);
+                    }
+                    prof.mark(FP_PANEL);
+                    __syncthreads();
+                    prof.mark(FP_PANEL_WAIT);
+                    tile_store<NCH>(V1, A, ld, n, j0, nch, j1, 1, wave, 4, lane);     // (its first chunk: rows of R, zeros in the tile)
+                } else {
+                    tile_store<NCH>(V0, A, ld, n, j0, nch, j0, 0, wave, 4, lane);
+                }
+            }
+            // [E] the strips right of the panel(s); their first 16 (32) rows leave as rows of R and are not written back
+            for (int c0 = j0 + (two ? 32 : 16) + 16 * wave; c0 <= n; c0 += 64) {
+                f64x4 S[NCH];
+                strip_load<NCH>(S, A, ld, n, j0, nch, c0, n + 1, g, m);
+                if (pp == 0) {
+                    const double nrm = strip_column_norm<NCH>(S);
+                    if (g == 0 && c0 + m < n) acnorm[c0 + m] = nrm;
+                }
+                strip_apply<NCH>(S, nch, V0, T0, lane);
+                r_rows_out(S[0], w.r, w.qtf, n, j0, c0, g, m, false);
+                if (two) {
+                    strip_apply<NCH>(S, nch, V1, T1, lane);
+                    if (NCH > 1) r_rows_out(S[NCH > 1 ? 1 : 0], w.r, w.qtf, n, j1, c0, g, m, false);
+                }
+                strip_store<NCH>(S, A, ld, n, j0, nch, c0, n + 1, g, m, two ? 2 : 1);
+            }
+            prof.mark(FP_TRAIL);
+            __syncthreads();
+            prof.mark(FP_TRAIL_WAIT);
+        }
+        // ---- (Q^T fvec and the packed R have been written row block by row block as the strips passed) "singular":
+        int zero = 0;
+        for (int j = tid; j < n; j += 256) zero |= (rdiag[j] == 0) ? 1 : 0;
+        const int sing = __syncthreads_or(zero);
+        prof.mark(FP_RPACK);
+        if (tid == 0) { states[p].sing = sing ? 1 : 0; states[p].pad = 1; }
+        }   // PHASE == 1
+        if constexpr (PHASE == 2) {
         // ---- qform (round 5): a strip of Q STAYS in a wavefront's registers while every panel that reaches it streams through LDS.
         // Q = H_0 ... H_last applied to the identity: the 16 columns c0 .. c0 + 15 start as identity columns and are touched by the
         // panels p <= c0 / 16 only (a later panel acts on rows below the columns' ones), last panel first.  So a strip is never READ
         // and is written ONCE (round 4: read and written once per pair of panels, 5 GB of the launch's 22); what is re-read instead are
-        // the panels' vectors -- from their strips' lower trapezoids, where qrfac left them -- once per ROUND of four strips (one per wavefront),
-        // double-buffered: the next panel's loads are in flight while the current one is applied.  Q is written to the row-major matrix A.
+        // the panels' vectors -- from A's lower triangle, where qrfac left them -- once per ROUND of four strips (one per wavefront),
+        // double-buffered: the next panel's loads are in flight while the current one is applied.  Rounds go from the last strips to
+        // the first: a strip's store overwrites the vectors of its own panel, which only the strips from it on need.
         {
             const int nstrips = npanels, nch_all = (n + 15) >> 4;
             const int t = tid & 15, r0 = tid >> 4;
@@ -789,7 +999,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 #pragma unroll
                     for (int it = 0; it < NCH; it++) {
                         const int row = r0 + 16 * it;
-                        xv[it] = (it < nch_all && row < n && row - jq >= t && t < npq) ? M[((long)q * strip_rows(n) + row) * 16 + t] : 0.0;
+                        xv[it] = (it < nch_all && row < n && row - jq >= t && t < npq) ? A[(long)row * ld + jq + t] : 0.0;
                     }
                     xt = Tsave[256 * q + tid];
                 };
@@ -816,9 +1026,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
                 }
 #pragma unroll
                 for (int u = 0; u < SPW; u++)
-                    if (have[u]) strip_store<NCH>(S[u], in_matrix(A, ld, 16 * sw[u]), n, 0, nch_all, 16 * sw[u], n, g, m);
+                    if (have[u]) strip_store<NCH>(S[u], A, ld, n, 0, nch_all, 16 * sw[u], n, g, m);
             }
         }
+        }   // PHASE == 2
         __syncthreads();
     }
 }
@@ -837,15 +1048,15 @@ hipError_t raise_lds_limit_fast()
     return e;
 }
 
-template <int NCH, int WPE>
-hipError_t launch_qform(hipStream_t st, const PoolDev &pool, const int *d_list, int count)
+template <int NCH, int WPE, int PHASE>
+hipError_t launch_phase(hipStream_t st, const PoolDev &pool, const int *d_list, int count)
 {
-    const size_t lds_bytes = sizeof(double) * (size_t)(2 * (16 * NCH * kLdV + 256));
+    const size_t lds_bytes = sizeof(double) * (size_t)(2 * (16 * NCH * kLdV + 256) + 256);
     if (lds_bytes > 65536) {
-        const hipError_t raised = raise_lds_limit_fast<qform_kernel<NCH, WPE>>();
+        const hipError_t raised = raise_lds_limit_fast<factor_fast_kernel<NCH, WPE, PHASE>>();
         if (raised != hipSuccess) return raised;
     }
-    hipLaunchKernelGGL((qform_kernel<NCH, WPE>), dim3((unsigned)count), dim3(256), lds_bytes, st, pool.cfg, pool.states, pool.ws, pool.ws_stride, d_list, count);
+    hipLaunchKernelGGL((factor_fast_kernel<NCH, WPE, PHASE>), dim3((unsigned)count), dim3(256), lds_bytes, st, pool.cfg, pool.states, pool.ws, pool.ws_stride, d_list, count);
     return hipGetLastError();
 }
 
@@ -866,6 +1077,9 @@ hipError_t launch_qform(hipStream_t st, const PoolDev &pool, const int *d_list, 
 #endif
 #ifndef SOCP_FACTOR_PANEL_WPE4
 #define SOCP_FACTOR_PANEL_WPE4 2
+#endif
+#ifndef SOCP_FACTOR_CHAIN_MIN_DEFAULT
+#define SOCP_FACTOR_CHAIN_MIN_DEFAULT 640
 #endif
 template <int NCH> struct ChainBudget;
 template <> struct ChainBudget<16> { static constexpr int panel = SOCP_FACTOR_PANEL_WPE16, trail = 2; };
@@ -912,12 +1126,28 @@ hipError_t launch_qrfac_chain(hipStream_t st, const PoolDev &pool, const int *d_
     return hipSuccess;
 }
 
+// Which form of qrfac a launch takes.  The chain pays where the launch holds more problems than the single kernel keeps resident (two
+// four-wavefront workgroups per CU = 512 problems): there the single kernel runs its problems in rounds, each round's panel phases with one
+// wavefront of four working, and the chain's panel launch -- every resident wavefront working -- is what shortens the refresh (4096 x n = 85:
+// 1.24 -> 0.80 ms).  A launch of FEW problems is one problem's latency either way, the same serial panels, and the chain only adds its launches'
+// start-up (the sweeps' later refreshes are such launches: M = 9, n = 127, 283 rounds, +2.7 % with the chain everywhere).  Measured crossover
+// (profiles/r06_factor_chain_crossover.txt): 512 problems and fewer -- one residency -- the single launch is 10-20 % faster, from 768 up the
+// chain is (n = 85: 0.24 against 0.30 ms at 768, 0.80 against 1.23 at 4096; n = 253: even from 768 on, 1-3 % from 2048 on).
+// SOCP_FACTOR_CHAIN_MIN=<problems>: the chain from that many problems up (0: always, a huge number: never).
+int chain_min_problems()
+{
+    static const int v = [] {
+        const char *e = std::getenv("SOCP_FACTOR_CHAIN_MIN");
+        return e ? std::atoi(e) : SOCP_FACTOR_CHAIN_MIN_DEFAULT;
+    }();
+    return v;
+}
+
 template <int NCH, int WPE>
 hipError_t launch_nch(hipStream_t st, const PoolDev &pool, const int *d_list, int count)
 {
-    // qrfac as a chain of launches per pair of panels, then qform (round 5's single qrfac launch: git history, profiles/r06_factor_chain_first_ab.txt)
-    const hipError_t e = launch_qrfac_chain(st, pool, d_list, count);
-    return e != hipSuccess ? e : launch_qform<NCH, WPE>(st, pool, d_list, count);
+    const hipError_t e = count >= chain_min_problems() ? launch_qrfac_chain(st, pool, d_list, count) : launch_phase<NCH, WPE, 1>(st, pool, d_list, count);
+    return e != hipSuccess ? e : launch_phase<NCH, WPE, 2>(st, pool, d_list, count);
 }
 
 }  // namespace

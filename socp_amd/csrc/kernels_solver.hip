@@ -149,9 +149,6 @@ __global__ void gather_result_kernel(Config c, double *ws, long ws_stride, const
 
 // A[i][j] (row-major, stride ld) = J[i + n j] (column-major): 32 x 32 tiles through LDS so that both sides are accessed along
 // their contiguous direction.  grid = (tiles, tiles, count), block = (32, 8)
-// STRIPS: the destination is the STRIP-MAJOR copy the matrix-core refresh works in (solver_dev.hpp: strip_major_index) -- a row of the
-// tile is two 128-byte lines of two strips -- and the row-major matrix is left alone (qform writes Q there).
-template <bool STRIPS>
 __global__ void scatter_jac_kernel(Config c, double *ws, long ws_stride, const int *__restrict__ list, const double *__restrict__ J)
 {
     __shared__ double tile[32][33];
@@ -164,10 +161,9 @@ __global__ void scatter_jac_kernel(Config c, double *ws, long ws_stride, const i
         if (i < n && j < n) tile[jj][threadIdx.x] = src[i + (long)n * j];
     }
     __syncthreads();
-    if (STRIPS) A += strip_major_offset(n, c.ld);
     for (int ii = threadIdx.y; ii < 32; ii += 8) {           // write: consecutive threads along j (contiguous in A)
         const int i = i0 + ii, j = j0 + threadIdx.x;
-        if (i < n && j < n) A[STRIPS ? strip_major_index(n, i, j) : (long)i * c.ld + j] = tile[threadIdx.x][ii];
+        if (i < n && j < n) A[(long)i * c.ld + j] = tile[threadIdx.x][ii];
     }
 }
 
@@ -384,19 +380,14 @@ hipError_t launch_gather_jac(hipStream_t st, const PoolDev &pool, const int *d_l
     return hipGetLastError();
 }
 
-hipError_t launch_scatter_jac(hipStream_t st, const PoolDev &pool, const int *d_list, int count, const double *d_J, bool strip_major)
+hipError_t launch_scatter_jac(hipStream_t st, const PoolDev &pool, const int *d_list, int count, const double *d_J)
 {
     if (count <= 0) return hipSuccess;
-    if (strip_major && !strip_major_sizes(pool.cfg.n)) return hipErrorInvalidValue;
     const unsigned tiles = (unsigned)((pool.cfg.n + 31) / 32);
     for (int k0 = 0; k0 < count; k0 += 32768) {              // grid.z is limited to 65535
         const int kc = count - k0 < 32768 ? count - k0 : 32768;
-        if (strip_major)
-            hipLaunchKernelGGL(scatter_jac_kernel<true>, dim3(tiles, tiles, (unsigned)kc), dim3(32, 8), 0, st, pool.cfg, pool.ws, pool.ws_stride, d_list + k0,
-                               d_J + (long)k0 * pool.cfg.n * pool.cfg.n);
-        else
-            hipLaunchKernelGGL(scatter_jac_kernel<false>, dim3(tiles, tiles, (unsigned)kc), dim3(32, 8), 0, st, pool.cfg, pool.ws, pool.ws_stride, d_list + k0,
-                               d_J + (long)k0 * pool.cfg.n * pool.cfg.n);
+        hipLaunchKernelGGL(scatter_jac_kernel, dim3(tiles, tiles, (unsigned)kc), dim3(32, 8), 0, st, pool.cfg, pool.ws, pool.ws_stride, d_list + k0,
+                           d_J + (long)k0 * pool.cfg.n * pool.cfg.n);
     }
     return hipGetLastError();
 }

@@ -67,31 +67,19 @@ struct Status {
 };
 
 constexpr int kVectors = 16;
-// The matrix-core refresh (kernels_factor_fast.hip; sizes 39 <= n <= 256) works in a STRIP-MAJOR copy of the matrix kept behind the other
-// areas: the 16-column strip s (columns 16 s .. 16 s + 15; column n = fvec rides along, so n / 16 + 1 strips) is stored contiguously,
-// strip_rows(n) rows of 16 doubles = one 128-byte line each.  A wavefront that takes a strip through a panel then reads and writes ONE RUN
-// of memory instead of n pieces of 128 bytes a row pitch apart -- which this memory system serves at a third of the rate
-// (profiles/r06_probe_strip_traffic.txt: 1.7 against 5 TB/s).  Element (row, col): strip_major_index.
-SOCP_HD int strip_rows(int n) { return (n + 15) / 16 * 16; }
-SOCP_HD bool strip_major_sizes(int n) { return n >= 39 && n <= 256; }
-SOCP_HD long strip_major_doubles(int n) { return strip_major_sizes(n) ? (long)(n / 16 + 1) * strip_rows(n) * 16 : 0; }
-SOCP_HD long strip_major_index(int n, int row, int col) { return ((long)(col >> 4) * strip_rows(n) + row) * 16 + (col & 15); }
-SOCP_HD long strip_major_offset(int n, int ld) { return (((long)n * ld + (long)n * (n + 1) + (long)kVectors * n) + 15) / 16 * 16; }   // (whole lines)
-SOCP_HD long ws_doubles(int n, int ld) { return strip_major_offset(n, ld) + strip_major_doubles(n); }
+SOCP_HD long ws_doubles(int n, int ld) { return (((long)n * ld + (long)n * (n + 1) + (long)kVectors * n) + 7) / 8 * 8; }
 SOCP_HD int ld_for(int n) { return (n + 1 + 7) / 8 * 8; }
 
 // views into one problem's workspace
 struct Work {
     double *A, *r, *x, *fvec, *diag, *qtf, *wa1, *wa2, *wa3, *wa4;
     double *V;       // the Householder vectors of the last factorisation, packed: v_k at V + row_off(n, k), n - k entries (factor_blocked)
-    double *strips;  // the strip-major copy of the matrix the matrix-core refresh works in (strip_major_doubles(n); nothing for other sizes)
     // eight "fast" vectors of n doubles for what every thread reads again and again (a column or row in hand, rotation
     // tables, copies whose norm is taken): LDS on the device, the tail of the workspace otherwise
     double *f[8];
     SOCP_HD Work(double *base, int n, int ld, double *fast = nullptr)
     {
         A = base; r = A + (long)n * ld;
-        strips = base + strip_major_offset(n, ld);
         double *v = r + (long)n * (n + 1) / 2;
         x = v; fvec = v + n; diag = v + 2 * n; qtf = v + 3 * n; wa1 = v + 4 * n; wa2 = v + 5 * n; wa3 = v + 6 * n; wa4 = v + 7 * n;
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -31,10 +31,8 @@ bool blocked_factor_applies(int n);
 hipError_t read_profile(unsigned long long out[16], bool reset);   // -DSOCP_SOLVER_PROFILE builds: per-phase clock totals
 hipError_t launch_factor(hipStream_t st, const PoolDev &pool, const int *d_list, int count);
 // the same refresh in the THROUGHPUT flavour (kernels_factor_fast.hip): blocked Householder QR, compact-WY panels of 16, trailing
-// updates on the FP64 matrix cores; results equal the order-preserving kernels' to rounding, not bit for bit.  It reads the Jacobian from the
-// problem's STRIP-MAJOR copy (launch_scatter_jac(..., strip_major = true)) and leaves Q in the row-major matrix; a chain of launches per
-// refresh (a panel launch and a trailing launch per pair of 16-column panels, then qform); fast_factor_applies: the sizes it is built
-// for (39 <= n <= 256)
+// updates on the FP64 matrix cores; results equal the order-preserving kernels' to rounding, not bit for bit.  A workgroup of four
+// wavefronts per problem; fast_factor_applies: the sizes it is built for (39 <= n <= 256)
 bool fast_factor_applies(int n);
 hipError_t launch_factor_fast(hipStream_t st, const PoolDev &pool, const int *d_list, int count);
 hipError_t read_factor_profile(unsigned long long out[16], bool reset);   // -DSOCP_FACTOR_PROFILE builds: per-phase clock totals of the fast kernel
@@ -49,9 +47,8 @@ hipError_t launch_scatter_fvec(hipStream_t st, const PoolDev &pool, const int *d
 hipError_t launch_copy_blocks(hipStream_t st, const double *src, const int *d_src_idx, double *dst, const int *d_dst_idx, int count, long len);
 // Jacobian requests: dX[k] = x, dF[k] = fvec of problem list[k]
 hipError_t launch_gather_jac(hipStream_t st, const PoolDev &pool, const int *d_list, int count, double *d_X, double *d_F);
-// column-major Jacobians J[k][n * n] (what the FD / variational kernels write) into the problems' row-major matrices -- or, strip_major,
-// into the strip-major copies the matrix-core refresh (launch_factor_fast) reads them from (solver_dev.hpp: strip_major_index)
-hipError_t launch_scatter_jac(hipStream_t st, const PoolDev &pool, const int *d_list, int count, const double *d_J, bool strip_major = false);
+// column-major Jacobians J[k][n * n] (what the FD / variational kernels write) into the problems' row-major matrices
+hipError_t launch_scatter_jac(hipStream_t st, const PoolDev &pool, const int *d_list, int count, const double *d_J);
 // out[k] = [x (n) | fvec (n)] of problem list[k] (a finished solve's result)
 hipError_t launch_gather_result(hipStream_t st, const PoolDev &pool, const int *d_list, int count, double *d_out);
 

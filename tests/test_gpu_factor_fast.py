@@ -69,33 +69,45 @@ def test_fast_factor_special_columns():
     assert np.max(np.abs(fa["Q"][1] @ fa["R"][1] - J[1])) <= 1e-12 * np.linalg.norm(J[1])
 
 
-@pytest.mark.parametrize("n", [39, 64, 85, 127, 200, 253, 256])
-def test_special_columns_at_every_strip_height(n):
-    """The chain of launches takes each pair of panels through kernels built for the strip height that pair needs (16, 12, 8, 6 or 4 chunks
-    of 16 rows): a zero column (no reflector) and a tiny one (the rescaling path of the panel's column step) in matrices of every height,
-    the same bars as above.  (Round 5's A/B forms of the refresh -- one launch, strips through registers -- are gone with the single qrfac
-    launch; profiles/r06_factor_chain_first_ab.txt holds the last A/B against it.)"""
-    from socp_amd import capi
+_BOTH_FORMS = r"""
+import numpy as np
+from socp_amd import capi
+for n in (39, 64, 85, 127, 200, 253, 256):
     rng = np.random.default_rng(100 + n)
-    J = rng.standard_normal((3, n, n))
-    J[:, np.arange(n), np.arange(n)] += 0.5 * np.sqrt(n)
-    J[1][:, 3] = 0.0
-    J[2][:, n // 2] *= 1e-170
+    J = rng.standard_normal((3, n, n)); J[:, np.arange(n), np.arange(n)] += 0.5 * np.sqrt(n)
+    J[1][:, 3] = 0.0; J[2][:, n // 2] *= 1e-170                      # a zero column, a tiny one: the rescaling path of the panel
     b = rng.standard_normal((3, n))
     ex = capi.qr_factor_batch(J, b, flavour=capi.FACTOR_EXACT)
     fa = capi.qr_factor_batch(J, b, flavour=capi.FACTOR_FAST)
     scale = np.linalg.norm(J, axis=(1, 2))[:, None, None]
-    assert np.max(np.abs(fa["Q"] @ fa["R"] - J) / scale) <= 1e-13
-    assert np.max(np.abs(np.transpose(fa["Q"], (0, 2, 1)) @ fa["Q"] - np.eye(n)[None])) <= 1e-13 * n
-    assert np.max(np.abs(fa["R"] - ex["R"]) / scale) <= 1e-11 and np.max(np.abs(fa["qtb"] - ex["qtb"])) <= 1e-11 * np.max(np.abs(b)) * np.sqrt(n)
-    assert np.max(np.abs(fa["acnorm"] - ex["acnorm"]) / np.maximum(ex["acnorm"], 1e-300)) <= 1e-12
-    assert fa["sing"][1] == 1 and ex["sing"][1] == 1 and fa["sing"][0] == 0 and fa["sing"][2] == 0
+    assert np.max(np.abs(fa["Q"] @ fa["R"] - J) / scale) <= 1e-13, n
+    assert np.max(np.abs(np.transpose(fa["Q"], (0, 2, 1)) @ fa["Q"] - np.eye(n)[None])) <= 1e-13 * n, n
+    assert np.max(np.abs(fa["R"] - ex["R"]) / scale) <= 1e-11 and np.max(np.abs(fa["qtb"] - ex["qtb"])) <= 1e-11 * np.max(np.abs(b)) * np.sqrt(n), n
+    assert np.max(np.abs(fa["acnorm"] - ex["acnorm"]) / np.maximum(ex["acnorm"], 1e-300)) <= 1e-12, n
+    assert fa["sing"][1] == 1 and ex["sing"][1] == 1 and fa["sing"][0] == 0 and fa["sing"][2] == 0, n
+print("forms ok")
+"""
+
+
+@pytest.mark.parametrize("chain_min", ["0", "99999999"], ids=["chain_of_launches", "single_qrfac_launch"])
+def test_both_forms_of_qrfac_at_every_strip_height(chain_min):
+    """qrfac runs as a chain of launches per pair of panels -- kernels built for the strip height the pair needs (16, 12, 8, 6 or 4 chunks of
+    16 rows) -- when a launch holds more problems than the single kernel keeps resident, as ONE launch otherwise (kernels_factor_fast.hip:
+    launch_nch; SOCP_FACTOR_CHAIN_MIN moves the boundary and is read once per process: a child process per form).  Each form forced on three
+    problems of every strip height, a zero column (no reflector) and a tiny one (the rescaling path of the panel's column step) among them,
+    the same bars as above."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", _BOTH_FORMS], capture_output=True, text=True, timeout=300, cwd=root,
+                         env=dict(os.environ, SOCP_FACTOR_CHAIN_MIN=chain_min))
+    assert out.returncode == 0 and "forms ok" in out.stdout, (out.stdout[-1500:], out.stderr[-1500:])
 
 
 def test_more_problems_than_the_chip_holds_and_a_permuted_list():
-    """Every launch of the chain walks the problem list with a grid-stride loop; 700 problems of n = 85 are more panel workgroups than fit
-    the chip at once at that strip height only in the trailing launches -- the results must not depend on which workgroup met which problem:
-    the same 700 matrices as 700 copies of 7 distinct ones."""
+    """700 problems are past the boundary (640) from which qrfac runs as the chain of launches: the results must not depend on which workgroup
+    of which launch met which problem, nor on the form -- 700 matrices that are 100 copies of 7 distinct ones, and the 7 alone (the single launch)."""
     from socp_amd import capi
     n = 85
     J7, b7 = _problems(n, 7, 5)
@@ -105,6 +117,9 @@ def test_more_problems_than_the_chip_holds_and_a_permuted_list():
         assert np.array_equal(fa["Q"][k::7], np.broadcast_to(fa["Q"][k], (100, n, n)))
         assert np.array_equal(fa["R"][k::7], np.broadcast_to(fa["R"][k], (100, n, n)))
         assert np.array_equal(fa["qtb"][k::7], np.broadcast_to(fa["qtb"][k], (100, n)))
+    few = capi.qr_factor_batch(J7, b7, flavour=capi.FACTOR_FAST)          # (7 problems: the single qrfac launch; same arithmetic, same panels)
+    scale = np.linalg.norm(J7, axis=(1, 2))[:, None, None]
+    assert np.max(np.abs(few["R"] - fa["R"][:7]) / scale) <= 1e-13 and np.max(np.abs(few["Q"] - fa["Q"][:7])) <= 1e-13
 
 
 def test_fast_factor_refuses_sizes_it_is_not_built_for():
