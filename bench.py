@@ -51,7 +51,7 @@ Objects in the JSON line beside the contract's fields (N = 1; `--lean` drops the
                   from the published algorithm / the reference's text).  `predicted` / `expected` from its own one-GPU curve.
   solver_kernels  the sweeps' second kernel with a roofline of its own: factor_fast = 2048 Jacobian refreshes of n = 253 (the factor
                   launch of a config-5 round) on the FP64 matrix cores, HIP-event time, fraction of the FP64 peak; traffic = the
-                  counters of this run as above (its two launches summed), the recorded figure (profiles/r05_factor_pmc.json) beside it.
+                  counters of this run as above (its two launches summed), the recorded figure (profiles/r06_factor_pmc.json) beside it.
   cpu_baseline    B1: the reference's own model::ComputeTraj (oracle/_ref, kind "reference") or the C oracle (kind
                   "port") on this box's host cores, bounded sample: `value` = MEDIAN of five samples, `spread`, `best`,
                   `worst`, `samples` beside it (all cores and one core).  cpu_baseline.b0 = "as shipped": the reference's
@@ -446,12 +446,15 @@ def traffic_child(args):
     return 0
 
 
-def live_traffic(args, kernel="fdrows_lane_kernel", child="headline", limit_s=90.0):
+def live_traffic(args, kernel="fdrows_lane_kernel", child="headline", limit_s=90.0, refreshes=None):
     """HBM bytes of one launch of the headline kernel from the PMC counters, measured NOW on this box: this file run twice as a child
     process under `rocprofv3 --pmc` -- FETCH_SIZE, then WRITE_SIZE, a pass each, no trace domain beside them (the guide's recipe:
     /opt/skills/guides/MI355X_MICROARCH.md, HBM section; FETCH_SIZE / WRITE_SIZE in KiB, reads doubled on gfx950).  The children are
     ordinary child processes with a time limit (killed by the process group THIS call started); any failure returns (None, why) and
-    the line keeps the recorded figure.  Not under a profiler (the profiling scripts run bench.py --lean) and at N = 1 only."""
+    the line keeps the recorded figure.  Not under a profiler (the profiling scripts run bench.py --lean) and at N = 1 only.
+    `kernel`: a name fragment, or a tuple of them.  `refreshes`: None -- per kernel name the median over its launches of the largest grid
+    (the headline kernel: two equal launches); an integer -- the child ran that many whole refreshes and a refresh is a CHAIN of launches
+    (round 6: panel and trailing launches per pair of panels, then qform): every matching dispatch summed, divided by it."""
     import csv
     import glob
     import shutil
@@ -483,17 +486,20 @@ def live_traffic(args, kernel="fdrows_lane_kernel", child="headline", limit_s=90
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 with open(f) as fh:
                     for r in csv.DictReader(fh):
-                        if kernel in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter:
+                        if any(k in r.get("Kernel_Name", "") for k in ((kernel,) if isinstance(kernel, str) else kernel)) and r.get("Counter_Name") == counter:
                             rows.setdefault(r["Kernel_Name"], []).append((float(r.get("Grid_Size", 0) or 0), float(r["Counter_Value"])))
             if not rows:
                 return None, "rocprofv3 --pmc %s: no dispatch of %s in its output" % (counter, kernel)
-            top = max(g for v in rows.values() for g, _ in v)                # (the launches over the whole workload, not a warm-up's)
-            total = 0.0
-            for v in rows.values():
-                x = sorted(c for g, c in v if g == top)
-                if x:
-                    total += x[len(x) // 2]
-            vals[counter] = total
+            if refreshes:
+                vals[counter] = sum(c for v in rows.values() for _, c in v) / float(refreshes)
+            else:
+                top = max(g for v in rows.values() for g, _ in v)            # (the launches over the whole workload, not a warm-up's)
+                total = 0.0
+                for v in rows.values():
+                    x = sorted(c for g, c in v if g == top)
+                    if x:
+                        total += x[len(x) // 2]
+                vals[counter] = total
         except Exception as exc:                                             # (a measurement aid must never take the bench line down)
             return None, "rocprofv3 --pmc %s: %s" % (counter, exc)
         finally:
@@ -586,6 +592,9 @@ def factor_workload(n=253, count=2048):
     return J, b
 
 
+FACTOR_KERNELS = ("qrfac_panel_kernel", "qrfac_trail_kernel", "factor_fast_kernel")     # the launches of one matrix-core refresh
+
+
 def solver_kernel_rooflines(capi, device, args=None, live=False):
     """The roofline of the sweeps' second-largest kernel beside the headline one: the Jacobian refresh of the device solvers in the
     throughput flavour (kernels_factor_fast.hip, blocked Householder QR on the FP64 matrix cores), 2048 problems of n = 253 -- the
@@ -600,16 +609,16 @@ def solver_kernel_rooflines(capi, device, args=None, live=False):
     alg = 8.0 * count * (2 * n * n + n * (n + 1) / 2)
     traffic, source = None, None
     try:
-        with open(os.path.join(ROOT, "profiles", "r05_factor_pmc.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r06_factor_pmc.json")) as f:
             rec = json.load(f)
         if rec.get("n") == n and rec.get("count") == count:
-            traffic, source = rec["hbm_bytes"], "profiles/r05_factor_pmc.json (RECORDED: 2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes)"
+            traffic, source = rec["hbm_bytes"], "profiles/r06_factor_pmc.json (RECORDED: 2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes)"
     except Exception:
         pass
     recorded = {"bytes": traffic, "source": source}
     measured, note = False, "not attempted"
     tflops = flop / (ms * 1e-3) / 1e12
-    rec = {"factor_fast": {"workload": "2048 Jacobian refreshes of n = 253 (qrfac + Q^T f + R + qform), throughput flavour", "kernel": "factor_fast_kernel<16, 2, 1> (qrfac) + factor_fast_kernel<16, 2, 2> (qform), two launches",
+    rec = {"factor_fast": {"workload": "2048 Jacobian refreshes of n = 253 (qrfac + Q^T f + R + qform), throughput flavour", "kernel": "qrfac_panel_kernel / qrfac_trail_kernel per pair of panels (15 launches) + factor_fast_kernel<16, 2, 2> (qform)",
                            "kernel_ms": ms, "roofline": {"bound": "mfma_fp64", "achieved": tflops, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": tflops / PEAK_FP64_TFLOPS,
                                                          "algorithmic_bytes": alg, "traffic": traffic, "traffic_over_algorithmic": traffic / alg if traffic else None,
                                                          "traffic_source": source, "traffic_measured_in_this_run": measured, "traffic_live_measurement": note,
@@ -624,10 +633,11 @@ def solver_kernel_live_traffic(rec, args):
     solver_kernel_rooflines made.  Called after EVERY timed leg of the line: a profiler child takes the card for up to
     90 s and may leave clocks or power state different, so no timed figure may come after one."""
     r = rec["factor_fast"]["roofline"]
-    got, why = live_traffic(args, kernel="factor_fast_kernel", child="factor")
+    got, why = live_traffic(args, kernel=FACTOR_KERNELS, child="factor", refreshes=2)
     if got is not None:
         r["traffic"], r["traffic_measured_in_this_run"], r["traffic_live_measurement"] = got, True, "ok"
-        r["traffic_source"] = why.replace("two launches of the kernel", "two refreshes (a qrfac and a qform launch each: their sum)")
+        r["traffic_source"] = why.replace("two launches of the kernel", "two refreshes (qrfac's chain of panel and trailing launches + the qform launch: "
+                                                                          "every dispatch summed, halved)").replace(", median of the launches", "")
         r["traffic_over_algorithmic"] = got / r["algorithmic_bytes"]
     else:
         r["traffic_live_measurement"] = why

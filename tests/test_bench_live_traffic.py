@@ -1,6 +1,7 @@
 """CPU: bench.py's in-run PMC measurement (live_traffic) against a stand-in for rocprofv3 -- what it asks the profiler for, how it reads
-the counter file (per kernel name, the launches over the whole workload, median, the two launches of the refresh summed, the guide's
-2 x FETCH_SIZE KiB + WRITE_SIZE KiB), and that a profiler that fails or hangs costs the bench line nothing but the live figure."""
+the counter file (the headline kernel: per kernel name, the launches over the whole workload, median; the matrix-core refresh: a chain of
+launches under several names, every dispatch summed and divided by the refreshes the child ran; the guide's 2 x FETCH_SIZE KiB +
+WRITE_SIZE KiB), and that a profiler that fails or hangs costs the bench line nothing but the live figure."""
 import os
 import stat
 import sys
@@ -61,11 +62,15 @@ def test_live_traffic_reads_the_counters_as_the_guide_prescribes(fake_profiler, 
     got, why = bench.live_traffic(args, kernel="KERNEL<A>", child="headline", limit_s=30)
     # median of the whole-workload launches of the one kernel: FETCH 1000, WRITE 300 (KiB); reads doubled
     assert got == 2.0 * 1000.0 * 1024.0 + 300.0 * 1024.0 and "MEASURED IN THIS RUN" in why
-    # two kernels under one name pattern (the refresh's qrfac + qform): their medians summed
+    # two kernels under one name pattern: their medians summed
     got2, _ = bench.live_traffic(args, kernel="KERNEL", child="factor", limit_s=30)
     assert got2 == 2.0 * 1500.0 * 1024.0 + 450.0 * 1024.0
+    # a refresh as a CHAIN of launches under several names (round 6): every matching dispatch -- whatever its grid -- summed and divided by
+    # the number of refreshes the child ran.  FETCH: 7 + 1000 + 1002 + 950 + 500 + 500 = 3959 KiB, WRITE: 7 + 300 + 302 + 250 + 150 + 150 = 1159
+    got3, why3 = bench.live_traffic(args, kernel=("KERNEL<A>", "KERNEL<B>"), child="factor", limit_s=30, refreshes=2)
+    assert got3 == (2.0 * 3959.0 * 1024.0 + 1159.0 * 1024.0) / 2.0 and "MEASURED IN THIS RUN" in why3
     calls = fake_profiler.read_text().splitlines()
-    assert [c.split(" | ")[0] for c in calls] == ["FETCH_SIZE", "WRITE_SIZE"] * 2          # a pass each, never combined
+    assert [c.split(" | ")[0] for c in calls] == ["FETCH_SIZE", "WRITE_SIZE"] * 3          # a pass each, never combined
     # the program after `--` is the interpreter itself running this file in its child mode, at the headline size
     prog = calls[0].split(" | ")[1].split()
     assert prog[0] == sys.executable and prog[1].endswith("bench.py") and prog[2:4] == ["--traffic-child", "headline"]
