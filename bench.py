@@ -604,6 +604,7 @@ def solver_kernel_rooflines(capi, device, args=None, live=False):
     n, count = 253, 2048
     J, b = factor_workload()
     capi.qr_factor_batch(J[:8], b[:8], flavour=capi.FACTOR_FAST, outputs=False, device=device)
+    capi.qr_factor_batch(J[:640], b[:640], flavour=capi.FACTOR_FAST, outputs=False, device=device)      # (the chain's kernels: from 640 problems up)
     ms = capi.qr_factor_batch(J, b, flavour=capi.FACTOR_FAST, reps=3, outputs=False, device=device)["kernel_ms"]
     flop = 8.0 / 3.0 * n ** 3 * count
     alg = 8.0 * count * (2 * n * n + n * (n + 1) / 2)
