@@ -21,6 +21,7 @@ reports exactly the store that faulted, in all eight residual_lane_kernel<Lqr1D,
 import argparse
 import os
 import re
+import shutil
 import subprocess
 import sys
 import tempfile
@@ -229,6 +230,7 @@ def main():
         total += found
         print("%-26s %4d functions, %6d global/flat/scratch stores, %d with a possibly undefined address" % (u, len(kernels), stores, found))
     print("total candidates: %d" % total)
+    shutil.rmtree(tmp, ignore_errors=True)                    # (the listings stay only where --keep named a directory)
     sys.exit(1 if (a.expect_clean and total) else 0)
 
 

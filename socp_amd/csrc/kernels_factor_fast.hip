@@ -8,13 +8,11 @@
 // Q = H_0 H_1 ... H_{n-1}) is computed as a BLOCKED Householder QR with compact-WY panels of 16 reflectors, the trailing-matrix
 // update on the FP64 matrix cores (v_mfma_f64_16x16x4_f64), summation order free:
 //
-//   one workgroup (4 wavefronts) per problem (round 5's structure; round 4 ran one panel per pass with a look-ahead wavefront):
 //     the panel   a 16-column strip (<= 256 rows) factorised by ONE wavefront in a ROW layout -- a lane owns rows, all 16 columns of a
 //                 row in its registers -- with one batched wave-wide reduction per column (panel_rows, wave_reduce.hpp), V published to
 //                 LDS at the end, then T of  H_j0 .. H_j0+15 = I - V T V^T  (larft's recurrence on the Gram matrix V^T V, one MFMA pass)
-//     qrfac       TWO panels per pass: both strips of the pair into the LDS tiles by all wavefronts (pair_tiles_load); [A] panel pp;
-//                 [C] the strip that is panel pp + 1 through panel pp, then factorised (the vectors go back to A by the idle wavefronts); [E] every
-//                 later 16-column strip (and the one that holds fvec, column n) through BOTH panels in one load / store:
+//     qrfac       TWO panels per pass over the trailing matrix: panel pp; the strip that is panel pp + 1 through panel pp, then factorised;
+//                 every later 16-column strip (and the one that holds fvec, column n) through BOTH panels in one load / store:
 //                   W = V^T S (MFMA, K = rows)   Y = T^T W (4 MFMA)   S -= V Y (MFMA, K = 16)
 //                 with the strip in registers in the MFMA C/D layout (row = 16 chunk + g + 4 reg, column = lane & 15).  Because a sum
 //                 over K has no prescribed order here, the K slot of lane group g in step `reg` is simply DEFINED to be that row: the
@@ -23,8 +21,14 @@
 //     qform       Q = (I - V_0 T_0 V_0^T) ... (I - V_last T_last V_last^T) I: a strip of Q STAYS in a wavefront's registers (it starts
 //                 as identity columns) while every panel that reaches it streams through LDS, last panel first; never read, written once.
 //
-// Two launches per refresh: qrfac (PHASE 1), then qform (PHASE 2).  HBM traffic at n = 253: 4.2 x the algorithmic bytes (round 4:
-// 8.3 x; the order-preserving kernel: 130 x).  Results differ from the
+// qrfac has two forms (launch_nch below picks by the number of problems in the launch; profiles/r06_factor_chain_crossover.txt):
+//   * from 640 problems up a CHAIN OF LAUNCHES (round 6): per pair of panels qrfac_panel_kernel -- ONE wavefront per problem, every resident
+//     wavefront works -- and qrfac_trail_kernel -- four wavefronts per problem for the strips right of the pair --, each instantiated by
+//     strip height and launched at the height the pair needs;
+//   * below that ONE launch of four-wavefront workgroups (round 5's kernel: factor_fast_kernel<., ., 1>), in which the panels are
+//     factorised by one wavefront each while three wait: a launch of few problems is one problem's latency either way.
+// qform (factor_fast_kernel<., ., 2>) follows either.  HBM traffic at 2048 x n = 253: 4.5 x the algorithmic bytes (the single launch 4.2 x;
+// round 4: 8.3 x; the order-preserving kernel: 130 x).  Results differ from the
 // order-preserving kernel at rounding level; the engine uses this kernel only when asked for the throughput flavour
 // (SOCP_SOLVER_DEVICE_FAST, or AUTO on a throughput-flavour context).
 // Sizes: 39 <= n <= 256 (fast_factor_applies: the strip of a panel must fit the registers of one wavefront); others keep `factor`.
