@@ -47,8 +47,8 @@ out["traffic_over_algorithmic"] = out["hbm_bytes"] / out["algorithmic_bytes"]
 json.dump(out, open("gpurun_out/%s_factor_chain_pmc_n%d.json" % (tag, n), "w"), indent=1)
 for i, r in enumerate(rows):
     hb = 2.0 * r.get("FETCH_SIZE", 0) * 1024 + r.get("WRITE_SIZE", 0) * 1024
-    print("%2d %-6s hbm %7.1f MB  mfma_busy %5.1f%%  wait_any/wave_cycles %4.2f  valu %9d mfma %8d lds %8d  waves %d" % (
-        i, r["kernel"], hb / 1e6, 100.0 * r.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / max(1.0, 4.0 * r.get("SQ_BUSY_CYCLES", 0)),
+    print("%2d %-6s hbm %7.1f MB  matrix-core time %6.1f us (SQ_INSTS_MFMA x 64 cycles / 1024 SIMDs at 2.3 GHz)  wait_any/wave_cycles %4.2f  valu %9d mfma %8d lds %8d  waves %d" % (
+        i, r["kernel"], hb / 1e6, r.get("SQ_INSTS_MFMA", 0) * 64.0 / 1024.0 / 2.3e3,
         r.get("SQ_WAIT_ANY", 0) / max(1.0, r.get("SQ_WAVE_CYCLES", 0)), r.get("SQ_INSTS_VALU", 0), r.get("SQ_INSTS_MFMA", 0), r.get("SQ_INSTS_LDS", 0), r.get("SQ_WAVES", 0)))
 print("total hbm %.2f GB = %.2f x algorithmic" % (out["hbm_bytes"] / 1e9, out["traffic_over_algorithmic"]))
 PY
