@@ -1066,7 +1066,8 @@ hipError_t launch_phase(hipStream_t st, const PoolDev &pool, const int *d_list, 
 
 // ---- the chain's launches.  Wavefronts per SIMD the registers are budgeted for: the panel launch holds as many problems per CU as tiles
 // fit (38.9 KB at 16 chunks: 4 = one wavefront per SIMD, which may then use the whole register file; 30 KB at 12: 5; 21.5 KB at 8: 7;
-// 17 KB at 6: 9; 13 KB at 4: 12); the trailing launch is round 5's [E] with round 5's budgets.
+// 17 KB at 6: 9; 13 KB at 4: 12); the trailing launch is round 5's [E]: two wavefronts per SIMD for the tall strips (181 / 224 registers), three for the
+// 6- and 8-chunk ones (121 / 144 registers fit 168: 4096 x n = 127 1.61 -> 1.55 ms, n = 96 0.965 -> 0.93; profiles/r06_factor_trail_wpe_ab.txt), four for 4 chunks.
 #ifndef SOCP_FACTOR_PANEL_WPE16
 #define SOCP_FACTOR_PANEL_WPE16 1
 #endif
@@ -1087,9 +1088,18 @@ hipError_t launch_phase(hipStream_t st, const PoolDev &pool, const int *d_list, 
 #endif
 template <int NCH> struct ChainBudget;
 template <> struct ChainBudget<16> { static constexpr int panel = SOCP_FACTOR_PANEL_WPE16, trail = 2; };
-template <> struct ChainBudget<12> { static constexpr int panel = SOCP_FACTOR_PANEL_WPE12, trail = 2; };
-template <> struct ChainBudget<8> { static constexpr int panel = SOCP_FACTOR_PANEL_WPE8, trail = 2; };
-template <> struct ChainBudget<6> { static constexpr int panel = SOCP_FACTOR_PANEL_WPE6, trail = 2; };
+#ifndef SOCP_FACTOR_TRAIL_WPE12
+#define SOCP_FACTOR_TRAIL_WPE12 2
+#endif
+#ifndef SOCP_FACTOR_TRAIL_WPE8
+#define SOCP_FACTOR_TRAIL_WPE8 3
+#endif
+#ifndef SOCP_FACTOR_TRAIL_WPE6
+#define SOCP_FACTOR_TRAIL_WPE6 3
+#endif
+template <> struct ChainBudget<12> { static constexpr int panel = SOCP_FACTOR_PANEL_WPE12, trail = SOCP_FACTOR_TRAIL_WPE12; };
+template <> struct ChainBudget<8> { static constexpr int panel = SOCP_FACTOR_PANEL_WPE8, trail = SOCP_FACTOR_TRAIL_WPE8; };
+template <> struct ChainBudget<6> { static constexpr int panel = SOCP_FACTOR_PANEL_WPE6, trail = SOCP_FACTOR_TRAIL_WPE6; };
 template <> struct ChainBudget<4> { static constexpr int panel = SOCP_FACTOR_PANEL_WPE4, trail = 4; };
 
 template <int NCH>
