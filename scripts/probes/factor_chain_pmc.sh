@@ -19,7 +19,7 @@ for d in ("pc_fetch", "pc_write", "pc_sq", "pc_sq2"):
         seen = {}
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            if not any(s in k for s in ("qrfac_panel", "qrfac_trail", "factor_fast_kernel")) or float(r["Grid_Size"]) < 64 * count:
+            if not any(s in k for s in ("qrfac_panel", "qrfac_trail", "factor_fast_kernel")) or float(r["Grid_Size"]) / max(1.0, float(r["Workgroup_Size"])) < count:
                 continue
             name = (lambda k: "panel" if "qrfac_panel" in k else "trail" if "qrfac_trail" in k else ("qform" if __import__("re").search(r"factor_fast_kernel<\d+, \d+, 2>", k) else "qrfac_single") if "factor_fast_kernel" in k else None)(k)
             did = int(r["Dispatch_Id"])

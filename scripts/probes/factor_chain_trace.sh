@@ -13,7 +13,7 @@ rows = []
 for f in glob.glob("gpurun_out/pf_chain/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if ("qrfac_" in k or "factor_fast_kernel" in k) and int(r["Grid_Size_X"]) >= 64 * count:
+        if ("qrfac_" in k or "factor_fast_kernel" in k) and int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"])) >= count:
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), (lambda k: "panel" if "qrfac_panel" in k else "trail" if "qrfac_trail" in k else ("qform" if __import__("re").search(r"factor_fast_kernel<\d+, \d+, 2>", k) else "qrfac_single") if "factor_fast_kernel" in k else None)(k)))
 rows.sort()
 out = open("gpurun_out/%s_factor_chain_trace_n%d.txt" % (tag, n), "w")

@@ -27,7 +27,7 @@ for f in glob.glob("gpurun_out/pf_stats/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         kind = ("exact" if "factor_only_kernel" in k else (lambda k: "panel" if "qrfac_panel" in k else "trail" if "qrfac_trail" in k else ("qform" if __import__("re").search(r"factor_fast_kernel<\d+, \d+, 2>", k) else "qrfac_single") if "factor_fast_kernel" in k else None)(k))
-        if kind and int(r["Grid_Size_X"]) >= 64 * count:
+        if kind and int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"])) >= count:          # (workgroups = problems: the warm-up calls are smaller)
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), kind))
 rows.sort()
 refreshes, cur = [], []

@@ -13,22 +13,28 @@ python3 - "$TAG" <<'PY'
 import csv, glob, json, sys
 tag = sys.argv[1]
 n, P = 253, 2048
+def kind_of(k):
+    # the launches of the matrix-core refresh: the chain's panel / trailing launches, the single qrfac launch, qform
+    import re
+    if "qrfac_panel" in k: return "refresh: qrfac_panel (chain)"
+    if "qrfac_trail" in k: return "refresh: qrfac_trail (chain)"
+    return "refresh: qform" if re.search(r"factor_fast_kernel<\d+, \d+, 2>", k) else "refresh: qrfac (single launch)"
 def rows(d, pat):
     f = sorted(glob.glob("gpurun_out/%s/**/*%s" % (d, pat), recursive=True))
     return list(csv.DictReader(open(f[-1]))) if f else []
 dur = {}
 for r in rows("pt_stats", "kernel_trace.csv"):
     k = r["Kernel_Name"]
-    if "advance_kernel" in k or "factor_fast" in k:
-        key = ("advance<%s>" % k.split("advance_kernel<")[1].split(">")[0]) if "advance_kernel" in k else "factor_fast"
-        if int(r["Grid_Size_X"]) >= 64 * P:
+    if "advance_kernel" in k or "factor_fast" in k or "qrfac_" in k:
+        key = ("advance<%s>" % k.split("advance_kernel<")[1].split(">")[0]) if "advance_kernel" in k else kind_of(k)
+        if int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"])) >= P:
             dur.setdefault(key, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6)
 pmc = {}
 for d, name in (("pt_fetch", "FETCH_SIZE"), ("pt_write", "WRITE_SIZE")):
     for r in rows(d, "counter_collection.csv"):
         k = r["Kernel_Name"]
-        if ("advance_kernel" in k or "factor_fast" in k) and float(r["Grid_Size"]) >= 64 * P and r["Counter_Name"] == name:
-            key = ("advance<%s>" % k.split("advance_kernel<")[1].split(">")[0]) if "advance_kernel" in k else "factor_fast"
+        if ("advance_kernel" in k or "factor_fast" in k or "qrfac_" in k) and float(r["Grid_Size"]) / max(1.0, float(r["Workgroup_Size"])) >= P and r["Counter_Name"] == name:
+            key = ("advance<%s>" % k.split("advance_kernel<")[1].split(">")[0]) if "advance_kernel" in k else kind_of(k)
             pmc.setdefault(key, {}).setdefault(name, []).append(float(r["Counter_Value"]))
 out = {"tag": tag, "command": "python3 -m socp_amd.sweep --model interceptor --starts 2048 --solver device_fast", "n": n, "problems": P,
        "note": "launches over all 2048 problems only; bytes = 2 x FETCH_SIZE KiB + WRITE_SIZE KiB (MI355X_MICROARCH.md); per-launch lists in dispatch order",
