@@ -1103,38 +1103,55 @@ template <> struct ChainBudget<6> { static constexpr int panel = SOCP_FACTOR_PAN
 template <> struct ChainBudget<4> { static constexpr int panel = SOCP_FACTOR_PANEL_WPE4, trail = 4; };
 
 template <int NCH>
-hipError_t launch_pair(hipStream_t st, const PoolDev &pool, const int *d_list, int count, int pp, bool has_trail, bool last_pair)
+hipError_t launch_panel(hipStream_t st, const PoolDev &pool, const int *d_list, int count, int pp, bool final_launch)
 {
-    {
-        const size_t lds_bytes = sizeof(double) * (size_t)(16 * NCH * kLdV + 512);
-        hipLaunchKernelGGL((qrfac_panel_kernel<NCH, ChainBudget<NCH>::panel>), dim3((unsigned)count), dim3(64), lds_bytes, st, pool.cfg, pool.states, pool.ws,
-                           pool.ws_stride, d_list, count, pp, (last_pair && !has_trail) ? 1 : 0);
-        const hipError_t e = hipGetLastError();
-        if (e != hipSuccess || !has_trail) return e;
-    }
+    const size_t lds_bytes = sizeof(double) * (size_t)(16 * NCH * kLdV + 512);
+    hipLaunchKernelGGL((qrfac_panel_kernel<NCH, ChainBudget<NCH>::panel>), dim3((unsigned)count), dim3(64), lds_bytes, st, pool.cfg, pool.states, pool.ws,
+                       pool.ws_stride, d_list, count, pp, final_launch ? 1 : 0);
+    return hipGetLastError();
+}
+template <int NCH>
+hipError_t launch_trail(hipStream_t st, const PoolDev &pool, const int *d_list, int count, int pp, bool final_launch)
+{
     const size_t lds_bytes = sizeof(double) * (size_t)(2 * (16 * NCH * kLdV + 256));
     if (lds_bytes > 65536) {
         const hipError_t raised = raise_lds_limit_fast<qrfac_trail_kernel<NCH, ChainBudget<NCH>::trail>>();
         if (raised != hipSuccess) return raised;
     }
     hipLaunchKernelGGL((qrfac_trail_kernel<NCH, ChainBudget<NCH>::trail>), dim3((unsigned)count), dim3(256), lds_bytes, st, pool.cfg, pool.states, pool.ws,
-                       pool.ws_stride, d_list, count, pp, last_pair ? 1 : 0);
+                       pool.ws_stride, d_list, count, pp, final_launch ? 1 : 0);
     return hipGetLastError();
+}
+// one launch of the chain at the strip height pair pp needs (chunks from panel pp's first row down to the matrix's last row)
+hipError_t launch_chain_step(bool trail, hipStream_t st, const PoolDev &pool, const int *d_list, int count, int pp, bool final_launch)
+{
+    const int nch = (pool.cfg.n - 16 * pp + 15) >> 4;
+#define SOCP_CHAIN_STEP(NCH) (trail ? launch_trail<NCH>(st, pool, d_list, count, pp, final_launch) : launch_panel<NCH>(st, pool, d_list, count, pp, final_launch))
+    if (nch <= 4) return SOCP_CHAIN_STEP(4);
+    if (nch <= 6) return SOCP_CHAIN_STEP(6);
+    if (nch <= 8) return SOCP_CHAIN_STEP(8);
+    if (nch <= 12) return SOCP_CHAIN_STEP(12);
+    return SOCP_CHAIN_STEP(16);
+#undef SOCP_CHAIN_STEP
+}
+
+struct PairPlan {
+    bool has_trail, last_pair;
+};
+PairPlan plan_of(int n, int pp)
+{
+    const int npanels = (n + 15) >> 4, j0 = 16 * pp;
+    const bool two = pp + 1 < npanels;
+    return {j0 + (two ? 32 : 16) <= n, pp + 2 >= npanels};
 }
 
 hipError_t launch_qrfac_chain(hipStream_t st, const PoolDev &pool, const int *d_list, int count)
 {
     const int n = pool.cfg.n, npanels = (n + 15) >> 4;
     for (int pp = 0; pp < npanels; pp += 2) {
-        const int j0 = 16 * pp, nch = (n - j0 + 15) >> 4;
-        const bool two = pp + 1 < npanels, has_trail = j0 + (two ? 32 : 16) <= n, last_pair = pp + 2 >= npanels;
-        // the strip height this pair needs (chunks from panel pp's first row down to the matrix's last row)
-        hipError_t e;
-        if (nch <= 4) e = launch_pair<4>(st, pool, d_list, count, pp, has_trail, last_pair);
-        else if (nch <= 6) e = launch_pair<6>(st, pool, d_list, count, pp, has_trail, last_pair);
-        else if (nch <= 8) e = launch_pair<8>(st, pool, d_list, count, pp, has_trail, last_pair);
-        else if (nch <= 12) e = launch_pair<12>(st, pool, d_list, count, pp, has_trail, last_pair);
-        else e = launch_pair<16>(st, pool, d_list, count, pp, has_trail, last_pair);
+        const PairPlan pl = plan_of(n, pp);
+        hipError_t e = launch_chain_step(false, st, pool, d_list, count, pp, pl.last_pair && !pl.has_trail);
+        if (e == hipSuccess && pl.has_trail) e = launch_chain_step(true, st, pool, d_list, count, pp, pl.last_pair);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
@@ -1160,6 +1177,10 @@ int chain_min_problems()
 template <int NCH, int WPE>
 hipError_t launch_nch(hipStream_t st, const PoolDev &pool, const int *d_list, int count)
 {
+    // (Tried on top and not kept: the chain for two halves of the launch's problems on two streams, a half's panel launch -- vector ALUs,
+    // latency -- beside the other half's trailing launch -- memory, matrix cores --, with the trailing launches alternating through events or
+    // the two chains running free: 4.62-4.68 resp. 4.34-4.36 ms against 4.33-4.36 at 2048 x n = 253, +3 ... +7 % at n = 85 / 127
+    // (profiles/r06_factor_halves_ab.txt): what the two kinds of launch do not share in execution units they share in LDS and registers.)
     const hipError_t e = count >= chain_min_problems() ? launch_qrfac_chain(st, pool, d_list, count) : launch_phase<NCH, WPE, 1>(st, pool, d_list, count);
     return e != hipSuccess ? e : launch_phase<NCH, WPE, 2>(st, pool, d_list, count);
 }
