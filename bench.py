@@ -51,7 +51,9 @@ Objects in the JSON line beside the contract's fields (N = 1; `--lean` drops the
                   from the published algorithm / the reference's text).  `predicted` / `expected` from its own one-GPU curve.
   solver_kernels  the sweeps' second kernel with a roofline of its own: factor_fast = 2048 Jacobian refreshes of n = 253 (the factor
                   launch of a config-5 round) on the FP64 matrix cores, HIP-event time, fraction of the FP64 peak; traffic = the
-                  counters of this run as above (its two launches summed), the recorded figure (profiles/r06_factor_pmc.json) beside it.
+                  counters of this run as above (a refresh is a chain of launches -- qrfac's panel and trailing launches per pair of panels,
+                  then qform: every dispatch of the child's two refreshes summed, halved), the recorded figure
+                  (profiles/r06_factor_pmc.json) beside it.
   cpu_baseline    B1: the reference's own model::ComputeTraj (oracle/_ref, kind "reference") or the C oracle (kind
                   "port") on this box's host cores, bounded sample: `value` = MEDIAN of five samples, `spread`, `best`,
                   `worst`, `samples` beside it (all cores and one core).  cpu_baseline.b0 = "as shipped": the reference's
